@@ -1,0 +1,74 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_names(prefixes=("f1", "f2", "f3", "f4", "f5", "f6")):
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLD, "*.npz"))):
+        n = os.path.basename(p)[:-4]
+        if n.split("_")[0] in prefixes:
+            out.append(n)
+    return out
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    d = {k: z[k] for k in z.files}
+    for k in ("n_train", "n_test", "g", "m", "t", "approx", "max_iters", "skip_variance", "seed"):
+        if k in d:
+            d[k] = int(d[k])
+    if "delta" in d:
+        d["delta"] = float(d["delta"])
+    for k in ("tri_sha256", "counts_sha256", "data"):
+        if k in d:
+            d[k] = str(d[k])
+    return d
+
+
+def load_tokens(data):
+    z = np.load(os.path.join(GOLD, "tokens_%s.npz" % data))
+    return (z["tokens"].astype(np.int32), z["offsets"].astype(np.int64), int(z["n_train"]),
+            int(z["n_test"]), z["y_train"], z["y_test"])
+
+
+def tri_to_square(tri, N):
+    full = np.zeros((N, N), dtype=tri.dtype)
+    il = np.tril_indices(N)
+    full[il] = tri
+    full.T[il] = tri
+    return full
+
+
+def synthetic_dna(N, L, seed=20201214):
+    """BASELINE config 5 generator: tokens 1..4, i.i.d. uniform."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    X = rng.integers(1, 5, size=(N, L), dtype=np.int32)
+    offsets = np.arange(N + 1, dtype=np.int64) * L
+    return X.reshape(-1).copy(), offsets
+
+
+@pytest.fixture(scope="session")
+def port():
+    from oracle import loader
+    return loader.port()
+
+
+@pytest.fixture(scope="session")
+def ref():
+    from oracle import loader
+    if not loader.have_ref():
+        pytest.skip("compiled reference (oracle/_ref) not present")
+    return loader.ref()
