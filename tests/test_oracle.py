@@ -94,7 +94,7 @@ def test_combo_table_is_lexicographic(port):
     for g, k in [(3, 1), (5, 2), (10, 4), (12, 4), (14, 4), (7, 7)]:
         want = list(itertools.combinations(range(g), k))
         assert port.num_combos(g, g - k) == len(want)
-        for c in (0, 1, len(want) // 2, len(want) - 1):
+        for c in {0, min(1, len(want) - 1), len(want) // 2, len(want) - 1}:
             assert tuple(port.combo_positions(g, k, c)) == want[c]
 
 
