@@ -1,0 +1,269 @@
+"""ctypes view of the C ABI in ``include/fastsk_amd.h`` (``libfastsk_amd.so``).
+
+Used by the staged / multi-GPU host code (``fastsk_amd.distributed``), ``bench.py`` and the parity
+tests; the drop-in ``FastSK`` class itself is the pybind11 module ``fastsk_amd._fastsk`` built on
+the same library. There is no CPU fallback: if the HIP library is missing this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfastsk_amd.so")
+
+PATH_AUTO, PATH_DENSE, PATH_SPARSE = 0, 1, 2
+
+ERRORS = {-1: "FSK_EINVAL", -2: "FSK_ESHORT", -3: "FSK_ESTATE", -4: "FSK_EDEVICE", -5: "FSK_ENOMEM",
+          -6: "FSK_EUNSUPPORTED"}
+
+
+class FskError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERRORS.get(code, "FSK_E?"), code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("g", C.c_int32), ("m", C.c_int32), ("t", C.c_int32), ("approx", C.c_int32),
+                ("delta", C.c_double), ("max_iters", C.c_int32), ("skip_variance", C.c_int32),
+                ("device", C.c_int32), ("path", C.c_int32), ("profile", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_seq", C.c_int64), ("n_train", C.c_int64), ("n_test", C.c_int64), ("n_feat", C.c_int64),
+                ("n_pairs", C.c_int64), ("alphabet", C.c_int32), ("bits_per_symbol", C.c_int32),
+                ("key_space", C.c_int64), ("path_used", C.c_int32), ("n_combos_total", C.c_int32),
+                ("combos_done", C.c_int64), ("cell_updates", C.c_uint64), ("sort_records", C.c_uint64),
+                ("sort_passes", C.c_int32), ("launches", C.c_int32), ("ms_count", C.c_double),
+                ("ms_tile", C.c_double), ("ms_extract", C.c_double), ("ms_sort", C.c_double),
+                ("ms_segment", C.c_double), ("ms_pairs", C.c_double), ("ms_total", C.c_double),
+                ("n_tile_launches", C.c_int64), ("dense_macs", C.c_uint64), ("panel_bytes", C.c_uint64),
+                ("reserved", C.c_double * 6)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+# every symbol include/fastsk_amd.h declares (checked by tests/test_abi.py)
+SYMBOLS = ["fsk_create", "fsk_destroy", "fsk_last_error", "fsk_abi_version", "fsk_device_count", "fsk_compute",
+           "fsk_set_combo_order", "fsk_set_seed", "fsk_load_sequences", "fsk_bind_counts",
+           "fsk_counts_device_ptr", "fsk_reset_counts", "fsk_accumulate", "fsk_synchronize", "fsk_finalize",
+           "fsk_get_block", "fsk_get_train", "fsk_get_test", "fsk_get_triangle", "fsk_get_counts",
+           "fsk_get_counts_block", "fsk_get_stdevs", "fsk_save_kernel", "fsk_get_stats", "fsk_num_combos",
+           "fsk_combo_positions"]
+
+
+class Library:
+    """The loaded shared library with typed entry points."""
+
+    def __init__(self, path=None):
+        path = path or LIB_PATH
+        if not os.path.exists(path):
+            raise ImportError(
+                "%s not found: build the HIP engine first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "fastsk_amd has no CPU fallback." % path)
+        L = C.CDLL(path)
+        self.path = path
+        vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+        sig = {
+            "fsk_create": ([C.POINTER(Config), C.POINTER(vp)], C.c_int),
+            "fsk_destroy": ([vp], None),
+            "fsk_last_error": ([vp], C.c_char_p),
+            "fsk_abi_version": ([], C.c_int),
+            "fsk_device_count": ([], C.c_int),
+            "fsk_compute": ([vp, vp, vp, i64, i64], C.c_int),
+            "fsk_set_combo_order": ([vp, vp, i32], C.c_int),
+            "fsk_set_seed": ([vp, C.c_uint64], C.c_int),
+            "fsk_load_sequences": ([vp, vp, vp, i64, i64], C.c_int),
+            "fsk_bind_counts": ([vp, vp, i64], C.c_int),
+            "fsk_counts_device_ptr": ([vp, C.POINTER(vp)], C.c_int),
+            "fsk_reset_counts": ([vp], C.c_int),
+            "fsk_accumulate": ([vp, vp, i32], C.c_int),
+            "fsk_synchronize": ([vp], C.c_int),
+            "fsk_finalize": ([vp], C.c_int),
+            "fsk_get_block": ([vp, i64, i64, i64, i64, vp], C.c_int),
+            "fsk_get_train": ([vp, vp], C.c_int),
+            "fsk_get_test": ([vp, vp], C.c_int),
+            "fsk_get_triangle": ([vp, vp], C.c_int),
+            "fsk_get_counts": ([vp, vp], C.c_int),
+            "fsk_get_counts_block": ([vp, i64, i64, i64, i64, vp], C.c_int),
+            "fsk_get_stdevs": ([vp, vp, i32, C.POINTER(i32)], C.c_int),
+            "fsk_save_kernel": ([vp, C.c_char_p], C.c_int),
+            "fsk_get_stats": ([vp, C.POINTER(Stats)], C.c_int),
+            "fsk_num_combos": ([i32, i32], i64),
+            "fsk_combo_positions": ([i32, i32, i64, vp], C.c_int),
+        }
+        for name, (argtypes, restype) in sig.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        self.L = L
+
+    def num_combos(self, g, m):
+        return int(self.L.fsk_num_combos(g, m))
+
+    def combo_positions(self, g, k, combo):
+        out = np.zeros(k, dtype=np.int32)
+        rc = self.L.fsk_combo_positions(g, k, combo, out.ctypes.data)
+        if rc:
+            raise FskError(rc, "bad combination id")
+        return out
+
+    def device_count(self):
+        return int(self.L.fsk_device_count())
+
+
+_default = None
+
+
+def library():
+    """The product library (hipcc build). Raises ImportError when it has not been built."""
+    global _default
+    if _default is None:
+        _default = Library()
+    return _default
+
+
+def flatten(X):
+    """Nested int sequences (or a 2-D array) -> (tokens int32, offsets int64)."""
+    if isinstance(X, np.ndarray) and X.ndim == 2:
+        n, L = X.shape
+        return np.ascontiguousarray(X, dtype=np.int32).reshape(-1), np.arange(n + 1, dtype=np.int64) * L
+    lens = np.fromiter((len(x) for x in X), dtype=np.int64, count=len(X))
+    offsets = np.zeros(len(X) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    tokens = np.empty(int(offsets[-1]), dtype=np.int32)
+    for i, x in enumerate(X):
+        tokens[offsets[i]:offsets[i + 1]] = x
+    return tokens, offsets
+
+
+class Engine:
+    """One engine handle = one device, one HIP stream. Mirrors the C ABI one to one."""
+
+    def __init__(self, g, m, t=-1, approx=False, delta=0.025, max_iters=-1, skip_variance=False, device=0,
+                 path=PATH_AUTO, profile=False, lib=None):
+        self.lib = lib or library()
+        cfg = Config(g=g, m=m, t=t, approx=int(bool(approx)), delta=delta, max_iters=max_iters,
+                     skip_variance=int(bool(skip_variance)), device=device, path=path, profile=int(bool(profile)))
+        h = C.c_void_p()
+        rc = self.lib.L.fsk_create(C.byref(cfg), C.byref(h))
+        if rc:
+            raise FskError(rc, (self.lib.L.fsk_last_error(None) or b"").decode())
+        self.h = h
+        self.g, self.m = g, m
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.L.fsk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc:
+            raise FskError(rc, (self.lib.L.fsk_last_error(self.h) or b"").decode())
+
+    # ---- inputs
+    @staticmethod
+    def _prep(tokens, offsets):
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        return tokens, offsets
+
+    def compute(self, tokens, offsets, n_train, n_test):
+        tokens, offsets = self._prep(tokens, offsets)
+        self.N, self.n_train, self.n_test = n_train + n_test, n_train, n_test
+        self._ck(self.lib.L.fsk_compute(self.h, tokens.ctypes.data, offsets.ctypes.data, n_train, n_test))
+
+    def load_sequences(self, tokens, offsets, n_train, n_test):
+        tokens, offsets = self._prep(tokens, offsets)
+        self.N, self.n_train, self.n_test = n_train + n_test, n_train, n_test
+        self._ck(self.lib.L.fsk_load_sequences(self.h, tokens.ctypes.data, offsets.ctypes.data, n_train, n_test))
+
+    def set_combo_order(self, order):
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        self._ck(self.lib.L.fsk_set_combo_order(self.h, order.ctypes.data, len(order)))
+
+    def set_seed(self, seed):
+        self._ck(self.lib.L.fsk_set_seed(self.h, seed))
+
+    # ---- staged path
+    def bind_counts(self, device_ptr, n_cells, keepalive=None):
+        self._keep = keepalive
+        self._ck(self.lib.L.fsk_bind_counts(self.h, C.c_void_p(device_ptr), n_cells))
+
+    def counts_device_ptr(self):
+        p = C.c_void_p()
+        self._ck(self.lib.L.fsk_counts_device_ptr(self.h, C.byref(p)))
+        return p.value
+
+    def reset_counts(self):
+        self._ck(self.lib.L.fsk_reset_counts(self.h))
+
+    def accumulate(self, combos):
+        combos = np.ascontiguousarray(combos, dtype=np.int32)
+        self._ck(self.lib.L.fsk_accumulate(self.h, combos.ctypes.data, len(combos)))
+
+    def synchronize(self):
+        self._ck(self.lib.L.fsk_synchronize(self.h))
+
+    def finalize(self):
+        self._ck(self.lib.L.fsk_finalize(self.h))
+
+    # ---- results
+    @property
+    def pairs(self):
+        return self.N * (self.N + 1) // 2
+
+    def get_block(self, i0, i1, j0, j1):
+        out = np.empty((i1 - i0, j1 - j0), dtype=np.float64)
+        self._ck(self.lib.L.fsk_get_block(self.h, i0, i1, j0, j1, out.ctypes.data))
+        return out
+
+    def get_train(self):
+        out = np.empty((self.n_train, self.n_train), dtype=np.float64)
+        self._ck(self.lib.L.fsk_get_train(self.h, out.ctypes.data))
+        return out
+
+    def get_test(self):
+        out = np.empty((self.n_test, self.n_train), dtype=np.float64)
+        self._ck(self.lib.L.fsk_get_test(self.h, out.ctypes.data))
+        return out
+
+    def get_triangle(self):
+        out = np.empty(self.pairs, dtype=np.float64)
+        self._ck(self.lib.L.fsk_get_triangle(self.h, out.ctypes.data))
+        return out
+
+    def get_counts(self):
+        out = np.empty(self.pairs, dtype=np.uint64)
+        self._ck(self.lib.L.fsk_get_counts(self.h, out.ctypes.data))
+        return out
+
+    def get_counts_block(self, i0, i1, j0, j1):
+        out = np.empty((i1 - i0, j1 - j0), dtype=np.uint64)
+        self._ck(self.lib.L.fsk_get_counts_block(self.h, i0, i1, j0, j1, out.ctypes.data))
+        return out
+
+    def get_stdevs(self):
+        n = C.c_int32(0)
+        self._ck(self.lib.L.fsk_get_stdevs(self.h, None, 0, C.byref(n)))
+        out = np.empty(max(n.value, 1), dtype=np.float64)
+        self._ck(self.lib.L.fsk_get_stdevs(self.h, out.ctypes.data, n.value, C.byref(n)))
+        return out[:n.value]
+
+    def save_kernel(self, path):
+        self._ck(self.lib.L.fsk_save_kernel(self.h, path.encode()))
+
+    def stats(self):
+        s = Stats()
+        self._ck(self.lib.L.fsk_get_stats(self.h, C.byref(s)))
+        return s.as_dict()

@@ -1,0 +1,193 @@
+// bindings.cpp — pybind11 module `fastsk_amd._fastsk`: the reference's Python surface
+// (QData/FastSK src/fastsk/_fastsk/bindings.cpp:12-51) on top of the C ABI in
+// include/fastsk_amd.h. Same class name, constructor keywords and defaults, method names and
+// return types; host C++ only — all computation happens behind fsk_* in libfastsk_amd.so.
+//
+// Deviations, all documented in INTEGRATION.md:
+//   - errors raise ValueError / RuntimeError instead of printf + exit(1) (fastsk.cpp:53-58);
+//   - fit() / score() (LIBSVM, fastsk.cpp:239-530) are outside this path and raise
+//     NotImplementedError (they are unusable from Python in the reference as well);
+//   - additive keyword arguments (device, path, seed, quiet) and numpy getters.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/fastsk_amd.h"
+
+namespace py = pybind11;
+
+namespace {
+
+struct Flat {
+    std::vector<int32_t> tokens;
+    std::vector<int64_t> offsets{0};
+    void add(const std::vector<std::vector<int>>& X) {
+        size_t total = tokens.size();
+        for (auto& r : X) total += r.size();
+        tokens.reserve(total);
+        for (auto& r : X) {
+            tokens.insert(tokens.end(), r.begin(), r.end());
+            offsets.push_back((int64_t)tokens.size());
+        }
+    }
+};
+
+int parse_path(const std::string& p) {
+    if (p == "auto") return FSK_PATH_AUTO;
+    if (p == "dense") return FSK_PATH_DENSE;
+    if (p == "sparse") return FSK_PATH_SPARSE;
+    throw std::invalid_argument("path must be 'auto', 'dense' or 'sparse'");
+}
+
+class FastSK {
+    fsk_engine* h_ = nullptr;
+    int64_t n_train_ = 0, n_test_ = 0;
+    bool computed_ = false;
+
+    void check(int rc) const {
+        if (rc == FSK_OK) return;
+        std::string msg = fsk_last_error(h_);
+        if (rc == FSK_EINVAL || rc == FSK_ESHORT) throw py::value_error(msg);
+        throw std::runtime_error(msg);
+    }
+    void run(const Flat& f, int64_t n_train, int64_t n_test) {
+        int rc;
+        {
+            py::gil_scoped_release nogil;  // the reference holds the GIL for the whole call
+            rc = fsk_compute(h_, f.tokens.data(), f.offsets.data(), n_train, n_test);
+        }
+        check(rc);
+        n_train_ = n_train;
+        n_test_ = n_test;
+        computed_ = true;
+    }
+    py::array_t<double> block(bool test) const {
+        if (!computed_) throw std::runtime_error("call compute_kernel or compute_train first");
+        const int64_t rows = test ? n_test_ : n_train_;
+        py::array_t<double> out({(py::ssize_t)rows, (py::ssize_t)n_train_});
+        if (rows > 0) check(test ? fsk_get_test(h_, out.mutable_data()) : fsk_get_train(h_, out.mutable_data()));
+        return out;
+    }
+    static std::vector<std::vector<double>> to_lists(const py::array_t<double>& a) {
+        const py::ssize_t r = a.shape(0), c = a.shape(1);
+        std::vector<std::vector<double>> v((size_t)r);
+        const double* p = a.data();
+        for (py::ssize_t i = 0; i < r; ++i) v[(size_t)i].assign(p + i * c, p + (i + 1) * c);
+        return v;
+    }
+
+public:
+    FastSK(int g, int m, int t, bool approx, double delta, int max_iters, bool skip_variance, int device,
+           const std::string& path, py::object seed) {
+        fsk_config c{};
+        c.g = g; c.m = m; c.t = t; c.approx = approx; c.delta = delta; c.max_iters = max_iters;
+        c.skip_variance = skip_variance; c.device = device; c.path = parse_path(path);
+        int rc = fsk_create(&c, &h_);
+        if (rc != FSK_OK) {
+            std::string msg = fsk_last_error(nullptr);
+            if (rc == FSK_EINVAL) throw py::value_error(msg);
+            throw std::runtime_error(msg);
+        }
+        if (!seed.is_none()) check(fsk_set_seed(h_, seed.cast<uint64_t>()));
+    }
+    ~FastSK() { fsk_destroy(h_); }
+    FastSK(const FastSK&) = delete;
+    FastSK& operator=(const FastSK&) = delete;
+
+    // FastSK::compute_kernel, fastsk.cpp:30-118 (arguments copied by value, as there)
+    void compute_kernel(std::vector<std::vector<int>> Xtrain, std::vector<std::vector<int>> Xtest) {
+        if (Xtrain.empty() || Xtest.empty()) throw py::value_error("Xtrain and Xtest must be non-empty (use compute_train for train only)");
+        Flat f;
+        f.add(Xtrain);
+        f.add(Xtest);
+        run(f, (int64_t)Xtrain.size(), (int64_t)Xtest.size());
+    }
+    // FastSK::compute_train, fastsk.cpp:120-188
+    void compute_train(std::vector<std::vector<int>> Xtrain) {
+        if (Xtrain.empty()) throw py::value_error("Xtrain must be non-empty");
+        Flat f;
+        f.add(Xtrain);
+        run(f, (int64_t)Xtrain.size(), 0);
+    }
+    std::vector<std::vector<double>> get_train_kernel() const { return to_lists(block(false)); }  // fastsk.cpp:190-200
+    std::vector<std::vector<double>> get_test_kernel() const { return to_lists(block(true)); }    // fastsk.cpp:202-217
+    py::array_t<double> get_train_kernel_np() const { return block(false); }
+    py::array_t<double> get_test_kernel_np() const { return block(true); }
+    std::vector<double> get_stdevs() const {  // fastsk.cpp:219-221
+        int32_t n = 0;
+        check(fsk_get_stdevs(h_, nullptr, 0, &n));
+        std::vector<double> v((size_t)n);
+        if (n) check(fsk_get_stdevs(h_, v.data(), n, &n));
+        return v;
+    }
+    void save_kernel(const std::string& path) const { check(fsk_save_kernel(h_, path.c_str())); }  // fastsk.cpp:223-237
+    void set_combo_order(std::vector<int32_t> order) { check(fsk_set_combo_order(h_, order.data(), (int32_t)order.size())); }
+    py::array_t<double> get_block(int64_t i0, int64_t i1, int64_t j0, int64_t j1) const {
+        if (i1 < i0 || j1 < j0) throw py::value_error("empty block");
+        py::array_t<double> out({(py::ssize_t)(i1 - i0), (py::ssize_t)(j1 - j0)});
+        check(fsk_get_block(h_, i0, i1, j0, j1, out.mutable_data()));
+        return out;
+    }
+    py::array_t<uint64_t> get_counts_np() const {
+        if (!computed_) throw std::runtime_error("call compute_kernel or compute_train first");
+        const int64_t N = n_train_ + n_test_;
+        py::array_t<uint64_t> out((py::ssize_t)(N * (N + 1) / 2));
+        check(fsk_get_counts(h_, out.mutable_data()));
+        return out;
+    }
+    py::dict stats() const {
+        fsk_stats s;
+        check(fsk_get_stats(h_, &s));
+        py::dict d;
+        d["n_seq"] = s.n_seq; d["n_feat"] = s.n_feat; d["n_pairs"] = s.n_pairs; d["alphabet"] = s.alphabet;
+        d["bits_per_symbol"] = s.bits_per_symbol; d["key_space"] = s.key_space;
+        d["path_used"] = s.path_used == FSK_PATH_DENSE ? "dense" : "sparse";
+        d["n_combos_total"] = s.n_combos_total; d["combos_done"] = s.combos_done;
+        d["cell_updates"] = s.cell_updates; d["launches"] = s.launches;
+        return d;
+    }
+    void fit(double, double, double, const std::string&) const {
+        PyErr_SetString(PyExc_NotImplementedError,
+                        "fit(): the LIBSVM stage is outside the accelerated path; feed get_train_kernel() to scikit-learn "
+                        "as the reference's own pipeline does (test/run_check.py:48-61)");
+        throw py::error_already_set();
+    }
+    double score(const std::string&) const {
+        PyErr_SetString(PyExc_NotImplementedError, "score(): see fit()");
+        throw py::error_already_set();
+    }
+};
+
+}  // namespace
+
+PYBIND11_MODULE(_fastsk, m) {
+    m.doc() = "MI355X-native gapped-k-mer kernel engine behind the FastSK Python surface";
+    py::class_<FastSK>(m, "FastSK")
+        .def(py::init<int, int, int, bool, double, int, bool, int, const std::string&, py::object>(),
+             py::arg("g"), py::arg("m"), py::arg("t") = -1, py::arg("approx") = false, py::arg("delta") = 0.025,
+             py::arg("max_iters") = -1, py::arg("skip_variance") = false, py::arg("device") = 0,
+             py::arg("path") = "auto", py::arg("seed") = py::none())
+        .def("compute_kernel", &FastSK::compute_kernel, py::arg("Xtrain"), py::arg("Xtest"))
+        .def("compute_train", &FastSK::compute_train, py::arg("Xtrain"))
+        .def("get_train_kernel", &FastSK::get_train_kernel)
+        .def("get_test_kernel", &FastSK::get_test_kernel)
+        .def("get_stdevs", &FastSK::get_stdevs)
+        .def("save_kernel", &FastSK::save_kernel)
+        .def("fit", &FastSK::fit, py::arg("C") = 1.0, py::arg("nu") = 0.5, py::arg("eps") = 0.001,
+             py::arg("kernel_type") = "linear")
+        .def("score", &FastSK::score, py::arg("metric") = "auc")
+        // additive, non-breaking extras
+        .def("get_train_kernel_np", &FastSK::get_train_kernel_np)
+        .def("get_test_kernel_np", &FastSK::get_test_kernel_np)
+        .def("get_block", &FastSK::get_block, py::arg("i0"), py::arg("i1"), py::arg("j0"), py::arg("j1"))
+        .def("get_counts_np", &FastSK::get_counts_np)
+        .def("set_combo_order", &FastSK::set_combo_order, py::arg("order"))
+        .def("stats", &FastSK::stats);
+    m.attr("__version__") = "dev";
+    m.attr("abi_version") = fsk_abi_version();
+}

@@ -1,0 +1,880 @@
+// fsk_engine.hip — host side of the C ABI declared in include/fastsk_amd.h.
+//
+// Replaces, for the kernel-construction path only, the reference's host driver
+// (FastSK::compute_kernel / compute_train, fastsk.cpp:30-188), its engine
+// (KernelFunction::compute_kernel / kernel_build_parallel / get_variance,
+// fastsk_kernel.cpp:24-322) and the getters (fastsk.cpp:190-237). No CPU compute fallback lives
+// here: every count is produced by the HIP kernels of fsk_kernels.h, and construction fails
+// loudly when no device is usable.
+#include "fsk_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fastsk_amd.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+#define FSK_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (call);                                                                \
+        if (_e != hipSuccess) return e->fail(FSK_EDEVICE, "%s failed: %s", #call, hipGetErrorString(_e)); \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t r = hipMalloc((void**)&p, n * sizeof(T));
+        if (r == hipSuccess) cap = n;
+        return r;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct PhaseTimer;
+
+}  // namespace
+
+struct fsk_engine {
+    fsk_config cfg{};
+    std::string err;
+    int k = 0;
+    int64_t ncomb = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // sequences
+    bool loaded = false, finalized = false, result_f64 = false;
+    int64_t N = 0, n_train = 0, n_test = 0, nfeat = 0, pairs = 0;
+    uint32_t sigma = 0, Lmax = 0, Lmin = 0, maxW = 0, Vq = 0, n_panels = 0;
+    int bits = 0;
+    u64 V = 0;
+    int path = 0;
+    DevBuf<uint32_t> d_words, d_wstart, d_len, d_fstart, d_featseq;
+    std::vector<uint32_t> h_len, h_fstart;
+    bool featseq_ready = false;
+
+    // combos
+    std::vector<uint8_t> all_pos;  // [ncomb][k]
+    DevBuf<uint8_t> d_pos;
+    std::vector<int32_t> order;
+    bool order_set = false;
+    uint64_t seed = 0;
+    std::vector<double> stdevs;
+
+    // counts / results
+    u64* d_K = nullptr;
+    bool K_owned = false;
+    int64_t bound_cells = 0;
+    DevBuf<u64> K_store;
+    DevBuf<double> d_Kf64, d_Khat, d_prod, d_diag, d_stage;
+    DevBuf<u64> d_stage_u64;
+
+    // dense scratch
+    DevBuf<uint32_t> d_C, d_flag;
+    // sparse scratch
+    DevBuf<unsigned char> d_keys[2];
+    DevBuf<uint32_t> d_vals[2], d_blockhist, d_totals, d_estart, d_eseq, d_erun, d_rstart, d_segtot;
+    DevBuf<u64> d_blocksum, d_U;
+
+    fsk_stats st{};
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+    fsk::SeqView view() const {
+        return fsk::SeqView{d_words.p, d_wstart.p, d_len.p, (uint32_t)N, bits};
+    }
+    void tic() {
+        if (cfg.profile) (void)hipEventRecord(ev0, stream);
+    }
+    void toc(double* acc) {
+        if (!cfg.profile) return;
+        (void)hipEventRecord(ev1, stream);
+        (void)hipEventSynchronize(ev1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ev0, ev1);
+        *acc += ms;
+    }
+};
+
+namespace {
+
+int64_t n_choose_k(int n, int k) {  // nchoosek, shared.cpp:335-345 (exact in 64 bits)
+    if (k < 0 || k > n) return 0;
+    if (k * 2 > n) k = n - k;
+    int64_t r = 1;
+    for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+    return r;
+}
+
+// all k-subsets of {0..g-1}, lexicographic (getCombinations, shared.cpp:347-360)
+void enumerate_combos(int g, int k, std::vector<uint8_t>& out) {
+    std::vector<int> pos(k);
+    for (int i = 0; i < k; ++i) pos[i] = i;
+    out.clear();
+    while (true) {
+        for (int i = 0; i < k; ++i) out.push_back((uint8_t)pos[i]);
+        int i = k - 1;
+        while (i >= 0 && pos[i] == g - k + i) --i;
+        if (i < 0) break;
+        ++pos[i];
+        for (int j = i + 1; j < k; ++j) pos[j] = pos[j - 1] + 1;
+    }
+}
+
+uint64_t splitmix64(uint64_t& s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+constexpr size_t LDS_BUDGET = 150 * 1024;       // of 160 KiB per CU
+constexpr u64 DENSE_MAX_KEYS = 1024;            // beyond this the count panels are mostly zeros
+constexpr size_t SPARSE_MAX_RECORDS = 1u << 25; // records per sort batch
+
+size_t dense_lds_bytes(uint32_t Lmax, uint32_t Vq) { return (size_t)Lmax * fsk::PANEL + (size_t)Vq * 512; }
+
+int choose_path(fsk_engine* e) {
+    bool dense_ok = e->V <= DENSE_MAX_KEYS && e->Lmax < 65536 && dense_lds_bytes(e->Lmax, e->Vq) <= LDS_BUDGET;
+    if (e->cfg.path == FSK_PATH_DENSE) {
+        if (!dense_ok)
+            return e->fail(FSK_EUNSUPPORTED, "dense path needs alphabet^k <= %llu and the panel histogram to fit in LDS",
+                           (unsigned long long)DENSE_MAX_KEYS);
+        e->path = FSK_PATH_DENSE;
+    } else if (e->cfg.path == FSK_PATH_SPARSE) {
+        e->path = FSK_PATH_SPARSE;
+    } else {
+        e->path = dense_ok ? FSK_PATH_DENSE : FSK_PATH_SPARSE;
+    }
+    return FSK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sparse dataflow for a batch of combos (composite key = slot * V + k-mer)
+template <typename KeyT>
+int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K) {
+    const size_t nrec = (size_t)nb * (size_t)e->nfeat;
+    if (nrec == 0) return FSK_OK;
+    int keybits = 1;
+    while (keybits < 64 && ((u64)1 << keybits) < (u64)nb * e->V) ++keybits;
+    const int passes = (keybits + 7) / 8;
+    const uint32_t rs_blocks = (uint32_t)((nrec + fsk::RS_TILE - 1) / fsk::RS_TILE);
+    const uint32_t seg_blocks = (uint32_t)((nrec + fsk::SEG_TILE - 1) / fsk::SEG_TILE);
+    for (int b = 0; b < 2; ++b) {
+        FSK_HIP(e->d_keys[b].reserve(nrec * sizeof(KeyT)));
+        FSK_HIP(e->d_vals[b].reserve(nrec));
+    }
+    FSK_HIP(e->d_blockhist.reserve((size_t)256 * rs_blocks));
+    FSK_HIP(e->d_totals.reserve(256));
+    FSK_HIP(e->d_blocksum.reserve(seg_blocks));
+    FSK_HIP(e->d_estart.reserve(nrec + 1));
+    FSK_HIP(e->d_eseq.reserve(nrec));
+    FSK_HIP(e->d_erun.reserve(nrec));
+    FSK_HIP(e->d_rstart.reserve(nrec));
+    FSK_HIP(e->d_segtot.reserve(2));
+    FSK_HIP(e->d_U.reserve(1));
+    FSK_HIP(e->d_pos.reserve((size_t)nb * e->k));
+    std::vector<uint8_t> pos((size_t)nb * e->k);
+    for (int s = 0; s < nb; ++s)
+        memcpy(&pos[(size_t)s * e->k], &e->all_pos[(size_t)combos[s] * e->k], e->k);
+    FSK_HIP(hipMemcpyAsync(e->d_pos.p, pos.data(), pos.size(), hipMemcpyHostToDevice, e->stream));
+    FSK_HIP(hipStreamSynchronize(e->stream));  // `pos` is a pageable temporary
+
+    KeyT* keys[2] = {(KeyT*)e->d_keys[0].p, (KeyT*)e->d_keys[1].p};
+    uint32_t* vals[2] = {e->d_vals[0].p, e->d_vals[1].p};
+    const uint32_t fblocks = (uint32_t)((e->nfeat + 255) / 256);
+
+    e->tic();
+    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sparse_extract<KeyT>), dim3(fblocks, nb), dim3(256), 0, e->stream, e->view(),
+               e->d_featseq.p, e->d_fstart.p, (uint32_t)e->nfeat, e->k, e->sigma, e->V, e->d_pos.p, keys[0], vals[0]);
+    e->toc(&e->st.ms_extract);
+    e->st.launches += 1;
+
+    e->tic();
+    int cur = 0;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 8 * p;
+        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_rs_hist<KeyT>), dim3(rs_blocks), dim3(256), 0, e->stream, keys[cur], (u64)nrec,
+                   shift, e->d_blockhist.p, rs_blocks);
+        FSK_LAUNCH(fsk::k_rs_scan_rows, dim3(256), dim3(256), 0, e->stream, e->d_blockhist.p, rs_blocks, e->d_totals.p);
+        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_rs_scatter<KeyT>), dim3(rs_blocks), dim3(256), 0, e->stream, keys[cur],
+                   vals[cur], keys[cur ^ 1], vals[cur ^ 1], (u64)nrec, shift, e->d_blockhist.p, e->d_totals.p, rs_blocks);
+        cur ^= 1;
+        e->st.launches += 3;
+    }
+    e->toc(&e->st.ms_sort);
+    e->st.sort_records += nrec;
+    e->st.sort_passes = passes;
+
+    e->tic();
+    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_seg_reduce<KeyT>), dim3(seg_blocks), dim3(256), 0, e->stream, keys[cur], vals[cur],
+               (u64)nrec, e->d_blocksum.p);
+    FSK_LAUNCH(fsk::k_seg_scan_blocks, dim3(1), dim3(256), 0, e->stream, e->d_blocksum.p, seg_blocks, (u64)nrec,
+               e->d_segtot.p, e->d_estart.p);
+    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_seg_write<KeyT>), dim3(seg_blocks), dim3(256), 0, e->stream, keys[cur], vals[cur],
+               (u64)nrec, e->d_blocksum.p, e->d_estart.p, e->d_eseq.p, e->d_erun.p, e->d_rstart.p);
+    e->toc(&e->st.ms_segment);
+
+    e->tic();
+    FSK_LAUNCH(fsk::k_sparse_pairs, dim3((uint32_t)((nrec + 255) / 256)), dim3(256), 0, e->stream, e->d_segtot.p,
+               e->d_estart.p, e->d_eseq.p, e->d_erun.p, e->d_rstart.p, K, e->d_U.p);
+    e->toc(&e->st.ms_pairs);
+    e->st.launches += 4;
+    FSK_HIP(hipGetLastError());
+    return FSK_OK;
+}
+
+int ensure_featseq(fsk_engine* e) {
+    if (e->featseq_ready) return FSK_OK;
+    std::vector<uint32_t> fs((size_t)e->nfeat);
+    for (int64_t i = 0; i < e->N; ++i)
+        for (uint32_t f = e->h_fstart[i]; f < e->h_fstart[i + 1]; ++f) fs[f] = (uint32_t)i;
+    FSK_HIP(e->d_featseq.reserve((size_t)e->nfeat));
+    FSK_HIP(hipMemcpy(e->d_featseq.p, fs.data(), fs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    e->featseq_ready = true;
+    return FSK_OK;
+}
+
+int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K) {
+    int rc = ensure_featseq(e);
+    if (rc) return rc;
+    // batch so that the composite key stays below 2^62 and the record count below the cap
+    size_t per = SPARSE_MAX_RECORDS / (size_t)std::max<int64_t>(1, e->nfeat);
+    int B = (int)std::max<size_t>(1, std::min<size_t>(per, (size_t)n));
+    while (B > 1 && (u64)B * e->V >= ((u64)1 << 62)) B /= 2;
+    for (int s = 0; s < n; s += B) {
+        const int nb = std::min(B, n - s);
+        const bool wide = (u64)nb * e->V > 0xffffffffull;
+        rc = wide ? sparse_batch<u64>(e, combos + s, nb, K) : sparse_batch<uint32_t>(e, combos + s, nb, K);
+        if (rc) return rc;
+    }
+    return FSK_OK;
+}
+
+int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K) {
+    const uint32_t panels_pad = (e->n_panels + 1u) & ~1u;  // tiles are 2x2 panels
+    const uint32_t T = panels_pad / 2;
+    const u64 n_tiles = (u64)T * (T + 1) / 2;
+    const size_t slot_dwords = (size_t)panels_pad * e->Vq * fsk::PANEL;  // dwords of panels per combo
+    // combos per launch: u32 accumulators must not wrap (per cell and combo <= maxW^2), and the
+    // count panels must fit in the memory we are willing to take
+    const u64 w2 = std::max<u64>(1, (u64)e->maxW * e->maxW);
+    u64 by_overflow = 0xffffffffull / w2;
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    size_t have = e->d_C.cap * sizeof(uint32_t);
+    size_t budget = std::max<size_t>(have, (size_t)((double)(free_b + have) * 0.6));
+    u64 by_memory = std::max<u64>(1, budget / (slot_dwords * sizeof(uint32_t)));
+    const int chunk = (int)std::max<u64>(1, std::min<u64>({(u64)n, by_overflow, by_memory}));
+    if (by_overflow == 0) return e->fail(FSK_EUNSUPPORTED, "sequence too long for the dense path");
+    FSK_HIP(e->d_C.reserve(slot_dwords * (size_t)chunk));
+    FSK_HIP(e->d_flag.reserve(1));
+    FSK_HIP(e->d_pos.reserve((size_t)chunk * e->k));
+    const size_t lds = dense_lds_bytes(e->Lmax, e->Vq);
+#ifndef FSK_EMU
+    FSK_HIP(hipFuncSetAttribute((const void*)fsk::k_dense_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#endif
+    std::vector<uint8_t> pos;
+    for (int s = 0; s < n; s += chunk) {
+        const int nb = std::min(chunk, n - s);
+        pos.resize((size_t)nb * e->k);
+        for (int q = 0; q < nb; ++q)
+            memcpy(&pos[(size_t)q * e->k], &e->all_pos[(size_t)combos[s + q] * e->k], e->k);
+        FSK_HIP(hipMemcpyAsync(e->d_pos.p, pos.data(), pos.size(), hipMemcpyHostToDevice, e->stream));
+        FSK_HIP(hipMemsetAsync(e->d_flag.p, 0, sizeof(uint32_t), e->stream));
+        FSK_HIP(hipStreamSynchronize(e->stream));  // `pos` is a pageable temporary
+        // ---- segment counts
+        const int slots_per_chunk = std::max(1, std::min(nb, 16));
+        const int n_chunks = (nb + slots_per_chunk - 1) / slots_per_chunk;
+        e->tic();
+        FSK_LAUNCH(fsk::k_dense_count, dim3(panels_pad, n_chunks), dim3(256), lds, e->stream, e->view(), e->cfg.g, e->k,
+                   e->sigma, e->Vq, e->Lmax, e->d_pos.p, nb, slots_per_chunk, e->d_C.p, e->d_flag.p);
+        e->toc(&e->st.ms_count);
+        e->st.panel_bytes += slot_dwords * sizeof(uint32_t) * (u64)nb;
+        if (e->maxW > 255) {  // a count could exceed u8: ask the device before trusting the panels
+            uint32_t flag = 0;
+            FSK_HIP(hipMemcpyAsync(&flag, e->d_flag.p, sizeof flag, hipMemcpyDeviceToHost, e->stream));
+            FSK_HIP(hipStreamSynchronize(e->stream));
+            if (flag) {  // a k-mer occurs > 255 times in one sequence: take the general dataflow
+                int rc = accumulate_sparse(e, combos + s, nb, K);
+                if (rc) return rc;
+                continue;
+            }
+        }
+        if (e->cfg.profile) {  // exact algorithmic update count U for the roofline
+            FSK_LAUNCH(fsk::k_dense_distinct, dim3(e->Vq, nb), dim3(64), 0, e->stream, e->d_C.p, panels_pad, nb, e->Vq, e->d_U.p);
+        }
+        // ---- tiled accumulate. Split the combo range when there are too few tiles to fill
+        // 256 CUs x 2 workgroups.
+        int n_splits = 1;
+        if (n_tiles < 1024) n_splits = (int)std::min<u64>((u64)nb, (1024 + n_tiles - 1) / n_tiles);
+        const int slots_per_split = (nb + n_splits - 1) / n_splits;
+        n_splits = (nb + slots_per_split - 1) / slots_per_split;
+        e->tic();
+        FSK_LAUNCH(fsk::k_dense_tile, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C.p, nb, e->Vq,
+                   (uint32_t)e->N, K, slots_per_split);
+        e->toc(&e->st.ms_tile);
+        e->st.n_tile_launches += 1;
+        e->st.dense_macs += n_tiles * (u64)fsk::TILE * fsk::TILE * (u64)nb * ((u64)((e->Vq + 31) / 32) * 32 * 4);
+        e->st.launches += 2;
+        FSK_HIP(hipGetLastError());
+    }
+    return FSK_OK;
+}
+
+int do_accumulate(fsk_engine* e, const int32_t* combos, int n, u64* K) {
+    for (int i = 0; i < n; ++i)
+        if (combos[i] < 0 || combos[i] >= e->ncomb) return e->fail(FSK_EINVAL, "combo id %d out of range [0,%lld)", combos[i], (long long)e->ncomb);
+    hipEvent_t a = nullptr, b = nullptr;
+    if (e->cfg.profile) {
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, e->stream);
+    }
+    int rc = e->path == FSK_PATH_DENSE ? accumulate_dense(e, combos, n, K) : accumulate_sparse(e, combos, n, K);
+    if (e->cfg.profile) {
+        (void)hipEventRecord(b, e->stream);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        e->st.ms_total += ms;
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+    }
+    if (rc == FSK_OK) e->st.combos_done += n;
+    return rc;
+}
+
+int make_diag(fsk_engine* e) {
+    FSK_HIP(e->d_diag.reserve((size_t)e->N));
+    const uint32_t blocks = (uint32_t)((e->N + 255) / 256);
+    if (e->result_f64)
+        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_diag<double>), dim3(blocks), dim3(256), 0, e->stream, e->d_Kf64.p, e->d_diag.p, (uint32_t)e->N);
+    else
+        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_diag<u64>), dim3(blocks), dim3(256), 0, e->stream, e->d_K, e->d_diag.p, (uint32_t)e->N);
+    FSK_HIP(hipStreamSynchronize(e->stream));
+    e->finalized = true;
+    return FSK_OK;
+}
+
+void default_order(fsk_engine* e) {
+    e->order.resize((size_t)e->ncomb);
+    for (int64_t i = 0; i < e->ncomb; ++i) e->order[i] = (int32_t)i;
+    uint64_t s = e->seed;
+    for (int64_t i = e->ncomb - 1; i > 0; --i) {
+        int64_t j = (int64_t)(splitmix64(s) % (uint64_t)(i + 1));
+        std::swap(e->order[i], e->order[j]);
+    }
+}
+
+// variance mode: T sequential Welford chains (fastsk_kernel.cpp:188-262, 286-315)
+int run_variance_mode(fsk_engine* e, int T) {
+    const int64_t pairs = e->pairs;
+    const int64_t train_pairs = (int64_t)((e->n_train / (double)2) * (e->n_train + 1));
+    FSK_HIP(e->d_Kf64.reserve((size_t)pairs));
+    FSK_HIP(e->d_Khat.reserve((size_t)pairs));
+    FSK_HIP(e->d_prod.reserve((size_t)std::max<int64_t>(1, train_pairs)));
+    FSK_HIP(hipMemsetAsync(e->d_Kf64.p, 0, (size_t)pairs * sizeof(double), e->stream));
+    std::vector<double> prod((size_t)train_pairs);
+    const uint32_t blocks = (uint32_t)((pairs + 255) / 256);
+    const int n_order = (int)e->order.size();
+    e->stdevs.clear();
+    for (int tid = 0; tid < T; ++tid) {
+        FSK_HIP(hipMemsetAsync(e->d_Khat.p, 0, (size_t)pairs * sizeof(double), e->stream));
+        int iter = 1, item = tid;
+        bool working = true;
+        while (working) {
+            FSK_HIP(hipMemsetAsync(e->d_K, 0, (size_t)pairs * sizeof(u64), e->stream));
+            int32_t combo = e->order[item];
+            int rc = do_accumulate(e, &combo, 1, e->d_K);
+            if (rc) return rc;
+            FSK_LAUNCH(fsk::k_welford, dim3(blocks), dim3(256), 0, e->stream, e->d_K, e->d_Khat.p, e->d_prod.p, (u64)pairs,
+                       (u64)train_pairs, (double)iter);
+            FSK_HIP(hipMemcpyAsync(prod.data(), e->d_prod.p, (size_t)train_pairs * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+            FSK_HIP(hipStreamSynchronize(e->stream));
+            // the reference's avg_variance is a sequential fp64 sum in triangle-index order
+            // (fastsk_kernel.cpp:116-131); keep that order so stdevs match to the last bit
+            double avg = 0;
+            for (int64_t i = 0; i < train_pairs; ++i) avg += prod[(size_t)i];
+            avg /= (double)train_pairs;
+            if (iter == 1) avg = 9999999;
+            else avg /= iter - 1;
+            double sd = std::sqrt(avg / iter);
+            if (tid == 0) e->stdevs.push_back(sd);
+            if (e->cfg.delta / sd > 1.96) working = false;
+            if (e->cfg.max_iters != -1 && iter >= e->cfg.max_iters) working = false;
+            item += T;
+            if (item >= n_order) working = false;
+            iter++;
+        }
+        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_add_nonzero<double>), dim3(blocks), dim3(256), 0, e->stream, e->d_Kf64.p, e->d_Khat.p, (u64)pairs);
+    }
+    e->result_f64 = true;
+    return FSK_OK;
+}
+
+int fetch_block(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1, double* out) {
+    if (!e->finalized) return e->fail(FSK_ESTATE, "no finalized kernel: call fsk_compute or fsk_finalize first");
+    if (i0 < 0 || j0 < 0 || i1 > e->N || j1 > e->N || i0 > i1 || j0 > j1) return e->fail(FSK_EINVAL, "block out of range");
+    const int64_t rows = i1 - i0, cols = j1 - j0;
+    if (rows == 0 || cols == 0) return FSK_OK;
+    if (!out) return e->fail(FSK_EINVAL, "null output");
+    const int64_t max_cells = (int64_t)32 << 20;  // 256 MB of doubles per staging round
+    const int64_t rows_per = std::max<int64_t>(1, std::min<int64_t>(rows, max_cells / cols));
+    FSK_HIP(e->d_stage.reserve((size_t)(rows_per * cols)));
+    for (int64_t r = 0; r < rows; r += rows_per) {
+        const int64_t nr = std::min(rows_per, rows - r);
+        const u64 cells = (u64)nr * cols;
+        const uint32_t blocks = (uint32_t)((cells + 255) / 256);
+        if (e->result_f64)
+            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_block<double>), dim3(blocks), dim3(256), 0, e->stream, e->d_Kf64.p, e->d_diag.p,
+                       (u64)(i0 + r), (u64)nr, (u64)j0, (u64)cols, e->d_stage.p);
+        else
+            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_block<u64>), dim3(blocks), dim3(256), 0, e->stream, e->d_K, e->d_diag.p,
+                       (u64)(i0 + r), (u64)nr, (u64)j0, (u64)cols, e->d_stage.p);
+        FSK_HIP(hipMemcpyAsync(out + r * cols, e->d_stage.p, cells * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        FSK_HIP(hipStreamSynchronize(e->stream));
+    }
+    return FSK_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int fsk_abi_version(void) { return FSK_ABI_VERSION; }
+
+int fsk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+int64_t fsk_num_combos(int32_t g, int32_t m) { return n_choose_k(g, m); }
+
+int fsk_combo_positions(int32_t g, int32_t k, int64_t combo, int32_t* out) {
+    if (!out || k <= 0 || k > g || combo < 0 || combo >= n_choose_k(g, k)) return FSK_EINVAL;
+    int next = 0;
+    for (int d = 0; d < k; ++d)
+        for (int p = next; p < g; ++p) {
+            int64_t below = n_choose_k(g - p - 1, k - d - 1);
+            if (combo < below) { out[d] = p; next = p + 1; break; }
+            combo -= below;
+        }
+    return FSK_OK;
+}
+
+const char* fsk_last_error(const fsk_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int fsk_create(const fsk_config* cfg, fsk_engine** out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return FSK_EINVAL; }
+    *out = nullptr;
+    if (cfg->g <= 0 || cfg->m < 0 || cfg->m >= cfg->g) {
+        g_create_error = "need 0 <= m < g";
+        return FSK_EINVAL;
+    }
+    if (cfg->g > 255) { g_create_error = "g > 255 unsupported"; return FSK_EUNSUPPORTED; }
+    if (cfg->t == 0 || cfg->t < -1) { g_create_error = "t must be -1 or >= 1"; return FSK_EINVAL; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_create_error = "no HIP device visible: the MI355X engine has no CPU fallback";
+        return FSK_EDEVICE;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "device ordinal out of range"; return FSK_EINVAL; }
+    if (hipSetDevice(cfg->device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return FSK_EDEVICE; }
+    fsk_engine* e = new fsk_engine;
+    e->cfg = *cfg;
+    e->k = cfg->g - cfg->m;
+    e->ncomb = n_choose_k(cfg->g, cfg->m);
+    if (e->ncomb > 0x7fffffff) { delete e; g_create_error = "C(g,m) >= 2^31 unsupported"; return FSK_EUNSUPPORTED; }
+    enumerate_combos(cfg->g, e->k, e->all_pos);
+    if (hipStreamCreate(&e->stream) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
+        hipEventCreate(&e->ev1) != hipSuccess) {
+        delete e;
+        g_create_error = "cannot create HIP stream/events";
+        return FSK_EDEVICE;
+    }
+    e->st.n_combos_total = (int32_t)e->ncomb;
+    *out = e;
+    return FSK_OK;
+}
+
+void fsk_destroy(fsk_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipStreamSynchronize(e->stream);
+    e->d_words.release(); e->d_wstart.release(); e->d_len.release(); e->d_fstart.release(); e->d_featseq.release();
+    e->d_pos.release(); e->K_store.release(); e->d_Kf64.release(); e->d_Khat.release(); e->d_prod.release();
+    e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_C.release(); e->d_flag.release();
+    for (int b = 0; b < 2; ++b) { e->d_keys[b].release(); e->d_vals[b].release(); }
+    e->d_blockhist.release(); e->d_totals.release(); e->d_estart.release(); e->d_eseq.release(); e->d_erun.release();
+    e->d_rstart.release(); e->d_segtot.release(); e->d_blocksum.release(); e->d_U.release();
+    (void)hipEventDestroy(e->ev0);
+    (void)hipEventDestroy(e->ev1);
+    (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int fsk_set_combo_order(fsk_engine* e, const int32_t* order, int32_t n) {
+    if (!e) return FSK_EINVAL;
+    if (!order || n <= 0 || n > e->ncomb) return e->fail(FSK_EINVAL, "combo order must hold 1..C(g,m) ids");
+    std::vector<char> seen((size_t)e->ncomb, 0);
+    for (int i = 0; i < n; ++i) {
+        if (order[i] < 0 || order[i] >= e->ncomb || seen[order[i]]) return e->fail(FSK_EINVAL, "combo order: id %d invalid or repeated", order[i]);
+        seen[order[i]] = 1;
+    }
+    e->order.assign(order, order + n);
+    e->order_set = true;
+    return FSK_OK;
+}
+
+int fsk_set_seed(fsk_engine* e, uint64_t seed) {
+    if (!e) return FSK_EINVAL;
+    e->seed = seed;
+    return FSK_OK;
+}
+
+int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offsets, int64_t n_train, int64_t n_test) {
+    if (!e) return FSK_EINVAL;
+    if (!offsets || n_train <= 0 || n_test < 0) return e->fail(FSK_EINVAL, "need n_train >= 1, n_test >= 0 and offsets");
+    FSK_HIP(hipSetDevice(e->cfg.device));
+    const int64_t N = n_train + n_test;
+    const int g = e->cfg.g;
+    if (N >= ((int64_t)1 << 31)) return e->fail(FSK_EUNSUPPORTED, "more than 2^31 sequences");
+    if (offsets[N] > 0 && !tokens) return e->fail(FSK_EINVAL, "null tokens");
+    // ---- lengths (fastsk.cpp:32-58)
+    int64_t shortest_train = INT64_MAX, shortest_test = INT64_MAX, longest = 0, nfeat = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        const int64_t len = offsets[i + 1] - offsets[i];
+        if (len < 0) return e->fail(FSK_EINVAL, "offsets must be non-decreasing");
+        if (i < n_train) shortest_train = std::min(shortest_train, len);
+        else shortest_test = std::min(shortest_test, len);
+        longest = std::max(longest, len);
+        nfeat += len >= g ? len - g + 1 : 0;
+    }
+    if (g > shortest_train)
+        return e->fail(FSK_ESHORT, "g cannot be longer than the shortest sequence in a dataset. g = %d, but shortest train sequence has length %lld", g, (long long)shortest_train);
+    if (n_test > 0 && g > shortest_test)
+        return e->fail(FSK_ESHORT, "g cannot be longer than the shortest sequence in a dataset. g = %d, but shortest test sequence has length %lld", g, (long long)shortest_test);
+    if (nfeat >= ((int64_t)1 << 31) || longest >= ((int64_t)1 << 24)) return e->fail(FSK_EUNSUPPORTED, "input too large (g-mers >= 2^31 or a sequence >= 2^24)");
+    // ---- alphabet: rank-remap the tokens that occur (equality preserving; the reference's
+    // dict_size = |{0} U tokens|, fastsk.cpp:70-85, only serves as its counting-sort radix)
+    const int64_t total = offsets[N];
+    std::vector<int32_t> distinct;
+    {
+        int32_t lo = INT32_MAX, hi = INT32_MIN;
+        for (int64_t i = 0; i < total; ++i) { lo = std::min(lo, tokens[i]); hi = std::max(hi, tokens[i]); }
+        if (total > 0 && lo >= 0 && hi < (1 << 20)) {
+            std::vector<char> seen((size_t)hi + 1, 0);
+            for (int64_t i = 0; i < total; ++i) seen[tokens[i]] = 1;
+            for (int32_t v = 0; v <= hi; ++v) if (seen[v]) distinct.push_back(v);
+        } else {
+            distinct.assign(tokens, tokens + total);
+            std::sort(distinct.begin(), distinct.end());
+            distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+        }
+    }
+    if (distinct.size() > 256) return e->fail(FSK_EUNSUPPORTED, "alphabet of %zu symbols (> 256)", distinct.size());
+    const uint32_t sigma = (uint32_t)std::max<size_t>(1, distinct.size());
+    const int bits = sigma <= 4 ? 2 : sigma <= 16 ? 4 : 8;
+    u64 V = 1;
+    for (int c = 0; c < e->k; ++c) {
+        if (V > (((u64)1 << 62) / sigma)) return e->fail(FSK_EUNSUPPORTED, "alphabet^(g-m) does not fit in 62 bits");
+        V *= sigma;
+    }
+    // ---- pack, every sequence word-aligned
+    std::vector<uint32_t> wstart((size_t)N), len32((size_t)N), fstart((size_t)N + 1);
+    uint64_t nwords = 0;
+    uint32_t fcount = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        const int64_t len = offsets[i + 1] - offsets[i];
+        wstart[i] = (uint32_t)nwords;
+        len32[i] = (uint32_t)len;
+        fstart[i] = fcount;
+        fcount += (uint32_t)(len - g + 1);
+        nwords += ((uint64_t)len * bits + 31) / 32;
+        if (nwords >= ((uint64_t)1 << 32)) return e->fail(FSK_EUNSUPPORTED, "packed sequences exceed 2^32 words");
+    }
+    fstart[N] = fcount;
+    std::vector<uint32_t> words((size_t)nwords + 4, 0u);
+    {
+        const int32_t base = distinct.empty() ? 0 : distinct.front();
+        const bool direct = !distinct.empty() && (int64_t)distinct.back() - base < (1 << 20);
+        std::vector<uint8_t> lut;
+        if (direct) {
+            lut.assign((size_t)(distinct.back() - base) + 1, 0);
+            for (size_t r = 0; r < distinct.size(); ++r) lut[(size_t)(distinct[r] - base)] = (uint8_t)r;
+        }
+        for (int64_t i = 0; i < N; ++i) {
+            const int32_t* s = tokens + offsets[i];
+            uint32_t* w = words.data() + wstart[i];
+            for (uint32_t p = 0; p < len32[i]; ++p) {
+                uint32_t r = direct ? lut[(size_t)(s[p] - base)]
+                                    : (uint32_t)(std::lower_bound(distinct.begin(), distinct.end(), s[p]) - distinct.begin());
+                const uint32_t bitpos = p * (uint32_t)bits;
+                w[bitpos >> 5] |= r << (bitpos & 31u);
+            }
+        }
+    }
+    // ---- commit
+    e->N = N; e->n_train = n_train; e->n_test = n_test; e->nfeat = nfeat;
+    e->pairs = N * (N + 1) / 2;
+    e->sigma = sigma; e->bits = bits; e->V = V; e->Vq = (uint32_t)((V + 3) / 4);
+    e->Lmax = (uint32_t)longest; e->Lmin = (uint32_t)std::min(shortest_train, n_test > 0 ? shortest_test : shortest_train);
+    e->maxW = (uint32_t)(longest - g + 1);
+    e->n_panels = (uint32_t)((N + fsk::PANEL - 1) / fsk::PANEL);
+    e->h_len = len32; e->h_fstart = fstart; e->featseq_ready = false;
+    if (e->V > DENSE_MAX_KEYS) e->Vq = 1;  // unused on the sparse path
+    int rc = choose_path(e);
+    if (rc) return rc;
+    FSK_HIP(e->d_words.reserve(words.size()));
+    FSK_HIP(e->d_wstart.reserve((size_t)N));
+    FSK_HIP(e->d_len.reserve((size_t)N));
+    FSK_HIP(e->d_fstart.reserve((size_t)N + 1));
+    FSK_HIP(hipMemcpy(e->d_words.p, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    FSK_HIP(hipMemcpy(e->d_wstart.p, wstart.data(), (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice));
+    FSK_HIP(hipMemcpy(e->d_len.p, len32.data(), (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice));
+    FSK_HIP(hipMemcpy(e->d_fstart.p, fstart.data(), ((size_t)N + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (e->d_K && !e->K_owned) {
+        if (e->bound_cells != e->pairs) return e->fail(FSK_EINVAL, "bound counts buffer holds %lld cells, need %lld", (long long)e->bound_cells, (long long)e->pairs);
+    } else {
+        hipError_t r = e->K_store.reserve((size_t)e->pairs);
+        if (r != hipSuccess) return e->fail(FSK_ENOMEM, "cannot allocate the %lld-cell integer triangle", (long long)e->pairs);
+        e->d_K = e->K_store.p;
+        e->K_owned = true;
+    }
+    FSK_HIP(hipMemsetAsync(e->d_K, 0, (size_t)e->pairs * sizeof(u64), e->stream));
+    FSK_HIP(e->d_U.reserve(1));
+    FSK_HIP(hipMemsetAsync(e->d_U.p, 0, sizeof(u64), e->stream));
+    e->loaded = true; e->finalized = false; e->result_f64 = false;
+    e->stdevs.clear();
+    fsk_stats& st = e->st;
+    st = fsk_stats{};
+    st.n_seq = N; st.n_train = n_train; st.n_test = n_test; st.n_feat = nfeat; st.n_pairs = e->pairs;
+    st.alphabet = (int32_t)sigma; st.bits_per_symbol = bits; st.key_space = (int64_t)V; st.path_used = e->path;
+    st.n_combos_total = (int32_t)e->ncomb;
+    return FSK_OK;
+}
+
+int fsk_bind_counts(fsk_engine* e, void* device_u64, int64_t n_cells) {
+    if (!e) return FSK_EINVAL;
+    if (!device_u64 || n_cells <= 0) return e->fail(FSK_EINVAL, "bad counts buffer");
+    if (e->loaded && n_cells != e->pairs) return e->fail(FSK_EINVAL, "counts buffer holds %lld cells, need %lld", (long long)n_cells, (long long)e->pairs);
+    if (e->K_owned) e->K_store.release();
+    e->bound_cells = n_cells;
+    e->d_K = (u64*)device_u64;
+    e->K_owned = false;
+    e->finalized = false;
+    return FSK_OK;
+}
+
+int fsk_counts_device_ptr(fsk_engine* e, void** out) {
+    if (!e || !out) return FSK_EINVAL;
+    if (!e->d_K) return e->fail(FSK_ESTATE, "no counts buffer yet");
+    *out = e->d_K;
+    return FSK_OK;
+}
+
+int fsk_reset_counts(fsk_engine* e) {
+    if (!e) return FSK_EINVAL;
+    if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
+    FSK_HIP(hipSetDevice(e->cfg.device));
+    FSK_HIP(hipMemsetAsync(e->d_K, 0, (size_t)e->pairs * sizeof(u64), e->stream));
+    if (e->d_U.p) FSK_HIP(hipMemsetAsync(e->d_U.p, 0, sizeof(u64), e->stream));
+    e->finalized = false; e->result_f64 = false;
+    e->st.combos_done = 0;
+    return FSK_OK;
+}
+
+int fsk_accumulate(fsk_engine* e, const int32_t* combos, int32_t n) {
+    if (!e) return FSK_EINVAL;
+    if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
+    if (n < 0 || (n > 0 && !combos)) return e->fail(FSK_EINVAL, "bad combo list");
+    if (n == 0) return FSK_OK;
+    FSK_HIP(hipSetDevice(e->cfg.device));
+    e->finalized = false;
+    return do_accumulate(e, combos, n, e->d_K);
+}
+
+int fsk_synchronize(fsk_engine* e) {
+    if (!e) return FSK_EINVAL;
+    FSK_HIP(hipSetDevice(e->cfg.device));
+    FSK_HIP(hipStreamSynchronize(e->stream));
+    FSK_HIP(hipGetLastError());
+    return FSK_OK;
+}
+
+int fsk_finalize(fsk_engine* e) {
+    if (!e) return FSK_EINVAL;
+    if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
+    FSK_HIP(hipSetDevice(e->cfg.device));
+    return make_diag(e);
+}
+
+int fsk_compute(fsk_engine* e, const int32_t* tokens, const int64_t* offsets, int64_t n_train, int64_t n_test) {
+    if (!e) return FSK_EINVAL;
+    int rc = fsk_load_sequences(e, tokens, offsets, n_train, n_test);
+    if (rc) return rc;
+    const fsk_config& c = e->cfg;
+    if (!c.approx) {  // exact: every combination, order irrelevant (integer sum)
+        std::vector<int32_t> all((size_t)e->ncomb);
+        for (int64_t i = 0; i < e->ncomb; ++i) all[i] = (int32_t)i;
+        rc = do_accumulate(e, all.data(), (int)all.size(), e->d_K);
+        if (rc) return rc;
+        return make_diag(e);
+    }
+    if (!e->order_set) default_order(e);
+    int T = c.t == -1 ? 20 : c.t;  // fastsk_kernel.cpp:54-61
+    T = std::max(1, std::min<int>(T, (int)e->order.size()));
+    if (c.skip_variance) {  // chains only select which combos enter the integer sum
+        std::vector<int32_t> used;
+        for (int tid = 0; tid < T; ++tid) {
+            int iters = 0;
+            for (size_t item = tid; item < e->order.size(); item += T) {
+                used.push_back(e->order[item]);
+                if (c.max_iters != -1 && ++iters >= c.max_iters) break;
+            }
+        }
+        rc = do_accumulate(e, used.data(), (int)used.size(), e->d_K);
+        if (rc) return rc;
+        return make_diag(e);
+    }
+    rc = run_variance_mode(e, T);
+    if (rc) return rc;
+    return make_diag(e);
+}
+
+int fsk_get_block(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1, double* out) {
+    if (!e) return FSK_EINVAL;
+    FSK_HIP(hipSetDevice(e->cfg.device));
+    return fetch_block(e, i0, i1, j0, j1, out);
+}
+int fsk_get_train(fsk_engine* e, double* out) {
+    if (!e) return FSK_EINVAL;
+    FSK_HIP(hipSetDevice(e->cfg.device));
+    return fetch_block(e, 0, e->n_train, 0, e->n_train, out);
+}
+int fsk_get_test(fsk_engine* e, double* out) {
+    if (!e) return FSK_EINVAL;
+    FSK_HIP(hipSetDevice(e->cfg.device));
+    return fetch_block(e, e->n_train, e->N, 0, e->n_train, out);
+}
+
+int fsk_get_triangle(fsk_engine* e, double* out) {
+    if (!e) return FSK_EINVAL;
+    if (!e->finalized) return e->fail(FSK_ESTATE, "no finalized kernel");
+    if (!out) return e->fail(FSK_EINVAL, "null output");
+    FSK_HIP(hipSetDevice(e->cfg.device));
+    const u64 chunk = (u64)32 << 20;
+    FSK_HIP(e->d_stage.reserve((size_t)std::min<u64>(chunk, (u64)e->pairs)));
+    for (u64 c0 = 0; c0 < (u64)e->pairs; c0 += chunk) {
+        const u64 cnt = std::min<u64>(chunk, (u64)e->pairs - c0);
+        const uint32_t blocks = (uint32_t)((cnt + 255) / 256);
+        if (e->result_f64)
+            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_triangle<double>), dim3(blocks), dim3(256), 0, e->stream, e->d_Kf64.p, e->d_diag.p, c0, cnt, e->d_stage.p);
+        else
+            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_triangle<u64>), dim3(blocks), dim3(256), 0, e->stream, e->d_K, e->d_diag.p, c0, cnt, e->d_stage.p);
+        FSK_HIP(hipMemcpyAsync(out + c0, e->d_stage.p, cnt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        FSK_HIP(hipStreamSynchronize(e->stream));
+    }
+    return FSK_OK;
+}
+
+int fsk_get_counts(fsk_engine* e, uint64_t* out) {
+    if (!e) return FSK_EINVAL;
+    if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
+    if (e->result_f64) return e->fail(FSK_ESTATE, "variance mode keeps a floating-point mean, not integer counts");
+    if (!out) return e->fail(FSK_EINVAL, "null output");
+    FSK_HIP(hipSetDevice(e->cfg.device));
+    FSK_HIP(hipStreamSynchronize(e->stream));
+    FSK_HIP(hipMemcpy(out, e->d_K, (size_t)e->pairs * sizeof(u64), hipMemcpyDeviceToHost));
+    return FSK_OK;
+}
+
+int fsk_get_counts_block(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint64_t* out) {
+    if (!e) return FSK_EINVAL;
+    if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
+    if (e->result_f64) return e->fail(FSK_ESTATE, "variance mode keeps a floating-point mean, not integer counts");
+    if (i0 < 0 || j0 < 0 || i1 > e->N || j1 > e->N || i0 > i1 || j0 > j1) return e->fail(FSK_EINVAL, "block out of range");
+    FSK_HIP(hipSetDevice(e->cfg.device));
+    const int64_t rows = i1 - i0, cols = j1 - j0;
+    if (rows == 0 || cols == 0) return FSK_OK;
+    if (!out) return e->fail(FSK_EINVAL, "null output");
+    const int64_t max_cells = (int64_t)32 << 20;
+    const int64_t rows_per = std::max<int64_t>(1, std::min<int64_t>(rows, max_cells / cols));
+    FSK_HIP(e->d_stage_u64.reserve((size_t)(rows_per * cols)));
+    for (int64_t r = 0; r < rows; r += rows_per) {
+        const int64_t nr = std::min(rows_per, rows - r);
+        const u64 cells = (u64)nr * cols;
+        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_block_raw<u64>), dim3((uint32_t)((cells + 255) / 256)), dim3(256), 0, e->stream, e->d_K,
+                   (u64)(i0 + r), (u64)nr, (u64)j0, (u64)cols, e->d_stage_u64.p);
+        FSK_HIP(hipMemcpyAsync(out + r * cols, e->d_stage_u64.p, cells * sizeof(u64), hipMemcpyDeviceToHost, e->stream));
+        FSK_HIP(hipStreamSynchronize(e->stream));
+    }
+    return FSK_OK;
+}
+
+int fsk_get_stdevs(fsk_engine* e, double* out, int32_t cap, int32_t* n) {
+    if (!e || !n) return FSK_EINVAL;
+    *n = (int32_t)e->stdevs.size();
+    for (int32_t i = 0; i < *n && i < cap && out; ++i) out[i] = e->stdevs[i];
+    return FSK_OK;
+}
+
+int fsk_save_kernel(fsk_engine* e, const char* path) {
+    if (!e) return FSK_EINVAL;
+    if (!e->finalized) return e->fail(FSK_ESTATE, "no finalized kernel");
+    if (!path || !*path) return FSK_OK;  // the reference silently does nothing for an empty name
+    FILE* f = fopen(path, "w");
+    if (!f) return e->fail(FSK_EINVAL, "cannot open %s", path);
+    std::vector<double> row((size_t)e->N);
+    for (int64_t i = 0; i < e->N; ++i) {
+        int rc = fsk_get_block(e, i, i + 1, 0, e->N, row.data());
+        if (rc) { fclose(f); return rc; }
+        for (int64_t j = 0; j < e->N; ++j) fprintf(f, "%d:%e ", (int)(j + 1), row[(size_t)j]);
+        fprintf(f, "\n");
+    }
+    fclose(f);
+    return FSK_OK;
+}
+
+int fsk_get_stats(fsk_engine* e, fsk_stats* out) {
+    if (!e || !out) return FSK_EINVAL;
+    if (e->d_U.p && e->loaded) {
+        (void)hipSetDevice(e->cfg.device);
+        u64 U = 0;
+        if (hipStreamSynchronize(e->stream) == hipSuccess &&
+            hipMemcpy(&U, e->d_U.p, sizeof U, hipMemcpyDeviceToHost) == hipSuccess)
+            e->st.cell_updates = U;
+    }
+    *out = e->st;
+    return FSK_OK;
+}
+
+}  // extern "C"

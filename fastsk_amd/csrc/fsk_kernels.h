@@ -1,0 +1,596 @@
+// fsk_kernels.h — hand-written gfx950 (CDNA4, wave64) kernels of the gapped-k-mer engine.
+//
+// What the reference does per mismatch combination (fastsk_kernel.cpp:216-241, shared.cpp):
+//   gather kept positions -> stable LSD counting sort (cntsrtna, shared.cpp:156-191)
+//   -> permute -> run-length co-occurrence count into the triangle (countAndUpdateTri,
+//   shared.cpp:268-333).
+// Here the same mathematics, K[i][j] += sum_v cnt_i(v) * cnt_j(v), is computed by one of two
+// dataflows, both integer VALU/LDS/atomic work (no MFMA):
+//
+//   DENSE  (small key space, e.g. DNA with k=4: 256 keys, every key present in most sequences)
+//     k_dense_count  per-sequence counting sort in LDS: 64 sequences per workgroup, symbols
+//                    unpacked once from bit-packed HBM, one LDS atomic per g-mer; the segment
+//                    counts leave as u8 "count panels" laid out [panel][combo][key/4][64 seqs]
+//                    so that the tile kernel streams them with 16-byte coalesced loads.
+//     k_dense_tile   output-stationary 128x128 tile of K per workgroup: panels staged through
+//                    LDS, 8x8 register block per lane, v_dot4_u32_u8 multiply-adds summed in
+//                    registers over ALL combos of the launch, then ONE 64-bit atomicAdd per cell.
+//
+//   SPARSE (large key space, e.g. protein: 24^4 keys, runs of 3-5) — the reference's dataflow
+//     k_sparse_extract  packed (combo,k-mer) key + sequence id per g-mer, straight from packed HBM
+//     k_rs_*            LDS-staged 8-bit LSD radix sort (wave64 ballot match ranking, stable)
+//     k_seg_*           run heads by neighbour compare, wave prefix sums -> distinct (k-mer,seq)
+//                       entries with multiplicities and run starts
+//     k_sparse_pairs    per (run, pair) 64-bit atomicAdd into K
+//
+// Everything is written for 64-wide wavefronts; lane = threadIdx.x & 63.
+#pragma once
+#include "fsk_platform.h"
+
+namespace fsk {
+
+struct SeqView {
+    const uint32_t* words;   // bit-packed symbols, every sequence starts on a 32-bit word
+    const uint32_t* wstart;  // [n_seq] first word of sequence i
+    const uint32_t* len;     // [n_seq] length in symbols
+    uint32_t n_seq;
+    int bits;                // 2, 4 or 8 bits per symbol (a symbol never straddles a word)
+};
+
+__device__ __forceinline__ uint32_t fetch_sym(const uint32_t* words, uint32_t wbase, uint32_t pos, int bits) {
+    uint32_t bitpos = pos * (uint32_t)bits;
+    return (words[wbase + (bitpos >> 5)] >> (bitpos & 31u)) & ((1u << bits) - 1u);
+}
+
+__device__ __forceinline__ u64 tri_index(u64 i, u64 j) {  // j <= i  (tri_access, shared.cpp:97-117)
+    return i * (i + 1) / 2 + j;
+}
+
+// ---------------------------------------------------------------------------------------------
+// block-wide exclusive scan of one value per thread, 256 threads (4 waves). tmp: >= 4 entries.
+// Every thread of the block must call it.
+template <typename T>
+__device__ __forceinline__ T block_excl_scan_256(T v, T* tmp, T* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();  // tmp may still be read from a previous call
+    if (lane == 63) tmp[wave] = x;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        T t = tmp[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    if (total) *total = tot;
+    return base + x - v;
+}
+
+// =============================================================================================
+// DENSE PATH
+// =============================================================================================
+constexpr int PANEL = 64;        // sequences per count panel (= one wave of lanes)
+constexpr int TILE = 128;        // K tile edge (2 panels)
+constexpr int STAGE_KQ = 32;     // key quads (4 keys = one dword of u8 counts) per LDS stage
+
+// Per-sequence counting sort of the k-mers selected by each combo ("segment counts").
+// grid = (n_panels, n_chunks), block = 256 (wave w takes windows j = w mod 4; lane = sequence).
+// dynamic LDS: symT[Lmax][64] u8 | hist[4*Vq][32] u32 (two u16 counters per dword).
+// LDS banking: lane r touches dword (key*32 + r/2): bank depends on r only -> conflict-free for
+// any key mix; the two lanes sharing a dword add to different halves (same-address atomics).
+__global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, uint32_t sigma, uint32_t Vq,
+                                                     uint32_t Lmax, const uint8_t* combo_pos, int n_slots,
+                                                     int slots_per_chunk, uint32_t* C, uint32_t* overflow_flag) {
+    FSK_DYN_SHARED(unsigned char, smem);
+    uint8_t* symT = smem;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (size_t)Lmax * PANEL);
+    const int tid = threadIdx.x, r = tid & 63, w = tid >> 6;
+    const uint32_t panel = blockIdx.x;
+    const uint32_t seq = panel * PANEL + r;
+    const uint32_t len = seq < S.n_seq ? S.len[seq] : 0u;
+    const uint32_t wbase = seq < S.n_seq ? S.wstart[seq] : 0u;
+    for (uint32_t p = w; p < Lmax; p += 4)
+        symT[p * PANEL + r] = p < len ? (uint8_t)fetch_sym(S.words, wbase, p, S.bits) : (uint8_t)0;
+    const uint32_t nwin = len >= (uint32_t)g ? len - g + 1 : 0u;
+    const uint32_t max_win = Lmax >= (uint32_t)g ? Lmax - g + 1 : 0u;
+    const int slot0 = blockIdx.y * slots_per_chunk;
+    const int slot1 = slot0 + slots_per_chunk < n_slots ? slot0 + slots_per_chunk : n_slots;
+    const uint32_t hist_dwords = 4u * Vq * 32u;
+    const uint32_t half = (uint32_t)(r & 1) * 16u;
+    bool ovf = false;
+    for (int slot = slot0; slot < slot1; ++slot) {
+        __syncthreads();  // symT complete / previous read-out finished
+        for (uint32_t i = tid; i < hist_dwords; i += 256) hist[i] = 0u;
+        __syncthreads();
+        const uint8_t* pos = combo_pos + (size_t)slot * k;
+        for (uint32_t j = w; j < max_win; j += 4) {
+            if (j < nwin) {
+                uint32_t key = 0;
+                for (int c = 0; c < k; ++c) key = key * sigma + symT[(j + pos[c]) * PANEL + r];
+                atomicAdd(&hist[key * 32u + (uint32_t)(r >> 1)], 1u << half);
+            }
+        }
+        __syncthreads();
+        uint32_t* out = C + ((size_t)panel * n_slots + slot) * ((size_t)Vq * PANEL);
+        for (uint32_t kq = w; kq < Vq; kq += 4) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t c = (hist[(4u * kq + q) * 32u + (uint32_t)(r >> 1)] >> half) & 0xffffu;
+                ovf |= c > 255u;
+                packed |= (c & 255u) << (8 * q);
+            }
+            out[kq * PANEL + r] = packed;  // 256 B per wave, coalesced
+        }
+    }
+    if (ovf) atomicOr(overflow_flag, 1u);
+}
+
+// U = sum over (combo, key) of d(d+1)/2, d = number of sequences in which the key occurs: the
+// number of `+=` the reference's countAndUpdateTri issues (shared.cpp:316-327), i.e. the
+// algorithmic update count the roofline is priced on. Read straight off the count
+// panels; profiling aid only. grid = (Vq, n_slots), block = 64 (lane = sequence within panel).
+__global__ __launch_bounds__(64) void k_dense_distinct(const uint32_t* C, uint32_t n_panels, int n_slots, uint32_t Vq, u64* U) {
+    const uint32_t kq = blockIdx.x, slot = blockIdx.y, r = threadIdx.x;
+    uint32_t d[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t p = 0; p < n_panels; ++p) {
+        const uint32_t v = C[((size_t)p * n_slots + slot) * ((size_t)Vq * PANEL) + (size_t)kq * PANEL + r];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] += ((v >> (8 * q)) & 255u) ? 1u : 0u;
+    }
+    u64 u = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t x = d[q];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) x += __shfl_xor(x, s);
+        u += (u64)x * (x + 1) / 2;
+    }
+    if (r == 0 && u) atomicAdd(U, u);
+}
+
+// Output-stationary tile accumulate. grid = (n_tiles, n_splits), block = 256 = 16 x 16 lanes,
+// each lane owns an 8x8 block of a 128x128 tile of K. LDS: As/Bs[kq][128 seqs] dwords, i.e. the
+// count panels as they lie in HBM. A-fragment reads are 4 addresses per wave (broadcast),
+// B-fragment reads are 16 consecutive 32-byte segments: conflict-free ds_read_b128.
+// Per key quad and lane: 4 x ds_read_b128 + 64 x v_dot4_u32_u8.
+__device__ __forceinline__ void tile_coords(uint32_t b, uint32_t* ti, uint32_t* tj) {
+    uint32_t t = (uint32_t)((sqrtf(8.0f * (float)b + 1.0f) - 1.0f) * 0.5f);
+    while ((u64)t * (t + 1) / 2 > b) --t;
+    while ((u64)(t + 1) * (t + 2) / 2 <= b) ++t;
+    *ti = t;
+    *tj = b - (uint32_t)((u64)t * (t + 1) / 2);
+}
+
+__global__ __launch_bounds__(256, 2) void k_dense_tile(const uint32_t* C, int n_slots, uint32_t Vq, uint32_t N,
+                                                       u64* K, int slots_per_split) {
+    __shared__ __attribute__((aligned(16))) uint32_t As[STAGE_KQ * TILE];
+    __shared__ __attribute__((aligned(16))) uint32_t Bs[STAGE_KQ * TILE];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    uint32_t ti, tj;
+    tile_coords(blockIdx.x, &ti, &tj);
+    const int s0 = blockIdx.y * slots_per_split;
+    const int s1 = s0 + slots_per_split < n_slots ? s0 + slots_per_split : n_slots;
+    if (s0 >= s1) return;
+    const uint32_t nst = (Vq + STAGE_KQ - 1) / STAGE_KQ;
+    const uint32_t total_stages = (uint32_t)(s1 - s0) * nst;
+    const size_t panel_stride = (size_t)n_slots * Vq * PANEL;  // dwords per panel
+    const size_t slot_stride = (size_t)Vq * PANEL;
+
+    uint32_t acc[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = 0u;
+
+    uint4 pre[8];
+    auto load_stage = [&](uint32_t st) {
+        const uint32_t slot = (uint32_t)s0 + st / nst;
+        const uint32_t kq0 = (st % nst) * STAGE_KQ;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const uint32_t idx = (uint32_t)it * 256u + (uint32_t)tid;  // [0,2048) uint4s
+            const uint32_t which = idx >> 9;                            // A0 A1 B0 B1
+            const uint32_t within = idx & 511u;
+            const uint32_t kq = within >> 4, r4 = within & 15u;
+            const uint32_t panel = (which < 2 ? ti : tj) * 2u + (which & 1u);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (kq0 + kq < Vq) {
+                const uint32_t* src = C + panel * panel_stride + slot * slot_stride + (size_t)(kq0 + kq) * PANEL + r4 * 4u;
+                v = *reinterpret_cast<const uint4*>(src);
+            }
+            pre[it] = v;
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const uint32_t idx = (uint32_t)it * 256u + (uint32_t)tid;
+            const uint32_t which = idx >> 9;
+            const uint32_t within = idx & 511u;
+            const uint32_t kq = within >> 4, r4 = within & 15u;
+            uint32_t* dst = (which < 2 ? As : Bs) + kq * TILE + (which & 1u) * PANEL + r4 * 4u;
+            *reinterpret_cast<uint4*>(dst) = pre[it];
+        }
+    };
+
+    load_stage(0);
+    for (uint32_t st = 0; st < total_stages; ++st) {
+        __syncthreads();  // everyone finished reading the previous stage
+        store_stage();
+        __syncthreads();
+        if (st + 1 < total_stages) load_stage(st + 1);  // in flight under the dot products
+#pragma unroll 4
+        for (int kq = 0; kq < STAGE_KQ; ++kq) {
+            const uint4 a0 = *reinterpret_cast<const uint4*>(&As[kq * TILE + ty * 8]);
+            const uint4 a1 = *reinterpret_cast<const uint4*>(&As[kq * TILE + ty * 8 + 4]);
+            const uint4 b0 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + tx * 8]);
+            const uint4 b1 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + tx * 8 + 4]);
+            const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const uint32_t bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int b = 0; b < 8; ++b) acc[a][b] = __builtin_amdgcn_udot4(av[a], bv[b], acc[a][b], false);
+        }
+    }
+    // flush: one 64-bit atomicAdd per cell of the lower triangle; a wave covers 128 consecutive
+    // cells of one row per (a) step -> 1 KiB contiguous
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const u64 i = (u64)ti * TILE + (u64)(ty * 8 + a);
+        if (i >= N) continue;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const u64 j = (u64)tj * TILE + (u64)(tx * 8 + b);
+            if (j <= i && acc[a][b] != 0u) atomicAdd(&K[tri_index(i, j)], (u64)acc[a][b]);
+        }
+    }
+}
+
+// =============================================================================================
+// SPARSE PATH
+// =============================================================================================
+// key = slot * V + sum_c sym[j+pos_c] * sigma^(k-1-c): one record per (slot, g-mer).
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_sparse_extract(SeqView S, const uint32_t* feat_seq, const uint32_t* fstart,
+                                                        uint32_t nfeat, int k, uint32_t sigma, u64 V,
+                                                        const uint8_t* combo_pos, KeyT* keys, uint32_t* vals) {
+    const uint32_t f = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t slot = blockIdx.y;
+    if (f >= nfeat) return;
+    const uint32_t seq = feat_seq[f];
+    const uint32_t j = f - fstart[seq];
+    const uint32_t wbase = S.wstart[seq];
+    const uint8_t* pos = combo_pos + (size_t)slot * k;
+    u64 key = 0;
+    for (int c = 0; c < k; ++c) key = key * sigma + fetch_sym(S.words, wbase, j + pos[c], S.bits);
+    const size_t o = (size_t)slot * nfeat + f;
+    keys[o] = (KeyT)((u64)slot * V + key);
+    vals[o] = seq;
+}
+
+constexpr int RS_ITEMS = 8;
+constexpr int RS_TILE = 256 * RS_ITEMS;
+
+// pass 1: per-workgroup digit histogram, stored digit-major so each digit row scans linearly
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_rs_hist(const KeyT* keys, u64 n, int shift, uint32_t* blockhist, uint32_t nblocks) {
+    __shared__ uint32_t h[256];
+    const int tid = threadIdx.x;
+    h[tid] = 0u;
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+        const u64 i = base + (u64)it * 256 + tid;
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    blockhist[(size_t)tid * nblocks + blockIdx.x] = h[tid];
+}
+
+// pass 2: one workgroup per digit: exclusive scan of its row in place, row total to totals[digit]
+__global__ __launch_bounds__(256) void k_rs_scan_rows(uint32_t* blockhist, uint32_t nblocks, uint32_t* totals) {
+    __shared__ uint32_t tmp[4];
+    __shared__ uint32_t carry_s;
+    uint32_t* row = blockhist + (size_t)blockIdx.x * nblocks;
+    const int tid = threadIdx.x;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nblocks; base += 1024) {
+        uint32_t v[4], s = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t i = base + (uint32_t)tid * 4u + q;
+            v[q] = i < nblocks ? row[i] : 0u;
+            s += v[q];
+        }
+        uint32_t tot;
+        uint32_t ex = block_excl_scan_256<uint32_t>(s, tmp, &tot) + carry;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t i = base + (uint32_t)tid * 4u + q;
+            if (i < nblocks) row[i] = ex;
+            ex += v[q];
+        }
+        carry += tot;
+    }
+    if (tid == 0) { totals[blockIdx.x] = carry; carry_s = carry; }
+    (void)carry_s;
+}
+
+// pass 3: stable scatter. Ranking inside the workgroup uses wave64 ballot matching (8 ballots
+// give the set of lanes holding the same digit); elements are first permuted into digit order
+// in LDS, then written out so that equal digits go to consecutive addresses.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_rs_scatter(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out,
+                                                    uint32_t* vals_out, u64 n, int shift, const uint32_t* blockhist,
+                                                    const uint32_t* totals, uint32_t nblocks) {
+    __shared__ uint32_t goff[256];         // global destination of this workgroup's first `digit`
+    __shared__ uint32_t wave_cnt[4][256];  // per round: count, then offset, of digit in wave
+    __shared__ uint32_t running[256];      // digit count in earlier rounds
+    __shared__ uint32_t blk_start[256];    // exclusive scan of this workgroup's digit totals
+    __shared__ uint32_t tmp[4];
+    __shared__ KeyT s_keys[RS_TILE];
+    __shared__ uint32_t s_vals[RS_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 base = (u64)blockIdx.x * RS_TILE;
+    {
+        const uint32_t tot = totals[tid];
+        const uint32_t dbase = block_excl_scan_256<uint32_t>(tot, tmp, nullptr);
+        goff[tid] = dbase + blockhist[(size_t)tid * nblocks + blockIdx.x];
+        running[tid] = 0u;
+    }
+    KeyT key[RS_ITEMS];
+    uint32_t val[RS_ITEMS], rank[RS_ITEMS];
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+        const u64 i = base + (u64)it * 256 + tid;
+        const bool valid = i < n;
+        key[it] = valid ? keys_in[i] : (KeyT)0;
+        val[it] = valid ? vals_in[i] : 0u;
+        const uint32_t digit = (uint32_t)(key[it] >> shift) & 255u;
+        u64 peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (digit >> b) & 1u;
+            const u64 m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t rank_in_wave = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        const uint32_t cnt = (uint32_t)__popcll(peers);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wave_cnt[q][tid] = 0u;
+        __syncthreads();
+        if (valid && rank_in_wave == 0) wave_cnt[wave][digit] = cnt;
+        __syncthreads();
+        {
+            uint32_t off = running[tid];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t c = wave_cnt[q][tid];
+                wave_cnt[q][tid] = off;
+                off += c;
+            }
+            running[tid] = off;
+        }
+        __syncthreads();
+        rank[it] = valid ? wave_cnt[wave][digit] + rank_in_wave : 0xffffffffu;
+        __syncthreads();  // wave_cnt is cleared at the top of the next round
+    }
+    {
+        const uint32_t mine = running[tid];
+        const uint32_t ex = block_excl_scan_256<uint32_t>(mine, tmp, nullptr);
+        blk_start[tid] = ex;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+        if (rank[it] != 0xffffffffu) {
+            const uint32_t digit = (uint32_t)(key[it] >> shift) & 255u;
+            const uint32_t p = blk_start[digit] + rank[it];
+            s_keys[p] = key[it];
+            s_vals[p] = val[it];
+        }
+    }
+    __syncthreads();
+    const u64 remain = n - base;
+    const uint32_t nvalid = remain < (u64)RS_TILE ? (uint32_t)remain : (uint32_t)RS_TILE;
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+        const uint32_t p = (uint32_t)it * 256u + (uint32_t)tid;
+        if (p < nvalid) {
+            const KeyT kx = s_keys[p];
+            const uint32_t digit = (uint32_t)(kx >> shift) & 255u;
+            const size_t dst = (size_t)goff[digit] + (p - blk_start[digit]);
+            keys_out[dst] = kx;
+            vals_out[dst] = s_vals[p];
+        }
+    }
+}
+
+// ---- segments: distinct (key, seq) entries and runs of equal keys ---------------------------
+// flag word: low 32 bits count entry heads, high 32 bits count run heads.
+constexpr int SEG_ITEMS = 8;
+constexpr int SEG_TILE = 256 * SEG_ITEMS;
+
+template <typename KeyT>
+__device__ __forceinline__ u64 seg_flag(const KeyT* keys, const uint32_t* vals, u64 i) {
+    if (i == 0) return (1ull << 32) | 1ull;
+    const bool hk = keys[i] != keys[i - 1];
+    const bool hkv = hk || vals[i] != vals[i - 1];
+    return ((u64)hk << 32) | (u64)hkv;
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_seg_reduce(const KeyT* keys, const uint32_t* vals, u64 n, u64* blocksum) {
+    __shared__ u64 tmp[4];
+    const int tid = threadIdx.x;
+    const u64 base = (u64)blockIdx.x * SEG_TILE + (u64)tid * SEG_ITEMS;
+    u64 s = 0;
+#pragma unroll
+    for (int q = 0; q < SEG_ITEMS; ++q)
+        if (base + q < n) s += seg_flag(keys, vals, base + q);
+    u64 tot;
+    block_excl_scan_256<u64>(s, tmp, &tot);
+    if (tid == 0) blocksum[blockIdx.x] = tot;
+}
+
+// single workgroup: exclusive scan of blocksum in place; totals[0]=entries D, totals[1]=runs R;
+// plants the sentinel estart[D] = n.
+__global__ __launch_bounds__(256) void k_seg_scan_blocks(u64* blocksum, uint32_t nblocks, u64 n, uint32_t* totals,
+                                                         uint32_t* estart) {
+    __shared__ u64 tmp[4];
+    const int tid = threadIdx.x;
+    u64 carry = 0;
+    for (uint32_t base = 0; base < nblocks; base += 256) {
+        const uint32_t i = base + (uint32_t)tid;
+        const u64 v = i < nblocks ? blocksum[i] : 0ull;
+        u64 tot;
+        const u64 ex = block_excl_scan_256<u64>(v, tmp, &tot) + carry;
+        if (i < nblocks) blocksum[i] = ex;
+        carry += tot;
+    }
+    if (tid == 0) {
+        const uint32_t D = (uint32_t)(carry & 0xffffffffull);
+        totals[0] = D;
+        totals[1] = (uint32_t)(carry >> 32);
+        estart[D] = (uint32_t)n;
+    }
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_seg_write(const KeyT* keys, const uint32_t* vals, u64 n, const u64* blocksum,
+                                                   uint32_t* estart, uint32_t* eseq, uint32_t* erun, uint32_t* rstart) {
+    __shared__ u64 tmp[4];
+    const int tid = threadIdx.x;
+    const u64 base = (u64)blockIdx.x * SEG_TILE + (u64)tid * SEG_ITEMS;
+    u64 fl[SEG_ITEMS], s = 0;
+#pragma unroll
+    for (int q = 0; q < SEG_ITEMS; ++q) {
+        fl[q] = base + q < n ? seg_flag(keys, vals, base + q) : 0ull;
+        s += fl[q];
+    }
+    u64 ex = block_excl_scan_256<u64>(s, tmp, nullptr) + blocksum[blockIdx.x];
+#pragma unroll
+    for (int q = 0; q < SEG_ITEMS; ++q) {
+        if (fl[q] & 1ull) {  // entry head
+            const uint32_t e = (uint32_t)(ex & 0xffffffffull);
+            const uint32_t hk = (uint32_t)(fl[q] >> 32);
+            const uint32_t run = (uint32_t)(ex >> 32) + hk - 1u;  // runs started up to here, minus 1
+            estart[e] = (uint32_t)(base + q);
+            eseq[e] = vals[base + q];
+            erun[e] = run;
+            if (hk) rstart[run] = e;
+        }
+        ex += fl[q];
+    }
+}
+
+// per (run, pair) atomics: entry e pairs with every earlier entry of its run and itself —
+// exactly the += the reference issues (shared.cpp:316-327). U counts them.
+__global__ __launch_bounds__(256) void k_sparse_pairs(const uint32_t* totals, const uint32_t* estart, const uint32_t* eseq,
+                                                      const uint32_t* erun, const uint32_t* rstart, u64* K, u64* U) {
+    const uint32_t D = totals[0];
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    const bool active = e < D;
+    u64 work = 0;
+    if (active) {
+        const u64 sa = eseq[e];
+        const u64 ca = estart[e + 1] - estart[e];
+        const uint32_t rs = rstart[erun[e]];
+        for (uint32_t b = rs; b <= e; ++b) {
+            const u64 sb = eseq[b];
+            const u64 cb = estart[b + 1] - estart[b];
+            const u64 i = sa > sb ? sa : sb, j = sa > sb ? sb : sa;
+            atomicAdd(&K[tri_index(i, j)], ca * cb);
+        }
+        work = (u64)(e - rs + 1u);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) work += __shfl_xor(work, d);
+    if ((threadIdx.x & 63) == 0 && work) atomicAdd(U, work);
+}
+
+// =============================================================================================
+// NORMALISATION / GETTERS  (fastsk_kernel.cpp:96-103, fastsk.cpp:190-217)
+// IEEE fp64 multiply, correctly rounded sqrt and divide, no contraction.
+// =============================================================================================
+template <typename SrcT>
+__global__ __launch_bounds__(256) void k_diag(const SrcT* K, double* diag, uint32_t N) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < N) diag[i] = (double)K[tri_index(i, i)];
+}
+
+__device__ __forceinline__ double normalised_cell(double x, double di, double dj, bool is_diag) {
+    // off-diagonal: K_ij / sqrt(K_ii * K_jj) with the RAW diagonals; diagonal: K_ii / sqrt(K_ii*K_ii)
+    const double prod = is_diag ? __dmul_rn(x, x) : __dmul_rn(di, dj);
+    return __ddiv_rn(x, __dsqrt_rn(prod));
+}
+
+template <typename SrcT>
+__global__ __launch_bounds__(256) void k_block(const SrcT* K, const double* diag, u64 i0, u64 rows, u64 j0, u64 cols,
+                                               double* out) {
+    const u64 c = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (c >= rows * cols) return;
+    const u64 i = i0 + c / cols, j = j0 + c % cols;
+    const u64 a = i > j ? i : j, b = i > j ? j : i;
+    const double x = (double)K[tri_index(a, b)];
+    out[c] = normalised_cell(x, diag[a], diag[b], a == b);
+}
+
+template <typename SrcT>
+__global__ __launch_bounds__(256) void k_block_raw(const SrcT* K, u64 i0, u64 rows, u64 j0, u64 cols, SrcT* out) {
+    const u64 c = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (c >= rows * cols) return;
+    const u64 i = i0 + c / cols, j = j0 + c % cols;
+    const u64 a = i > j ? i : j, b = i > j ? j : i;
+    out[c] = K[tri_index(a, b)];
+}
+
+// whole triangle, cells [c0, c0+count) of the reference layout
+template <typename SrcT>
+__global__ __launch_bounds__(256) void k_triangle(const SrcT* K, const double* diag, u64 c0, u64 count, double* out) {
+    const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= count) return;
+    const u64 c = c0 + t;
+    u64 i = (u64)((sqrt(8.0 * (double)c + 1.0) - 1.0) * 0.5);
+    while (i * (i + 1) / 2 > c) --i;
+    while ((i + 1) * (i + 2) / 2 <= c) ++i;
+    const u64 j = c - i * (i + 1) / 2;
+    const double x = (double)K[c];
+    out[t] = normalised_cell(x, diag[i], diag[j], i == j);
+}
+
+// =============================================================================================
+// APPROX / VARIANCE MODE  (get_variance, fastsk_kernel.cpp:108-143)
+// =============================================================================================
+// K_hat += (Ks - K_hat)/iter; prod = delta * (Ks - K_hat') for the train x train prefix.
+// The reference then sums prod sequentially in index order; that one reduction stays on the host.
+__global__ __launch_bounds__(256) void k_welford(const u64* Ks, double* K_hat, double* prod, u64 pairs, u64 train_pairs,
+                                                 double iter) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pairs) return;
+    const double x = (double)Ks[i];
+    const double delta = __dsub_rn(x, K_hat[i]);
+    const double kh = __dadd_rn(K_hat[i], __ddiv_rn(delta, iter));
+    K_hat[i] = kh;
+    if (i < train_pairs) prod[i] = __dmul_rn(delta, __dsub_rn(x, kh));
+}
+
+// K += val where val != 0 (fastsk_kernel.cpp:286-315)
+template <typename SrcT>
+__global__ __launch_bounds__(256) void k_add_nonzero(double* K, const SrcT* src, u64 pairs) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pairs) return;
+    const double v = (double)src[i];
+    if (v != 0.0) K[i] = __dadd_rn(K[i], v);
+}
+
+}  // namespace fsk

@@ -1,0 +1,161 @@
+/*
+ * fastsk_amd.h — C ABI of the MI355X-native gapped-k-mer kernel engine (libfastsk_amd.so).
+ *
+ * This is the drop-in boundary for ONE path of QData/FastSK: the per-mismatch-combination
+ * partial-kernel worker behind fastsk.FastSK(g,m,...).compute_kernel(Xtrain,Xtest). Every entry
+ * point names the reference interface it replaces (paths relative to
+ * /root/reference/src/fastsk/_fastsk). Plain pointers and sizes only: no C++ types, no torch
+ * types, no exceptions across the boundary. All functions return FSK_OK (0) or a negative
+ * FSK_E* code; fsk_last_error() holds the message. INTEGRATION.md shows the pybind11 binding a
+ * reference maintainer would write against this header.
+ *
+ * Data conventions (same as the reference):
+ *   - sequences arrive as one int32 token array + int64 offsets (n_train rows first, then
+ *     n_test rows), i.e. the flattened form of the vector<vector<int>> arguments of
+ *     FastSK::compute_kernel (fastsk.cpp:30); buffers are caller-owned and only read during
+ *     the call;
+ *   - the kernel triangle is row-major lower-triangular, cell (i,j), j<=i, at i(i+1)/2+j
+ *     (tri_access, shared.cpp:97-117), N = n_train + n_test;
+ *   - combination id c is the c-th (g-m)-subset of {0..g-1} in lexicographic order
+ *     (getCombinations, shared.cpp:347-360).
+ */
+#ifndef FASTSK_AMD_H
+#define FASTSK_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSK_ABI_VERSION 1
+
+enum {
+    FSK_OK = 0,
+    FSK_EINVAL = -1,   /* bad argument (g<=m, m<0, null pointer, bad combo id, ...)              */
+    FSK_ESHORT = -2,   /* g > shortest sequence: the reference printf+exit(1)s, fastsk.cpp:53-58 */
+    FSK_ESTATE = -3,   /* call out of order (e.g. getter before compute)                          */
+    FSK_EDEVICE = -4,  /* HIP runtime error / no device                                           */
+    FSK_ENOMEM = -5,   /* device or host allocation failed                                        */
+    FSK_EUNSUPPORTED = -6 /* alphabet > 256 symbols or (g-m)*log2(alphabet) > 62 bits            */
+};
+
+/* accumulate dataflow */
+enum {
+    FSK_PATH_AUTO = 0,
+    FSK_PATH_DENSE = 1,  /* per-sequence LDS counting sort -> u8 count panels -> LDS-tiled
+                            integer co-occurrence accumulate, one 64-bit atomicAdd per cell      */
+    FSK_PATH_SPARSE = 2  /* radix sort of (k-mer, seq) -> run-length segments -> 64-bit atomicAdd
+                            per (run, pair): the reference's dataflow, cntsrtna+countAndUpdateTri */
+};
+
+typedef struct fsk_engine fsk_engine; /* opaque; replaces class FastSK + KernelFunction state */
+
+/* Constructor arguments of FastSK (bindings.cpp:14-22, fastsk.cpp:19-28), plus placement. */
+typedef struct fsk_config {
+    int32_t g;             /* g-mer length                                                      */
+    int32_t m;             /* mismatch positions; k = g - m kept positions (fastsk.cpp:22)      */
+    int32_t t;             /* host threads in the reference; here: number of approx-mode chains
+                              (-1 -> 20, capped at #combos: fastsk_kernel.cpp:54-61)            */
+    int32_t approx;        /* 0 exact, 1 approx (fastsk_kernel.cpp:188-262)                     */
+    double delta;          /* approx convergence threshold (default 0.025)                      */
+    int32_t max_iters;     /* approx: max combos per chain, -1 = unlimited                      */
+    int32_t skip_variance; /* approx: integer sums, no Welford chain                            */
+    int32_t device;        /* HIP device ordinal                                                */
+    int32_t path;          /* FSK_PATH_*                                                        */
+    int32_t profile;       /* 1: time every kernel family with HIP events (fsk_get_stats)       */
+    int32_t reserved[5];
+} fsk_config;
+
+/* Measured and algorithmic quantities of the work done so far. */
+typedef struct fsk_stats {
+    int64_t n_seq, n_train, n_test, n_feat, n_pairs;
+    int32_t alphabet;        /* distinct tokens actually present (rank-remapped 0..alphabet-1)  */
+    int32_t bits_per_symbol; /* packed width in HBM                                             */
+    int64_t key_space;       /* alphabet^k                                                      */
+    int32_t path_used;       /* FSK_PATH_DENSE / FSK_PATH_SPARSE                                */
+    int32_t n_combos_total;  /* C(g,m)                                                          */
+    int64_t combos_done;     /* combos accumulated so far                                       */
+    uint64_t cell_updates;   /* U = sum over runs d(d+1)/2 (sparse path: exact; dense: 0)       */
+    uint64_t sort_records;   /* records pushed through the radix sort                           */
+    int32_t sort_passes;     /* 8-bit LSD passes per batch                                      */
+    int32_t launches;        /* kernel launches in accumulate                                   */
+    /* HIP-event milliseconds on the engine's stream (profile=1), summed over launches         */
+    double ms_count;         /* dense: k-mer extraction + LDS counting sort -> count panels     */
+    double ms_tile;          /* dense: tiled co-occurrence accumulate + flush                   */
+    double ms_extract;       /* sparse: key extraction                                          */
+    double ms_sort;          /* sparse: radix sort                                              */
+    double ms_segment;       /* sparse: run/segment detection + compaction                      */
+    double ms_pairs;         /* sparse: per-run pair atomics                                    */
+    double ms_total;         /* whole accumulate calls                                          */
+    int64_t n_tile_launches; /* launches of the tile kernel (for per-launch averages)           */
+    uint64_t dense_macs;     /* 8-bit multiply-adds issued by the tile kernel                   */
+    uint64_t panel_bytes;    /* bytes of count panels written (= read at least once)            */
+    double reserved[6];
+} fsk_stats;
+
+/* ---- lifecycle: replaces FastSK::FastSK (fastsk.cpp:19-28) and ~nothing (the reference leaks) */
+int fsk_create(const fsk_config* cfg, fsk_engine** out);
+void fsk_destroy(fsk_engine* e);
+/* message of the last failure on `e` (or of the last failed fsk_create when e == NULL) */
+const char* fsk_last_error(const fsk_engine* e);
+int fsk_abi_version(void);
+/* number of visible HIP devices (<0 on runtime error) */
+int fsk_device_count(void);
+
+/* ---- one-call path: replaces FastSK::compute_kernel (fastsk.cpp:30-118, n_test > 0) and
+ * FastSK::compute_train (fastsk.cpp:120-188, n_test == 0) including
+ * KernelFunction::compute_kernel (fastsk_kernel.cpp:24-106): exact / skip-variance / variance
+ * modes per the config. Blocks until the result is resident on the device. */
+int fsk_compute(fsk_engine* e, const int32_t* tokens, const int64_t* offsets, int64_t n_train,
+                int64_t n_test);
+
+/* Combo order used by the approx modes. Replaces the time(0)-seeded std::shuffle of
+ * fastsk_kernel.cpp:29-38 with an explicit permutation (or prefix of one) of 0..C(g,m)-1.
+ * Without it approx mode draws its own seeded Fisher-Yates order (fsk_set_seed). */
+int fsk_set_combo_order(fsk_engine* e, const int32_t* order, int32_t n);
+int fsk_set_seed(fsk_engine* e, uint64_t seed);
+
+/* ---- staged path (multi-GPU sharding, benchmarking with inputs resident in HBM) ------------ */
+/* lengths check + dictionary + packing + H2D: fastsk.cpp:32-88 (extractFeatures is replaced by
+ * bit-packed sequences that every combo re-reads) */
+int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offsets, int64_t n_train,
+                       int64_t n_test);
+/* Use caller-provided device memory (uint64[n_pairs], e.g. a torch tensor that RCCL will
+ * all-reduce) for the integer triangle instead of an engine-owned allocation. */
+int fsk_bind_counts(fsk_engine* e, void* device_u64, int64_t n_cells);
+/* device address of the integer triangle (engine-owned or bound) */
+int fsk_counts_device_ptr(fsk_engine* e, void** out);
+int fsk_reset_counts(fsk_engine* e);
+/* THE HOT PATH. Adds the partial kernels of the listed combos into the integer triangle:
+ * the loop body of kernel_build_parallel (fastsk_kernel.cpp:188-281) for each combo, and the
+ * K += Ks reduce (fastsk_kernel.cpp:286-315). Asynchronous on the engine's stream. */
+int fsk_accumulate(fsk_engine* e, const int32_t* combos, int32_t n);
+/* wait for the engine's stream */
+int fsk_synchronize(fsk_engine* e);
+/* extract the raw diagonal for normalisation (fastsk_kernel.cpp:96-103); call after the last
+ * accumulate (and after any cross-GPU all-reduce of the triangle) */
+int fsk_finalize(fsk_engine* e);
+
+/* ---- results: replace the getters of fastsk.cpp:190-221 ---------------------------------- */
+/* normalised K[i0:i1, j0:j1] as row-major doubles, any sub-block of the symmetric N x N matrix */
+int fsk_get_block(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1, double* out);
+int fsk_get_train(fsk_engine* e, double* out);      /* n_train x n_train, get_train_kernel()   */
+int fsk_get_test(fsk_engine* e, double* out);       /* n_test  x n_train, get_test_kernel()    */
+int fsk_get_triangle(fsk_engine* e, double* out);   /* double[N(N+1)/2], the reference's K     */
+int fsk_get_counts(fsk_engine* e, uint64_t* out);   /* raw integer triangle (exact/skip-var)   */
+int fsk_get_counts_block(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint64_t* out);
+/* approx/variance mode: thread 0's convergence trace, get_stdevs() (fastsk.cpp:219-221) */
+int fsk_get_stdevs(fsk_engine* e, double* out, int32_t cap, int32_t* n);
+/* "%d:%e " text dump, one row per line, 1-based column ids: save_kernel (fastsk.cpp:223-237) */
+int fsk_save_kernel(fsk_engine* e, const char* path);
+int fsk_get_stats(fsk_engine* e, fsk_stats* out);
+
+/* ---- helpers shared with the host side --------------------------------------------------- */
+int64_t fsk_num_combos(int32_t g, int32_t m);                              /* nchoosek */
+int fsk_combo_positions(int32_t g, int32_t k, int64_t combo, int32_t* out); /* getCombinations */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTSK_AMD_H */

@@ -1,0 +1,281 @@
+// tests/emu/hip_emu.h — TEST INFRASTRUCTURE ONLY.
+//
+// A tiny single-process emulator of the subset of HIP that fastsk_amd/csrc uses, so that the
+// kernels' *logic* (indexing, barriers, wave64 ballots/shuffles, LDS staging, atomics) can be
+// exercised by `pytest -m "not gpu"` in a container that has no GPU. It is compiled ONLY into
+// tests/emu/libfastsk_emu.so by tests/emu/build_emu.py; the product library (hipcc, gfx950)
+// never sees this file and the product loader never loads the emulated library.
+//
+// Model: a launch runs its workgroups one after another on the calling OS thread; the threads of
+// one workgroup are ucontext fibers scheduled round-robin, switching only at __syncthreads() and
+// at wave-collective operations (__ballot/__shfl*). `__shared__` becomes `static`, which is sound
+// because only one workgroup is alive at a time. Wavefront width is 64, as on gfx950.
+// Limitations: wave collectives must be reached by every live lane of the wave (no divergent
+// ballots); there is no memory-model emulation (races that need two CUs cannot be found here).
+#pragma once
+#include <ucontext.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define FSK_EMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct ulonglong2 { unsigned long long x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+
+namespace emu {
+constexpr int WAVE = 64;
+constexpr size_t STACK = 128 * 1024;
+
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    bool done = false;
+    dim3 tid;
+};
+
+struct Block {
+    std::vector<Fiber> fibers;
+    ucontext_t sched;
+    int cur = 0;
+    int nthreads = 0;
+    int live = 0;
+    // block barrier
+    int bar_count = 0;
+    unsigned bar_gen = 0;
+    // per-wave collective slots
+    struct WaveSlot {
+        unsigned long long vals[WAVE];
+        bool pred[WAVE];
+        bool present[WAVE];
+        int arrived = 0;
+        int live = 0;
+        unsigned gen = 0;
+        unsigned long long ballot = 0;
+        unsigned long long snap[WAVE];
+    };
+    std::vector<WaveSlot> waves;
+    dim3 bid, bdim, gdim;
+    char* dyn_shared = nullptr;
+    const std::function<void()>* body = nullptr;
+};
+
+inline Block*& cur_block() {
+    static Block* b = nullptr;
+    return b;
+}
+
+inline void yield() {
+    Block* b = cur_block();
+    Fiber& f = b->fibers[b->cur];
+    swapcontext(&f.ctx, &b->sched);
+}
+
+inline void fiber_entry() {
+    Block* b = cur_block();
+    (*b->body)();
+    Fiber& f = b->fibers[b->cur];
+    f.done = true;
+    b->live--;
+    b->waves[b->cur / WAVE].live--;
+    // a thread that exits counts as arrived for any barrier others are waiting on
+    if (b->live > 0 && b->bar_count >= b->live) { b->bar_count = 0; b->bar_gen++; }
+    Block::WaveSlot& w = b->waves[b->cur / WAVE];
+    if (w.live > 0 && w.arrived >= w.live) {
+        // complete a pending wave collective on behalf of the remaining lanes
+        unsigned long long m = 0;
+        for (int l = 0; l < WAVE; ++l) if (w.present[l] && w.pred[l]) m |= 1ull << l;
+        w.ballot = m;
+        memcpy(w.snap, w.vals, sizeof(w.snap));
+        w.arrived = 0;
+        for (int l = 0; l < WAVE; ++l) w.present[l] = false;
+        w.gen++;
+    }
+    swapcontext(&f.ctx, &b->sched);
+}
+
+inline void run_block(Block& b) {
+    cur_block() = &b;
+    b.live = b.nthreads;
+    b.bar_count = 0;
+    for (auto& w : b.waves) { w.arrived = 0; w.live = 0; for (int l = 0; l < WAVE; ++l) w.present[l] = false; }
+    for (int t = 0; t < b.nthreads; ++t) {
+        Fiber& f = b.fibers[t];
+        f.done = false;
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = STACK;
+        f.ctx.uc_link = &b.sched;
+        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+        b.waves[t / WAVE].live++;
+    }
+    while (b.live > 0) {
+        for (int t = 0; t < b.nthreads; ++t) {
+            if (b.fibers[t].done) continue;
+            b.cur = t;
+            swapcontext(&b.sched, &b.fibers[t].ctx);
+        }
+    }
+}
+
+inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
+    static Block b;  // fibers (and their stacks) are reused across launches
+    int nthreads = (int)(block.x * block.y * block.z);
+    if ((int)b.fibers.size() < nthreads) {
+        size_t old = b.fibers.size();
+        b.fibers.resize(nthreads);
+        for (size_t i = old; i < b.fibers.size(); ++i) b.fibers[i].stack = (char*)malloc(STACK);
+    }
+    b.nthreads = nthreads;
+    b.waves.resize((nthreads + WAVE - 1) / WAVE);
+    b.bdim = block;
+    b.gdim = grid;
+    b.body = &body;
+    std::vector<char> dyn(shmem + 64);
+    b.dyn_shared = dyn.data();
+    for (int t = 0; t < nthreads; ++t)
+        b.fibers[t].tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+    for (unsigned z = 0; z < grid.z; ++z)
+        for (unsigned y = 0; y < grid.y; ++y)
+            for (unsigned x = 0; x < grid.x; ++x) {
+                b.bid = dim3(x, y, z);
+                run_block(b);
+            }
+    cur_block() = nullptr;
+}
+
+inline void syncthreads() {
+    Block* b = cur_block();
+    unsigned gen = b->bar_gen;
+    if (++b->bar_count >= b->live) { b->bar_count = 0; b->bar_gen++; return; }
+    while (b->bar_gen == gen) yield();
+}
+
+// wave collective: every live lane deposits (pred, val); returns after all have.
+inline Block::WaveSlot& wave_exchange(bool pred, unsigned long long val) {
+    Block* b = cur_block();
+    int lane = b->cur % WAVE;
+    Block::WaveSlot& w = b->waves[b->cur / WAVE];
+    w.pred[lane] = pred;
+    w.vals[lane] = val;
+    w.present[lane] = true;
+    unsigned gen = w.gen;
+    if (++w.arrived >= w.live) {
+        unsigned long long m = 0;
+        for (int l = 0; l < WAVE; ++l) if (w.present[l] && w.pred[l]) m |= 1ull << l;
+        w.ballot = m;
+        memcpy(w.snap, w.vals, sizeof(w.snap));
+        w.arrived = 0;
+        for (int l = 0; l < WAVE; ++l) w.present[l] = false;
+        w.gen++;
+    } else {
+        while (w.gen == gen) yield();
+    }
+    return w;
+}
+inline int lane_id() { return cur_block()->cur % WAVE; }
+}  // namespace emu
+
+#define threadIdx (emu::cur_block()->fibers[emu::cur_block()->cur].tid)
+#define blockIdx (emu::cur_block()->bid)
+#define blockDim (emu::cur_block()->bdim)
+#define gridDim (emu::cur_block()->gdim)
+#define FSK_DYN_SHARED(type, name) type* name = (type*)(((uintptr_t)emu::cur_block()->dyn_shared + 15) & ~(uintptr_t)15)
+
+static inline void __syncthreads() { emu::syncthreads(); }
+static inline unsigned long long __ballot(int pred) { return emu::wave_exchange(pred != 0, 0).ballot; }
+template <typename T> static inline T __shfl(T v, int src) {
+    unsigned long long raw = 0;
+    memcpy(&raw, &v, sizeof(T));
+    auto& w = emu::wave_exchange(false, raw);
+    // snapshot taken at completion: safe even if other lanes start the next collective first
+    unsigned long long r = w.snap[src & 63];
+    T out;
+    memcpy(&out, &r, sizeof(T));
+    return out;
+}
+template <typename T> static inline T __shfl_up(T v, unsigned d) {
+    int l = emu::lane_id();
+    T o = __shfl(v, l - (int)d < 0 ? l : l - (int)d);
+    return o;
+}
+template <typename T> static inline T __shfl_down(T v, unsigned d) {
+    int l = emu::lane_id();
+    return __shfl(v, l + (int)d > 63 ? l : l + (int)d);
+}
+template <typename T> static inline T __shfl_xor(T v, int m) { return __shfl(v, emu::lane_id() ^ m); }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+static inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
+static inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
+
+template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, int v) { unsigned o = *p; *p = o + (unsigned)v; return o; }
+template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+
+static inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool) {
+    for (int i = 0; i < 4; ++i) c += ((a >> (8 * i)) & 255u) * ((b >> (8 * i)) & 255u);
+    return c;
+}
+static inline double __dsqrt_rn(double x) { return __builtin_sqrt(x); }
+static inline double __dmul_rn(double a, double b) { return a * b; }
+static inline double __ddiv_rn(double a, double b) { return a / b; }
+static inline double __dadd_rn(double a, double b) { return a + b; }
+static inline double __dsub_rn(double a, double b) { return a - b; }
+
+// ---- host runtime shims ---------------------------------------------------------------------
+typedef int hipError_t;
+typedef void* hipStream_t;
+struct emuEvent { std::chrono::steady_clock::time_point t; };
+typedef emuEvent* hipEvent_t;
+constexpr hipError_t hipSuccess = 0;
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipSetDevice(int) { return 0; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
+template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+static inline hipError_t hipFree(void* p) { free(p); return 0; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return 0; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static inline hipError_t hipDeviceSynchronize() { return 0; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emuEvent; return 0; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return 0; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return 0;
+}
+static inline hipError_t hipMemGetInfo(size_t* fr, size_t* tot) { *fr = *tot = (size_t)8 << 30; return 0; }
+
+#define FSK_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    emu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })

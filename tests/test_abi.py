@@ -1,0 +1,72 @@
+"""The C-ABI library loads and exports every symbol include/fastsk_amd.h declares (no compute
+calls: there is no GPU here), and the product refuses to run without a device."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "fastsk_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fsk_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def product_lib():
+    import __graft_entry__ as ge
+    ge.build_engine()
+    from fastsk_amd import _native
+    return _native.Library()
+
+
+def test_every_declared_symbol_is_exported(product_lib):
+    from fastsk_amd import _native
+    names = header_functions()
+    assert len(names) >= 25
+    assert sorted(_native.SYMBOLS) == names, "ctypes view and header disagree"
+    for n in names:
+        assert hasattr(product_lib.L, n), n
+    assert product_lib.L.fsk_abi_version() == 1
+
+
+def test_host_helpers_without_gpu(product_lib):
+    import itertools
+    assert product_lib.num_combos(12, 8) == 495 and product_lib.num_combos(14, 10) == 1001
+    want = list(itertools.combinations(range(10), 4))
+    for c in (0, 57, 209):
+        assert tuple(product_lib.combo_positions(10, 4, c)) == want[c]
+
+
+def test_no_cpu_fallback(product_lib):
+    """Without a device the product must fail loudly, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from fastsk_amd import _native
+    with pytest.raises(_native.FskError) as ei:
+        _native.Engine(10, 6, lib=product_lib)
+    assert ei.value.code == -4 and "no CPU fallback" in str(ei.value)
+
+
+def test_pybind_surface_signature():
+    """Same class, keywords and defaults as the reference (bindings.cpp:12-44)."""
+    import __graft_entry__ as ge
+    ge.build_engine()
+    ge.build_bindings()
+    from fastsk_amd import _fastsk
+    doc = _fastsk.FastSK.__init__.__doc__
+    order = [doc.index(" %s: " % kw) for kw in ("g", "m", "t", "approx", "delta", "max_iters", "skip_variance")]
+    assert order == sorted(order), "positional order differs from the reference"
+    for pat in (r"t: [^,]*= -1", r"approx: bool = False", r"delta: [^,]*= 0.025", r"max_iters: [^,]*= -1",
+                r"skip_variance: bool = False"):
+        assert re.search(pat, doc), pat
+    for meth in ("compute_kernel", "compute_train", "get_train_kernel", "get_test_kernel", "get_stdevs",
+                 "save_kernel", "fit", "score"):
+        assert hasattr(_fastsk.FastSK, meth)
+    assert _fastsk.__version__ == "dev"
+    import fastsk  # the drop-in package name
+    assert fastsk.FastSK is _fastsk.FastSK and fastsk.FastaUtility is not None

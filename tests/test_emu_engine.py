@@ -1,0 +1,166 @@
+"""Kernel LOGIC on the CPU: the engine's HIP source compiled against tests/emu/hip_emu.h
+(fibers + wave64 collectives) must reproduce the golden vectors bit for bit through the C ABI.
+This does not replace the GPU parity tests (tests/test_gpu_parity.py); it catches indexing,
+barrier and ranking mistakes without spending GPU minutes."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden, tri_to_square, ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    import build_emu
+    from fastsk_amd import _native
+    return _native.Library(build_emu.build())
+
+
+def run_case(emu_lib, d, path):
+    from fastsk_amd import _native
+    e = _native.Engine(d["g"], d["m"], t=d["t"], approx=bool(d["approx"]), delta=d["delta"],
+                       max_iters=d["max_iters"], skip_variance=bool(d["skip_variance"]), path=path, lib=emu_lib)
+    if d["approx"]:
+        e.set_combo_order(d["order"])
+    e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+    return e
+
+
+SMALL = [n for n in golden_names() if n.split("_")[0] in ("f1", "f2", "f3")]
+
+
+@pytest.mark.parametrize("path", [1, 2])
+@pytest.mark.parametrize("name", SMALL)
+def test_emu_small_cases_both_paths(emu_lib, name, path):
+    d = load_golden(name)
+    e = run_case(emu_lib, d, path)
+    N = d["n_train"] + d["n_test"]
+    assert np.array_equal(e.get_counts(), d["counts"])
+    assert np.array_equal(e.get_triangle(), d["tri"])
+    assert np.array_equal(e.get_train(), d["train"])
+    if d["n_test"]:
+        assert np.array_equal(e.get_test(), d["test"])
+    sq = tri_to_square(d["tri"], N)
+    assert np.array_equal(e.get_block(0, N, 0, N), sq)
+    st = e.stats()
+    assert st["path_used"] == path and st["combos_done"] == len(d["combos"])
+    e.close()
+
+
+def test_emu_ep300_slice_exact_dense(emu_lib):
+    d = load_golden("f4_ep300_exact")
+    e = run_case(emu_lib, d, 0)
+    assert e.stats()["path_used"] == 1  # DNA, 4^4 keys -> dense
+    assert np.array_equal(e.get_counts(), d["counts"])
+    assert np.array_equal(e.get_triangle(), d["tri"])
+    assert np.array_equal(e.get_test(), d["test"])
+
+
+@pytest.mark.parametrize("name,path,ncombo", [("f4_ep300_exact", 2, 9), ("f5_prot11_exact", 0, 14),
+                                               ("f6_prot219_exact", 0, 40), ("f6_ep47848_slice_exact", 1, 210),
+                                               ("f6_ep47848_slice_exact", 2, 6)])
+def test_emu_staged_accumulate_vs_port(emu_lib, port, name, path, ncombo):
+    """load -> accumulate (two calls) -> finalize, against the oracle on the same combos."""
+    from fastsk_amd import _native
+    d = load_golden(name)
+    nc = port.num_combos(d["g"], d["m"])
+    combos = np.linspace(0, nc - 1, ncombo).astype(np.int32)
+    combos = np.unique(combos)
+    want, _, U = port.raw_counts(d["tokens"], d["offsets"], d["g"], d["m"], combos)
+    e = _native.Engine(d["g"], d["m"], path=path, lib=emu_lib)
+    e.load_sequences(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+    half = len(combos) // 2
+    e.accumulate(combos[:half])
+    e.accumulate(combos[half:])
+    e.finalize()
+    assert np.array_equal(e.get_counts(), want)
+    N = d["n_train"] + d["n_test"]
+    assert np.array_equal(e.get_triangle(), port.normalise(want.astype(np.float64), N))
+    st = e.stats()
+    if st["path_used"] == 2:
+        assert st["cell_updates"] == U  # the engine issues exactly the reference's `+=` count
+    blk = e.get_counts_block(3, 17, 1, 9)
+    assert np.array_equal(blk, tri_to_square(want, N)[3:17, 1:9])
+
+
+@pytest.mark.parametrize("name", ["f4_ep300_skipvar_T1", "f4_ep300_skipvar_T3", "f4_ep300_variance_T1",
+                                  "f4_ep300_variance_T1_conv", "f5_prot11_variance_T1", "f6_prot219_skipvar16"])
+def test_emu_approx_modes(emu_lib, name):
+    d = load_golden(name)
+    e = run_case(emu_lib, d, 0)
+    assert np.array_equal(e.get_triangle(), d["tri"])
+    assert np.array_equal(e.get_stdevs(), d["stdevs"])
+    assert np.array_equal(e.get_train(), d["train"])
+    assert np.array_equal(e.get_test(), d["test"])
+    if "counts" in d:
+        assert np.array_equal(e.get_counts(), d["counts"])
+
+
+def test_emu_bound_counts_buffer_and_reset(emu_lib, port):
+    """fsk_bind_counts: the integer triangle lives in caller-provided memory (on the GPU: a torch
+    tensor that RCCL all-reduces). Under emulation device memory is host memory."""
+    from fastsk_amd import _native
+    d = load_golden("f3_ragged_sigma7_g6m3")
+    N = d["n_train"] + d["n_test"]
+    buf = np.full(N * (N + 1) // 2, 7, dtype=np.uint64)
+    e = _native.Engine(d["g"], d["m"], lib=emu_lib)
+    e.bind_counts(buf.ctypes.data, buf.size, keepalive=buf)
+    e.load_sequences(d["tokens"], d["offsets"], d["n_train"], d["n_test"])  # zeroes the bound buffer
+    assert e.counts_device_ptr() == buf.ctypes.data
+    e.accumulate(d["combos"][:5])
+    e.synchronize()
+    want5, _, _ = port.raw_counts(d["tokens"], d["offsets"], d["g"], d["m"], d["combos"][:5])
+    assert np.array_equal(buf, want5)
+    e.reset_counts()
+    e.accumulate(d["combos"])
+    e.finalize()
+    assert np.array_equal(buf, d["counts"])
+    assert np.array_equal(e.get_triangle(), d["tri"])
+
+
+def test_emu_error_convention(emu_lib):
+    from fastsk_amd import _native
+    with pytest.raises(_native.FskError) as ei:
+        _native.Engine(3, 3, lib=emu_lib)
+    assert ei.value.code == -1
+    e = _native.Engine(6, 2, lib=emu_lib)
+    tok, off = _native.flatten([[1, 2, 3, 4, 1, 2, 3], [1, 2, 3, 4, 1]])
+    with pytest.raises(_native.FskError) as ei:  # reference: printf + exit(1), fastsk.cpp:53-58
+        e.compute(tok, off, 1, 1)
+    assert ei.value.code == -2 and "shortest test sequence has length 5" in str(ei.value)
+    with pytest.raises(_native.FskError) as ei:
+        e.get_train()
+    assert ei.value.code == -3
+    tok, off = _native.flatten([[1, 2, 3, 4, 1, 2, 3], [1, 2, 3, 4, 1, 4]])
+    e.load_sequences(tok, off, 2, 0)
+    with pytest.raises(_native.FskError) as ei:
+        e.accumulate([15])
+    assert ei.value.code == -1
+    e.accumulate(np.arange(15))
+    e.finalize()
+    assert e.get_test().shape == (0, 2)
+    assert e.get_train()[0, 0] == 1.0
+
+
+def test_emu_relabelled_and_wide_alphabets(emu_lib, port):
+    from fastsk_amd import _native
+    d = load_golden("f3_ragged_sigma7_g6m3")
+    remap = np.array([0, 1000, 7, 300000, -12, 99, 5, 2 ** 30], dtype=np.int32)
+    e = _native.Engine(d["g"], d["m"], lib=emu_lib)
+    e.compute(remap[d["tokens"]], d["offsets"], d["n_train"], d["n_test"])
+    assert np.array_equal(e.get_triangle(), d["tri"])
+    # 20-symbol alphabet, k = 9: 20^9 keys -> 64-bit composite keys on the sparse path
+    rng = np.random.default_rng(2)
+    X = [rng.integers(1, 21, size=int(L)) for L in rng.integers(12, 50, size=9)]
+    for x in X[:4]:
+        x[3:15] = X[5][3:15]  # shared 12-mers so that off-diagonals are non-trivial
+    tok, off = _native.flatten(X)
+    e = _native.Engine(12, 3, lib=emu_lib)
+    e.compute(tok, off, 6, 3)
+    want, _, _ = port.compute(tok, off, 6, 3, 12, 3, t=1)
+    assert np.array_equal(e.get_triangle(), want)
+    assert e.stats()["path_used"] == 2
