@@ -16,6 +16,9 @@
 #include <string>
 #include <vector>
 
+#include <cstdint>
+#include <climits>
+
 #include "../../include/fastsk_amd.h"
 
 namespace {
@@ -127,7 +130,10 @@ int64_t n_choose_k(int n, int k) {  // nchoosek, shared.cpp:335-345 (exact in 64
     if (k < 0 || k > n) return 0;
     if (k * 2 > n) k = n - k;
     int64_t r = 1;
-    for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+    for (int i = 1; i <= k; ++i) {
+        if (r > (INT64_MAX / 2) / (n - k + i)) return INT64_MAX / 2;  // saturate: callers reject >= 2^31
+        r = r * (n - k + i) / i;
+    }
     return r;
 }
 
@@ -706,7 +712,6 @@ int fsk_reset_counts(fsk_engine* e) {
     if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
     FSK_HIP(hipSetDevice(e->cfg.device));
     FSK_HIP(hipMemsetAsync(e->d_K, 0, (size_t)e->pairs * sizeof(u64), e->stream));
-    if (e->d_U.p) FSK_HIP(hipMemsetAsync(e->d_U.p, 0, sizeof(u64), e->stream));
     e->finalized = false; e->result_f64 = false;
     e->st.combos_done = 0;
     return FSK_OK;

@@ -217,7 +217,7 @@ def test_pybind_surface_on_gpu(native):
     f.compute_train(X[:60])
     assert f.get_test_kernel() == []
     with pytest.raises(ValueError):
-        FastSK(g=200, m=6).compute_train(X[:10])
+        FastSK(g=101, m=99).compute_train(X[:10])  # g > shortest (100): the reference exit(1)s
     with pytest.raises(NotImplementedError):
         f.fit()
 
