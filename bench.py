@@ -27,7 +27,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
-VALU_DOT4_PEAK_TMACS = 256 * 4 * 32 * 4 * 2.4e9 / 1e12  # CUs*SIMDs*lanes*MACs/dot4*clk = 314.6
+# v_dot8_u32_u4 / v_dot4_u32_u8 issue at HALF the v_fma_f32 rate on gfx950 (measured:
+# profiles/r01_ubench_valu_rates.txt): 64 lanes/clk/CU. Peak = CUs * 64 lanes * 8 MACs * 2.4 GHz.
+VALU_DOT8_PEAK_TMACS = 256 * 64 * 8 * 2.4e9 / 1e12  # = 314.6 T MAC/s
 
 
 def synthetic(N, L, seed=20201214):
@@ -81,8 +83,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # FSK_BENCH_FORCE_DIST=1 exercises the RCCL leg on a single GPU (world size 1): a smoke test of
+    # the code the multi-GPU runs take, not a measurement
+    use_dist = world > 1 or os.environ.get("FSK_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     N, L, g, m = args.n_seq, args.seq_len, args.g, args.m
@@ -98,7 +104,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -106,7 +112,7 @@ def main():
         eng.reset_counts()
         eng.accumulate(mine)
         eng.synchronize()
-        if world > 1:
+        if use_dist:
             # one all-reduce of the partial triangles (sum of uint64 == sum of int64 bit patterns)
             dist.all_reduce(K, op=dist.ReduceOp.SUM)
             torch.cuda.synchronize()
@@ -122,7 +128,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     s1 = eng.stats()
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -155,7 +161,7 @@ def main():
             "metric": "gkm kernel build: mismatch-combos/s", "value": value, "unit": "combos/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "u8 counts, u32 accumulate, u64 atomics", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u4/u8 counts, u32 accumulate, u64 atomics", "data": "synthetic",
             "config": {"workload": "config5: synthetic DNA %d x %d bp, g=%d m=%d exact, %d combos" % (N, L, g, m, ncomb),
                        "n_seq": N, "seq_len": L, "g": g, "m": m, "combos": int(ncomb),
                        "parallelism": "combo-sharded x%d + 1 RCCL all-reduce" % world if world > 1 else "single GPU",
@@ -167,8 +173,8 @@ def main():
                          "note": "algorithmic bytes = 16*U + sort + input (direct-atomic dataflow, SURVEY 8d); "
                                  "frac > 1 means the tile kernel sums on chip what that dataflow would do in HBM",
                          "valu": {"achieved": macs / (tile_ms * 1e-3) / 1e12 if tile_ms > 0 else 0.0,
-                                  "peak": VALU_DOT4_PEAK_TMACS, "unit": "T u8-MAC/s (v_dot4_u32_u8)",
-                                  "frac": (macs / (tile_ms * 1e-3) / 1e12) / VALU_DOT4_PEAK_TMACS if tile_ms > 0 else 0.0}},
+                                  "peak": VALU_DOT8_PEAK_TMACS, "unit": "T count-MAC/s (v_dot8_u32_u4 at 64 lanes/clk/CU, 2.4 GHz)",
+                                  "frac": (macs / (tile_ms * 1e-3) / 1e12) / VALU_DOT8_PEAK_TMACS if tile_ms > 0 else 0.0}},
             "phases_ms_per_step": {"count": d("ms_count") / args.steps, "tile": d("ms_tile") / args.steps,
                                    "accumulate_total": d("ms_total") / args.steps},
         }
@@ -183,7 +189,7 @@ def main():
                           "value = that x (%d/%d)^2 (count time scales as N^2; the reference itself cannot index N > 46340)"
                           % (ns, N, nc, ncomb, secs, cores, measured, ns, ns, N)}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -40,7 +40,7 @@ class Stats(C.Structure):
                 ("ms_tile", C.c_double), ("ms_extract", C.c_double), ("ms_sort", C.c_double),
                 ("ms_segment", C.c_double), ("ms_pairs", C.c_double), ("ms_total", C.c_double),
                 ("n_tile_launches", C.c_int64), ("dense_macs", C.c_uint64), ("panel_bytes", C.c_uint64),
-                ("reserved", C.c_double * 6)]
+                ("u4_tile_launches", C.c_double), ("reserved", C.c_double * 5)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -73,6 +74,7 @@ struct fsk_engine {
     DevBuf<uint32_t> d_words, d_wstart, d_len, d_fstart, d_featseq;
     std::vector<uint32_t> h_len, h_fstart;
     bool featseq_ready = false;
+    bool force_u8 = false;  // FSK_FORCE_U8=1: keep the dot4/u8 tile kernel (testing)
 
     // combos
     std::vector<uint8_t> all_pos;  // [ncomb][k]
@@ -91,7 +93,8 @@ struct fsk_engine {
     DevBuf<u64> d_stage_u64;
 
     // dense scratch
-    DevBuf<uint32_t> d_C, d_flag;
+    DevBuf<uint32_t> d_C, d_C4, d_flag;
+    DevBuf<uint8_t> d_flags4;
     // sparse scratch
     DevBuf<unsigned char> d_keys[2];
     DevBuf<uint32_t> d_vals[2], d_blockhist, d_totals, d_estart, d_eseq, d_erun, d_rstart, d_segtot;
@@ -286,20 +289,24 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K) {
     const uint32_t panels_pad = (e->n_panels + 1u) & ~1u;  // tiles are 2x2 panels
     const uint32_t T = panels_pad / 2;
     const u64 n_tiles = (u64)T * (T + 1) / 2;
-    const size_t slot_dwords = (size_t)panels_pad * e->Vq * fsk::PANEL;  // dwords of panels per combo
+    const uint32_t Vq8 = (e->Vq + 1u) / 2u;                               // dwords of 4-bit counts
+    const size_t slot_dwords = (size_t)panels_pad * e->Vq * fsk::PANEL;   // u8 panel dwords per combo
+    const size_t slot_dwords4 = (size_t)panels_pad * Vq8 * fsk::PANEL;    // u4 panel dwords per combo
     // combos per launch: u32 accumulators must not wrap (per cell and combo <= maxW^2), and the
     // count panels must fit in the memory we are willing to take
     const u64 w2 = std::max<u64>(1, (u64)e->maxW * e->maxW);
     u64 by_overflow = 0xffffffffull / w2;
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    size_t have = e->d_C.cap * sizeof(uint32_t);
+    size_t have = (e->d_C.cap + e->d_C4.cap) * sizeof(uint32_t);
     size_t budget = std::max<size_t>(have, (size_t)((double)(free_b + have) * 0.6));
-    u64 by_memory = std::max<u64>(1, budget / (slot_dwords * sizeof(uint32_t)));
+    u64 by_memory = std::max<u64>(1, budget / ((slot_dwords + slot_dwords4) * sizeof(uint32_t)));
     const int chunk = (int)std::max<u64>(1, std::min<u64>({(u64)n, by_overflow, by_memory}));
     if (by_overflow == 0) return e->fail(FSK_EUNSUPPORTED, "sequence too long for the dense path");
     FSK_HIP(e->d_C.reserve(slot_dwords * (size_t)chunk));
-    FSK_HIP(e->d_flag.reserve(1));
+    FSK_HIP(e->d_C4.reserve(slot_dwords4 * (size_t)chunk));
+    FSK_HIP(e->d_flag.reserve(2));
+    FSK_HIP(e->d_flags4.reserve((size_t)panels_pad * chunk));
     FSK_HIP(e->d_pos.reserve((size_t)chunk * e->k));
     const size_t lds = dense_lds_bytes(e->Lmax, e->Vq);
 #ifndef FSK_EMU
@@ -313,20 +320,23 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K) {
             memcpy(&pos[(size_t)q * e->k], &e->all_pos[(size_t)combos[s + q] * e->k], e->k);
         FSK_HIP(hipMemcpyAsync(e->d_pos.p, pos.data(), pos.size(), hipMemcpyHostToDevice, e->stream));
         FSK_HIP(hipMemsetAsync(e->d_flag.p, 0, sizeof(uint32_t), e->stream));
+        FSK_HIP(hipMemsetAsync(e->d_flags4.p, 0, (size_t)panels_pad * nb, e->stream));
         FSK_HIP(hipStreamSynchronize(e->stream));  // `pos` is a pageable temporary
         // ---- segment counts
         const int slots_per_chunk = std::max(1, std::min(nb, 16));
         const int n_chunks = (nb + slots_per_chunk - 1) / slots_per_chunk;
         e->tic();
         FSK_LAUNCH(fsk::k_dense_count, dim3(panels_pad, n_chunks), dim3(256), lds, e->stream, e->view(), e->cfg.g, e->k,
-                   e->sigma, e->Vq, e->Lmax, e->d_pos.p, nb, slots_per_chunk, e->d_C.p, e->d_flag.p);
+                   e->sigma, e->Vq, e->Lmax, e->d_pos.p, nb, slots_per_chunk, e->d_C.p, e->d_C4.p, e->d_flags4.p, e->d_flag.p);
         e->toc(&e->st.ms_count);
-        e->st.panel_bytes += slot_dwords * sizeof(uint32_t) * (u64)nb;
-        if (e->maxW > 255) {  // a count could exceed u8: ask the device before trusting the panels
+        e->st.panel_bytes += (slot_dwords + slot_dwords4) * sizeof(uint32_t) * (u64)nb;
+        // a count above 255 does not fit the u8 panels either: take the general dataflow for
+        // this batch (only possible when a sequence has more than 255 windows)
+        if (e->maxW > 255) {
             uint32_t flag = 0;
             FSK_HIP(hipMemcpyAsync(&flag, e->d_flag.p, sizeof flag, hipMemcpyDeviceToHost, e->stream));
             FSK_HIP(hipStreamSynchronize(e->stream));
-            if (flag) {  // a k-mer occurs > 255 times in one sequence: take the general dataflow
+            if (flag & 1u) {
                 int rc = accumulate_sparse(e, combos + s, nb, K);
                 if (rc) return rc;
                 continue;
@@ -342,11 +352,14 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K) {
         const int slots_per_split = (nb + n_splits - 1) / n_splits;
         n_splits = (nb + slots_per_split - 1) / slots_per_split;
         e->tic();
-        FSK_LAUNCH(fsk::k_dense_tile, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C.p, nb, e->Vq,
-                   (uint32_t)e->N, K, slots_per_split);
+        const int mixed = e->force_u8 ? 0 : 1;
+        FSK_LAUNCH(fsk::k_dense_tile, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C.p, e->d_C4.p,
+                   e->d_flags4.p, mixed, nb, e->Vq, (uint32_t)e->N, K, slots_per_split);
         e->toc(&e->st.ms_tile);
         e->st.n_tile_launches += 1;
-        e->st.dense_macs += n_tiles * (u64)fsk::TILE * fsk::TILE * (u64)nb * ((u64)((e->Vq + 31) / 32) * 32 * 4);
+        const uint32_t rows = mixed ? Vq8 : e->Vq;  // nominal: the u8 fallback stages are rare
+        e->st.dense_macs += n_tiles * (u64)fsk::TILE * fsk::TILE * (u64)nb * ((u64)((rows + 31) / 32) * 32 * (mixed ? 8 : 4));
+        if (mixed) e->st.u4_tile_launches += 1;
         e->st.launches += 2;
         FSK_HIP(hipGetLastError());
     }
@@ -520,6 +533,7 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     e->ncomb = n_choose_k(cfg->g, cfg->m);
     if (e->ncomb > 0x7fffffff) { delete e; g_create_error = "C(g,m) >= 2^31 unsupported"; return FSK_EUNSUPPORTED; }
     enumerate_combos(cfg->g, e->k, e->all_pos);
+    { const char* f = getenv("FSK_FORCE_U8"); e->force_u8 = f && *f == '1'; }
     if (hipStreamCreate(&e->stream) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
         hipEventCreate(&e->ev1) != hipSuccess) {
         delete e;
@@ -537,7 +551,7 @@ void fsk_destroy(fsk_engine* e) {
     (void)hipStreamSynchronize(e->stream);
     e->d_words.release(); e->d_wstart.release(); e->d_len.release(); e->d_fstart.release(); e->d_featseq.release();
     e->d_pos.release(); e->K_store.release(); e->d_Kf64.release(); e->d_Khat.release(); e->d_prod.release();
-    e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_C.release(); e->d_flag.release();
+    e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_C.release(); e->d_C4.release(); e->d_flag.release(); e->d_flags4.release();
     for (int b = 0; b < 2; ++b) { e->d_keys[b].release(); e->d_vals[b].release(); }
     e->d_blockhist.release(); e->d_totals.release(); e->d_estart.release(); e->d_eseq.release(); e->d_erun.release();
     e->d_rstart.release(); e->d_segtot.release(); e->d_blocksum.release(); e->d_U.release();

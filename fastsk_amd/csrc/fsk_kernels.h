@@ -86,7 +86,8 @@ constexpr int STAGE_KQ = 32;     // key quads (4 keys = one dword of u8 counts) 
 // any key mix; the two lanes sharing a dword add to different halves (same-address atomics).
 __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, uint32_t sigma, uint32_t Vq,
                                                      uint32_t Lmax, const uint8_t* combo_pos, int n_slots,
-                                                     int slots_per_chunk, uint32_t* C, uint32_t* overflow_flag) {
+                                                     int slots_per_chunk, uint32_t* C, uint32_t* C4,
+                                                     uint8_t* flags4, uint32_t* overflow_flag) {
     FSK_DYN_SHARED(unsigned char, smem);
     uint8_t* symT = smem;
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (size_t)Lmax * PANEL);
@@ -103,7 +104,8 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
     const int slot1 = slot0 + slots_per_chunk < n_slots ? slot0 + slots_per_chunk : n_slots;
     const uint32_t hist_dwords = 4u * Vq * 32u;
     const uint32_t half = (uint32_t)(r & 1) * 16u;
-    bool ovf = false;
+    bool ovf = false, ovf4 = false;
+    const uint32_t Vq8 = (Vq + 1u) >> 1;
     for (int slot = slot0; slot < slot1; ++slot) {
         __syncthreads();  // symT complete / previous read-out finished
         for (uint32_t i = tid; i < hist_dwords; i += 256) hist[i] = 0u;
@@ -128,6 +130,24 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
             }
             out[kq * PANEL + r] = packed;  // 256 B per wave, coalesced
         }
+        // the same counts as 4-bit fields (8 keys per dword) for the v_dot8_u32_u4 tile kernel;
+        // only trusted by the host when no count exceeded 15 (flag bit 1)
+        uint32_t* out4 = C4 + ((size_t)panel * n_slots + slot) * ((size_t)Vq8 * PANEL);
+        for (uint32_t k8 = w; k8 < Vq8; k8 += 4) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t key = 8u * k8 + q;
+                uint32_t c = key < 4u * Vq ? (hist[key * 32u + (uint32_t)(r >> 1)] >> half) & 0xffffu : 0u;
+                ovf4 |= c > 15u;
+                packed |= (c & 15u) << (4 * q);
+            }
+            out4[k8 * PANEL + r] = packed;
+        }
+        // a count above 15: this (panel, combo) must be consumed in its u8 form (all writers
+        // store the same value; the array is zeroed before the launch)
+        if (ovf4) flags4[(size_t)panel * n_slots + slot] = 1;
+        ovf4 = false;
     }
     if (ovf) atomicOr(overflow_flag, 1u);
 }
@@ -168,8 +188,15 @@ __device__ __forceinline__ void tile_coords(uint32_t b, uint32_t* ti, uint32_t* 
     *tj = b - (uint32_t)((u64)t * (t + 1) / 2);
 }
 
-__global__ __launch_bounds__(256, 2) void k_dense_tile(const uint32_t* C, int n_slots, uint32_t Vq, uint32_t N,
-                                                       u64* K, int slots_per_split) {
+// Count panels come in two encodings written side by side by k_dense_count: 4-bit fields
+// (8 keys per dword, v_dot8_u32_u4: same issue rate as dot4, twice the multiply-adds) and u8
+// (4 keys per dword, v_dot4_u32_u8). A (panel, combo) whose counts all fit 4 bits is consumed
+// in the 4-bit form; the rare one with a count above 15 (flag byte set by k_dense_count) makes
+// the tiles that touch it fall back to the u8 form for that combo only. The choice is uniform
+// per workgroup and per combo, so there is no divergence. mixed == 0 forces u8 everywhere.
+__global__ __launch_bounds__(256, 2) void k_dense_tile(const uint32_t* C8, const uint32_t* C4, const uint8_t* flags4,
+                                                       int mixed, int n_slots, uint32_t Vq, uint32_t N, u64* K,
+                                                       int slots_per_split) {
     __shared__ __attribute__((aligned(16))) uint32_t As[STAGE_KQ * TILE];
     __shared__ __attribute__((aligned(16))) uint32_t Bs[STAGE_KQ * TILE];
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
@@ -178,10 +205,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_tile(const uint32_t* C, int n_
     const int s0 = blockIdx.y * slots_per_split;
     const int s1 = s0 + slots_per_split < n_slots ? s0 + slots_per_split : n_slots;
     if (s0 >= s1) return;
-    const uint32_t nst = (Vq + STAGE_KQ - 1) / STAGE_KQ;
-    const uint32_t total_stages = (uint32_t)(s1 - s0) * nst;
-    const size_t panel_stride = (size_t)n_slots * Vq * PANEL;  // dwords per panel
-    const size_t slot_stride = (size_t)Vq * PANEL;
+    const uint32_t Vq8 = (Vq + 1u) >> 1;
 
     uint32_t acc[8][8];
 #pragma unroll
@@ -189,10 +213,18 @@ __global__ __launch_bounds__(256, 2) void k_dense_tile(const uint32_t* C, int n_
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = 0u;
 
+    // a stage = up to STAGE_KQ dword-rows of one combo's panels, in one encoding
+    auto slot_is_u4 = [&](int slot) -> bool {
+        if (!mixed) return false;
+        const size_t a = (size_t)(ti * 2u) * n_slots + slot, b = (size_t)(tj * 2u) * n_slots + slot;
+        return (flags4[a] | flags4[a + n_slots] | flags4[b] | flags4[b + n_slots]) == 0;
+    };
     uint4 pre[8];
-    auto load_stage = [&](uint32_t st) {
-        const uint32_t slot = (uint32_t)s0 + st / nst;
-        const uint32_t kq0 = (st % nst) * STAGE_KQ;
+    auto load_stage = [&](int slot, uint32_t kq0, bool u4) {
+        const uint32_t rows = u4 ? Vq8 : Vq;
+        const uint32_t* C = u4 ? C4 : C8;
+        const size_t slot_stride = (size_t)rows * PANEL;
+        const size_t panel_stride = (size_t)n_slots * slot_stride;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const uint32_t idx = (uint32_t)it * 256u + (uint32_t)tid;  // [0,2048) uint4s
@@ -201,8 +233,8 @@ __global__ __launch_bounds__(256, 2) void k_dense_tile(const uint32_t* C, int n_
             const uint32_t kq = within >> 4, r4 = within & 15u;
             const uint32_t panel = (which < 2 ? ti : tj) * 2u + (which & 1u);
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (kq0 + kq < Vq) {
-                const uint32_t* src = C + panel * panel_stride + slot * slot_stride + (size_t)(kq0 + kq) * PANEL + r4 * 4u;
+            if (kq0 + kq < rows) {
+                const uint32_t* src = C + panel * panel_stride + (size_t)slot * slot_stride + (size_t)(kq0 + kq) * PANEL + r4 * 4u;
                 v = *reinterpret_cast<const uint4*>(src);
             }
             pre[it] = v;
@@ -220,25 +252,56 @@ __global__ __launch_bounds__(256, 2) void k_dense_tile(const uint32_t* C, int n_
         }
     };
 
-    load_stage(0);
-    for (uint32_t st = 0; st < total_stages; ++st) {
+    int slot = s0;
+    uint32_t kq0 = 0;
+    bool u4 = slot_is_u4(slot);
+    load_stage(slot, kq0, u4);
+    while (slot < s1) {
         __syncthreads();  // everyone finished reading the previous stage
         store_stage();
         __syncthreads();
-        if (st + 1 < total_stages) load_stage(st + 1);  // in flight under the dot products
-#pragma unroll 4
-        for (int kq = 0; kq < STAGE_KQ; ++kq) {
-            const uint4 a0 = *reinterpret_cast<const uint4*>(&As[kq * TILE + ty * 8]);
-            const uint4 a1 = *reinterpret_cast<const uint4*>(&As[kq * TILE + ty * 8 + 4]);
-            const uint4 b0 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + tx * 8]);
-            const uint4 b1 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + tx * 8 + 4]);
-            const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            const uint32_t bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-            for (int a = 0; a < 8; ++a)
-#pragma unroll
-                for (int b = 0; b < 8; ++b) acc[a][b] = __builtin_amdgcn_udot4(av[a], bv[b], acc[a][b], false);
+        // next stage: the rest of this combo's rows, else the next combo
+        int nslot = slot;
+        uint32_t nkq0 = kq0 + STAGE_KQ;
+        bool nu4 = u4;
+        if (nkq0 >= (u4 ? Vq8 : Vq)) {
+            nslot = slot + 1;
+            nkq0 = 0;
+            nu4 = nslot < s1 ? slot_is_u4(nslot) : false;
         }
+        if (nslot < s1) load_stage(nslot, nkq0, nu4);  // in flight under the dot products
+        if (u4) {
+#pragma unroll 4
+            for (int kq = 0; kq < STAGE_KQ; ++kq) {
+                const uint4 a0 = *reinterpret_cast<const uint4*>(&As[kq * TILE + ty * 8]);
+                const uint4 a1 = *reinterpret_cast<const uint4*>(&As[kq * TILE + ty * 8 + 4]);
+                const uint4 b0 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + tx * 8]);
+                const uint4 b1 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + tx * 8 + 4]);
+                const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                const uint32_t bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int a = 0; a < 8; ++a)
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) acc[a][b] = __builtin_amdgcn_udot8(av[a], bv[b], acc[a][b], false);
+            }
+        } else {
+#pragma unroll 2
+            for (int kq = 0; kq < STAGE_KQ; ++kq) {
+                const uint4 a0 = *reinterpret_cast<const uint4*>(&As[kq * TILE + ty * 8]);
+                const uint4 a1 = *reinterpret_cast<const uint4*>(&As[kq * TILE + ty * 8 + 4]);
+                const uint4 b0 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + tx * 8]);
+                const uint4 b1 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + tx * 8 + 4]);
+                const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                const uint32_t bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int a = 0; a < 8; ++a)
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) acc[a][b] = __builtin_amdgcn_udot4(av[a], bv[b], acc[a][b], false);
+            }
+        }
+        slot = nslot;
+        kq0 = nkq0;
+        u4 = nu4;
     }
     // flush: one 64-bit atomicAdd per cell of the lower triangle; a wave covers 128 consecutive
     // cells of one row per (a) step -> 1 KiB contiguous

@@ -91,7 +91,8 @@ typedef struct fsk_stats {
     int64_t n_tile_launches; /* launches of the tile kernel (for per-launch averages)           */
     uint64_t dense_macs;     /* 8-bit multiply-adds issued by the tile kernel                   */
     uint64_t panel_bytes;    /* bytes of count panels written (= read at least once)            */
-    double reserved[6];
+    double u4_tile_launches; /* tile launches that used the 4-bit panels / v_dot8_u32_u4       */
+    double reserved[5];
 } fsk_stats;
 
 /* ---- lifecycle: replaces FastSK::FastSK (fastsk.cpp:19-28) and ~nothing (the reference leaks) */

@@ -1,0 +1,32 @@
+"""Worker for tests/test_distributed.py: one rank of a world_size-2 gloo job on the CPU, running
+fastsk_amd.distributed.compute_sharded against the emulated engine library."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    from fastsk_amd import _native, distributed
+    import build_emu
+
+    fixture, outdir = sys.argv[1], sys.argv[2]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lib = _native.Library(build_emu.build())
+    d = np.load(fixture)
+    eng, K = distributed.compute_sharded(d["tokens"], d["offsets"], int(d["n_train"]), int(d["n_test"]), int(d["g"]),
+                                         int(d["m"]), combos=d["combos"], device=torch.device("cpu"), lib=lib)
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), counts=K.numpy().view(np.uint64), tri=eng.get_triangle(),
+             done=eng.stats()["combos_done"], world=world)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

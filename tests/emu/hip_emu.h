@@ -239,6 +239,10 @@ static inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c
     for (int i = 0; i < 4; ++i) c += ((a >> (8 * i)) & 255u) * ((b >> (8 * i)) & 255u);
     return c;
 }
+static inline unsigned __builtin_amdgcn_udot8(unsigned a, unsigned b, unsigned c, bool) {
+    for (int i = 0; i < 8; ++i) c += ((a >> (4 * i)) & 15u) * ((b >> (4 * i)) & 15u);
+    return c;
+}
 static inline double __dsqrt_rn(double x) { return __builtin_sqrt(x); }
 static inline double __dmul_rn(double a, double b) { return a * b; }
 static inline double __ddiv_rn(double a, double b) { return a / b; }

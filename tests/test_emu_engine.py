@@ -164,3 +164,23 @@ def test_emu_relabelled_and_wide_alphabets(emu_lib, port):
     want, _, _ = port.compute(tok, off, 6, 3, 12, 3, t=1)
     assert np.array_equal(e.get_triangle(), want)
     assert e.stats()["path_used"] == 2
+
+
+def test_emu_mixed_4bit_and_8bit_panels(emu_lib, port):
+    """Only the (panel, combo) pairs holding a count above 15 leave the 4-bit/dot8 form: mix
+    random DNA with a few low-complexity sequences in different panels and combos."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(9)
+    X = [rng.integers(1, 5, size=70).astype(np.int32) for _ in range(200)]
+    X[5][:40] = 1                      # poly-A: counts of 'aaaa' far above 15 in panel 0
+    X[130][10:50] = [2, 3] * 20        # dinucleotide repeat in panel 2
+    X[199][:] = 4                      # whole sequence one letter, last (partial) panel
+    tok, off = _native.flatten(X)
+    combos = np.arange(0, 70, 3, dtype=np.int32)
+    want, _, _ = port.raw_counts(tok, off, 8, 4, combos, threads=4)
+    e = _native.Engine(8, 4, path=1, lib=emu_lib)
+    e.load_sequences(tok, off, 150, 50)
+    e.accumulate(combos)
+    e.finalize()
+    assert np.array_equal(e.get_counts(), want)
+    assert e.stats()["u4_tile_launches"] == 1

@@ -87,8 +87,11 @@ def test_baseline_configs_full_size(native, name):
     e.close()
 
 
-def test_dense_equals_sparse_on_seeded_dna(native, port):
-    """Two independent HIP dataflows and the oracle agree on config-5-shaped data (smaller N)."""
+@pytest.mark.parametrize("force_u8", ["0", "1"])
+def test_dense_equals_sparse_on_seeded_dna(native, port, monkeypatch, force_u8):
+    """Two independent HIP dataflows and the oracle agree on config-5-shaped data (smaller N);
+    the dense one with 4-bit panels / v_dot8_u32_u4 (counts <= 15) and with u8 / v_dot4_u32_u8."""
+    monkeypatch.setenv("FSK_FORCE_U8", force_u8)
     tokens, offsets = synthetic_dna(700, 300)
     combos = np.arange(0, 495, 33, dtype=np.int32)
     out = []
@@ -104,6 +107,7 @@ def test_dense_equals_sparse_on_seeded_dna(native, port):
     assert np.array_equal(out[0][1], out[1][1])
     assert np.array_equal(out[0][1], port.normalise(want.astype(np.float64), 700))
     assert out[1][2]["cell_updates"] == U
+    assert out[0][2]["u4_tile_launches"] == (0 if force_u8 == "1" else 1)
 
 
 @pytest.mark.parametrize("sigma,g,m,n,lo,hi", [(4, 8, 4, 257, 8, 90), (5, 10, 6, 130, 10, 400), (20, 7, 3, 300, 7, 120),
