@@ -154,6 +154,7 @@ def slice_cases():
     Xtr, Xte = Xtr[:70], Xte[:30]
     make_case("f5_prot11_exact", Xtr, Xte, 10, 6, t=4)
     make_case("f5_prot11_variance_T1", Xtr, Xte, 10, 6, t=1, approx=True)
+    make_case("f5_prot11_variance_T1_it9", Xtr[:40], Xte[:20], 10, 6, t=1, approx=True, max_iters=9)
     Xtr, _, Xte, _ = read_pair("2.19")
     Xtr, Xte = Xtr[:50], Xte[:30]
     make_case("f6_prot219_exact", Xtr, Xte, 14, 10, t=8)

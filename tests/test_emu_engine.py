@@ -88,7 +88,7 @@ def test_emu_staged_accumulate_vs_port(emu_lib, port, name, path, ncombo):
 
 
 @pytest.mark.parametrize("name", ["f4_ep300_skipvar_T1", "f4_ep300_skipvar_T3", "f4_ep300_variance_T1",
-                                  "f4_ep300_variance_T1_conv", "f5_prot11_variance_T1", "f6_prot219_skipvar16"])
+                                  "f4_ep300_variance_T1_conv", "f5_prot11_variance_T1_it9", "f6_prot219_skipvar16"])
 def test_emu_approx_modes(emu_lib, name):
     d = load_golden(name)
     e = run_case(emu_lib, d, 0)
