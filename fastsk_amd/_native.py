@@ -40,7 +40,8 @@ class Stats(C.Structure):
                 ("ms_tile", C.c_double), ("ms_extract", C.c_double), ("ms_sort", C.c_double),
                 ("ms_segment", C.c_double), ("ms_pairs", C.c_double), ("ms_total", C.c_double),
                 ("n_tile_launches", C.c_int64), ("dense_macs", C.c_uint64), ("panel_bytes", C.c_uint64),
-                ("u4_tile_launches", C.c_double), ("reserved", C.c_double * 5)]
+                ("u4_tile_launches", C.c_double), ("max_windows", C.c_double), ("count_launches", C.c_double),
+                ("reserved", C.c_double * 3)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -49,7 +50,7 @@ class Stats(C.Structure):
 # every symbol include/fastsk_amd.h declares (checked by tests/test_abi.py)
 SYMBOLS = ["fsk_create", "fsk_destroy", "fsk_last_error", "fsk_abi_version", "fsk_device_count", "fsk_compute",
            "fsk_set_combo_order", "fsk_set_seed", "fsk_load_sequences", "fsk_bind_counts",
-           "fsk_counts_device_ptr", "fsk_reset_counts", "fsk_accumulate", "fsk_synchronize", "fsk_finalize",
+           "fsk_counts_device_ptr", "fsk_reset_counts", "fsk_accumulate", "fsk_accumulate_rows", "fsk_synchronize", "fsk_finalize",
            "fsk_get_block", "fsk_get_train", "fsk_get_test", "fsk_get_triangle", "fsk_get_counts",
            "fsk_get_counts_block", "fsk_get_stdevs", "fsk_save_kernel", "fsk_get_stats", "fsk_num_combos",
            "fsk_combo_positions"]
@@ -81,6 +82,7 @@ class Library:
             "fsk_counts_device_ptr": ([vp, C.POINTER(vp)], C.c_int),
             "fsk_reset_counts": ([vp], C.c_int),
             "fsk_accumulate": ([vp, vp, i32], C.c_int),
+            "fsk_accumulate_rows": ([vp, vp, i32, i64, i64], C.c_int),
             "fsk_synchronize": ([vp], C.c_int),
             "fsk_finalize": ([vp], C.c_int),
             "fsk_get_block": ([vp, i64, i64, i64, i64, vp], C.c_int),
@@ -211,6 +213,10 @@ class Engine:
     def accumulate(self, combos):
         combos = np.ascontiguousarray(combos, dtype=np.int32)
         self._ck(self.lib.L.fsk_accumulate(self.h, combos.ctypes.data, len(combos)))
+
+    def accumulate_rows(self, combos, row_begin, row_end):
+        combos = np.ascontiguousarray(combos, dtype=np.int32)
+        self._ck(self.lib.L.fsk_accumulate_rows(self.h, combos.ctypes.data, len(combos), row_begin, row_end))
 
     def synchronize(self):
         self._ck(self.lib.L.fsk_synchronize(self.h))

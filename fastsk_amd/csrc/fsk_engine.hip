@@ -95,6 +95,10 @@ struct fsk_engine {
     // dense scratch
     DevBuf<uint32_t> d_C, d_C4, d_flag;
     DevBuf<uint8_t> d_flags4;
+    DevBuf<uint32_t> d_tiletab;
+    uint32_t tab_t0 = 0, tab_t1 = 0, tab_n = 0;   // tile-row range the table on the device covers
+    std::vector<int32_t> prep_combos;              // combos whose count panels are resident
+    bool prep_valid = false, prep_overflow = false;
     // sparse scratch
     DevBuf<unsigned char> d_keys[2];
     DevBuf<uint32_t> d_vals[2], d_blockhist, d_totals, d_estart, d_eseq, d_erun, d_rstart, d_segtot;
@@ -186,7 +190,7 @@ int choose_path(fsk_engine* e) {
 // ---------------------------------------------------------------------------------------------
 // sparse dataflow for a batch of combos (composite key = slot * V + k-mer)
 template <typename KeyT>
-int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K) {
+int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t row0, int64_t row1) {
     const size_t nrec = (size_t)nb * (size_t)e->nfeat;
     if (nrec == 0) return FSK_OK;
     int keybits = 1;
@@ -251,7 +255,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K) {
 
     e->tic();
     FSK_LAUNCH(fsk::k_sparse_pairs, dim3((uint32_t)((nrec + 255) / 256)), dim3(256), 0, e->stream, e->d_segtot.p,
-               e->d_estart.p, e->d_eseq.p, e->d_erun.p, e->d_rstart.p, K, e->d_U.p);
+               e->d_estart.p, e->d_eseq.p, e->d_erun.p, e->d_rstart.p, (u64)row0, (u64)row1, K, e->d_U.p);
     e->toc(&e->st.ms_pairs);
     e->st.launches += 4;
     FSK_HIP(hipGetLastError());
@@ -269,7 +273,7 @@ int ensure_featseq(fsk_engine* e) {
     return FSK_OK;
 }
 
-int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K) {
+int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0, int64_t row1) {
     int rc = ensure_featseq(e);
     if (rc) return rc;
     // batch so that the composite key stays below 2^62 and the record count below the cap
@@ -279,16 +283,48 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K) {
     for (int s = 0; s < n; s += B) {
         const int nb = std::min(B, n - s);
         const bool wide = (u64)nb * e->V > 0xffffffffull;
-        rc = wide ? sparse_batch<u64>(e, combos + s, nb, K) : sparse_batch<uint32_t>(e, combos + s, nb, K);
+        rc = wide ? sparse_batch<u64>(e, combos + s, nb, K, row0, row1) : sparse_batch<uint32_t>(e, combos + s, nb, K, row0, row1);
         if (rc) return rc;
     }
     return FSK_OK;
 }
 
-int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K) {
+// XCD-aware tile order for the tile rows [t0, t1) of the lower-triangular tile grid: 8x8
+// super-tiles are dealt to 8 queues (one per XCD, balanced by tile count); block b = 8q + x takes
+// the q-th tile of queue x, because the dispatcher is observed to place blocks b, b+8, ... on one
+// XCD (placement only changes speed, never results).
+void build_tile_table(uint32_t t0, uint32_t t1, std::vector<uint32_t>& tab) {
+    constexpr uint32_t S = 8;
+    std::vector<std::vector<uint32_t>> q(8);
+    for (uint32_t si = t0 / S; si * S < t1; ++si)
+        for (uint32_t sj = 0; sj <= si; ++sj) {
+            size_t best = 0;
+            for (size_t x = 1; x < 8; ++x)
+                if (q[x].size() < q[best].size()) best = x;
+            for (uint32_t ti = std::max(si * S, t0); ti < std::min((si + 1) * S, t1); ++ti)
+                for (uint32_t tj = sj * S; tj < (sj + 1) * S && tj <= ti; ++tj) q[best].push_back(ti << 16 | tj);
+        }
+    size_t total = 0, pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (auto& v : q) total += v.size();
+    tab.clear();
+    tab.reserve(total);
+    while (tab.size() < total)
+        for (size_t x = 0; x < 8 && tab.size() < total; ++x) {
+            size_t src = x;
+            if (pos[src] >= q[src].size()) {  // queue exhausted: steal from the longest remainder
+                for (size_t y = 0; y < 8; ++y)
+                    if (q[y].size() - pos[y] > q[src].size() - pos[src]) src = y;
+            }
+            tab.push_back(q[src][pos[src]++]);
+        }
+}
+
+int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0, int64_t row1) {
     const uint32_t panels_pad = (e->n_panels + 1u) & ~1u;  // tiles are 2x2 panels
-    const uint32_t T = panels_pad / 2;
-    const u64 n_tiles = (u64)T * (T + 1) / 2;
+    const uint32_t t0 = (uint32_t)(row0 / fsk::TILE), t1 = (uint32_t)((row1 + fsk::TILE - 1) / fsk::TILE);
+    if (t1 > 0xffffu) return e->fail(FSK_EUNSUPPORTED, "more than 65535 tile rows");
+    const u64 n_tiles = (u64)t1 * (t1 + 1) / 2 - (u64)t0 * (t0 + 1) / 2;
+    if (n_tiles == 0) return FSK_OK;
     const uint32_t Vq8 = (e->Vq + 1u) / 2u;                               // dwords of 4-bit counts
     const size_t slot_dwords = (size_t)panels_pad * e->Vq * fsk::PANEL;   // u8 panel dwords per combo
     const size_t slot_dwords4 = (size_t)panels_pad * Vq8 * fsk::PANEL;    // u4 panel dwords per combo
@@ -296,18 +332,27 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K) {
     // count panels must fit in the memory we are willing to take
     const u64 w2 = std::max<u64>(1, (u64)e->maxW * e->maxW);
     u64 by_overflow = 0xffffffffull / w2;
+    if (by_overflow == 0) return e->fail(FSK_EUNSUPPORTED, "sequence too long for the dense path");
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     size_t have = (e->d_C.cap + e->d_C4.cap) * sizeof(uint32_t);
     size_t budget = std::max<size_t>(have, (size_t)((double)(free_b + have) * 0.6));
     u64 by_memory = std::max<u64>(1, budget / ((slot_dwords + slot_dwords4) * sizeof(uint32_t)));
     const int chunk = (int)std::max<u64>(1, std::min<u64>({(u64)n, by_overflow, by_memory}));
-    if (by_overflow == 0) return e->fail(FSK_EUNSUPPORTED, "sequence too long for the dense path");
     FSK_HIP(e->d_C.reserve(slot_dwords * (size_t)chunk));
     FSK_HIP(e->d_C4.reserve(slot_dwords4 * (size_t)chunk));
     FSK_HIP(e->d_flag.reserve(2));
     FSK_HIP(e->d_flags4.reserve((size_t)panels_pad * chunk));
     FSK_HIP(e->d_pos.reserve((size_t)chunk * e->k));
+    if (e->tab_t0 != t0 || e->tab_t1 != t1 || e->tab_n == 0) {
+        std::vector<uint32_t> tab;
+        build_tile_table(t0, t1, tab);
+        if (tab.size() != n_tiles) return e->fail(FSK_EDEVICE, "internal: tile table size mismatch");
+        FSK_HIP(e->d_tiletab.reserve(tab.size()));
+        FSK_HIP(hipMemcpyAsync(e->d_tiletab.p, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        FSK_HIP(hipStreamSynchronize(e->stream));
+        e->tab_t0 = t0; e->tab_t1 = t1; e->tab_n = (uint32_t)tab.size();
+    }
     const size_t lds = dense_lds_bytes(e->Lmax, e->Vq);
 #ifndef FSK_EMU
     FSK_HIP(hipFuncSetAttribute((const void*)fsk::k_dense_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -315,35 +360,51 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K) {
     std::vector<uint8_t> pos;
     for (int s = 0; s < n; s += chunk) {
         const int nb = std::min(chunk, n - s);
-        pos.resize((size_t)nb * e->k);
-        for (int q = 0; q < nb; ++q)
-            memcpy(&pos[(size_t)q * e->k], &e->all_pos[(size_t)combos[s + q] * e->k], e->k);
-        FSK_HIP(hipMemcpyAsync(e->d_pos.p, pos.data(), pos.size(), hipMemcpyHostToDevice, e->stream));
-        FSK_HIP(hipMemsetAsync(e->d_flag.p, 0, sizeof(uint32_t), e->stream));
-        FSK_HIP(hipMemsetAsync(e->d_flags4.p, 0, (size_t)panels_pad * nb, e->stream));
-        FSK_HIP(hipStreamSynchronize(e->stream));  // `pos` is a pageable temporary
-        // ---- segment counts
-        const int slots_per_chunk = std::max(1, std::min(nb, 16));
-        const int n_chunks = (nb + slots_per_chunk - 1) / slots_per_chunk;
-        e->tic();
-        FSK_LAUNCH(fsk::k_dense_count, dim3(panels_pad, n_chunks), dim3(256), lds, e->stream, e->view(), e->cfg.g, e->k,
-                   e->sigma, e->Vq, e->Lmax, e->d_pos.p, nb, slots_per_chunk, e->d_C.p, e->d_C4.p, e->d_flags4.p, e->d_flag.p);
-        e->toc(&e->st.ms_count);
-        e->st.panel_bytes += (slot_dwords + slot_dwords4) * sizeof(uint32_t) * (u64)nb;
-        // a count above 255 does not fit the u8 panels either: take the general dataflow for
-        // this batch (only possible when a sequence has more than 255 windows)
-        if (e->maxW > 255) {
-            uint32_t flag = 0;
-            FSK_HIP(hipMemcpyAsync(&flag, e->d_flag.p, sizeof flag, hipMemcpyDeviceToHost, e->stream));
-            FSK_HIP(hipStreamSynchronize(e->stream));
-            if (flag & 1u) {
-                int rc = accumulate_sparse(e, combos + s, nb, K);
-                if (rc) return rc;
-                continue;
+        // the count panels of an unchanged single-chunk combo list are reused by the FOLLOWING row
+        // bands of one pass (row0 > 0); a call that starts at row 0 always recounts
+        const bool cached = row0 > 0 && e->prep_valid && nb == n && (int)e->prep_combos.size() == n &&
+                            std::equal(combos, combos + n, e->prep_combos.begin());
+        if (!cached) {
+            e->prep_valid = false;
+            pos.resize((size_t)nb * e->k);
+            for (int q = 0; q < nb; ++q)
+                memcpy(&pos[(size_t)q * e->k], &e->all_pos[(size_t)combos[s + q] * e->k], e->k);
+            FSK_HIP(hipMemcpyAsync(e->d_pos.p, pos.data(), pos.size(), hipMemcpyHostToDevice, e->stream));
+            FSK_HIP(hipMemsetAsync(e->d_flag.p, 0, sizeof(uint32_t), e->stream));
+            FSK_HIP(hipMemsetAsync(e->d_flags4.p, 0, (size_t)panels_pad * nb, e->stream));
+            FSK_HIP(hipStreamSynchronize(e->stream));  // `pos` is a pageable temporary
+            // ---- segment counts
+            const int slots_per_chunk = std::max(1, std::min(nb, 16));
+            const int n_chunks = (nb + slots_per_chunk - 1) / slots_per_chunk;
+            e->tic();
+            FSK_LAUNCH(fsk::k_dense_count, dim3(panels_pad, n_chunks), dim3(256), lds, e->stream, e->view(), e->cfg.g, e->k,
+                       e->sigma, e->Vq, e->Lmax, e->d_pos.p, nb, slots_per_chunk, e->d_C.p, e->d_C4.p, e->d_flags4.p,
+                       e->d_flag.p);
+            e->toc(&e->st.ms_count);
+            e->st.count_launches += 1;
+            e->st.launches += 1;
+            e->st.panel_bytes += (slot_dwords + slot_dwords4) * sizeof(uint32_t) * (u64)nb;
+            // a count above 255 does not fit the u8 panels either: take the general dataflow
+            // for this batch (only possible when a sequence has more than 255 windows)
+            e->prep_overflow = false;
+            if (e->maxW > 255) {
+                uint32_t flag = 0;
+                FSK_HIP(hipMemcpyAsync(&flag, e->d_flag.p, sizeof flag, hipMemcpyDeviceToHost, e->stream));
+                FSK_HIP(hipStreamSynchronize(e->stream));
+                e->prep_overflow = (flag & 1u) != 0;
+            }
+            if (e->cfg.profile && !e->prep_overflow) {  // exact algorithmic update count U
+                FSK_LAUNCH(fsk::k_dense_distinct, dim3(e->Vq, nb), dim3(64), 0, e->stream, e->d_C.p, panels_pad, nb, e->Vq, e->d_U.p);
+            }
+            if (nb == n) {
+                e->prep_combos.assign(combos, combos + n);
+                e->prep_valid = true;
             }
         }
-        if (e->cfg.profile) {  // exact algorithmic update count U for the roofline
-            FSK_LAUNCH(fsk::k_dense_distinct, dim3(e->Vq, nb), dim3(64), 0, e->stream, e->d_C.p, panels_pad, nb, e->Vq, e->d_U.p);
+        if (e->prep_overflow) {
+            int rc = accumulate_sparse(e, combos + s, nb, K, row0, row1);
+            if (rc) return rc;
+            continue;
         }
         // ---- tiled accumulate. Split the combo range when there are too few tiles to fill
         // 256 CUs x 2 workgroups.
@@ -354,19 +415,20 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K) {
         e->tic();
         const int mixed = e->force_u8 ? 0 : 1;
         FSK_LAUNCH(fsk::k_dense_tile, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C.p, e->d_C4.p,
-                   e->d_flags4.p, mixed, nb, e->Vq, (uint32_t)e->N, K, slots_per_split);
+                   e->d_flags4.p, e->d_tiletab.p, mixed, nb, e->Vq, (uint32_t)e->N, K, slots_per_split);
         e->toc(&e->st.ms_tile);
         e->st.n_tile_launches += 1;
         const uint32_t rows = mixed ? Vq8 : e->Vq;  // nominal: the u8 fallback stages are rare
         e->st.dense_macs += n_tiles * (u64)fsk::TILE * fsk::TILE * (u64)nb * ((u64)((rows + 31) / 32) * 32 * (mixed ? 8 : 4));
         if (mixed) e->st.u4_tile_launches += 1;
-        e->st.launches += 2;
+        e->st.launches += 1;
         FSK_HIP(hipGetLastError());
     }
     return FSK_OK;
 }
 
-int do_accumulate(fsk_engine* e, const int32_t* combos, int n, u64* K) {
+int do_accumulate(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0 = 0, int64_t row1 = -1) {
+    if (row1 < 0) row1 = e->N;
     for (int i = 0; i < n; ++i)
         if (combos[i] < 0 || combos[i] >= e->ncomb) return e->fail(FSK_EINVAL, "combo id %d out of range [0,%lld)", combos[i], (long long)e->ncomb);
     hipEvent_t a = nullptr, b = nullptr;
@@ -375,7 +437,7 @@ int do_accumulate(fsk_engine* e, const int32_t* combos, int n, u64* K) {
         (void)hipEventCreate(&b);
         (void)hipEventRecord(a, e->stream);
     }
-    int rc = e->path == FSK_PATH_DENSE ? accumulate_dense(e, combos, n, K) : accumulate_sparse(e, combos, n, K);
+    int rc = e->path == FSK_PATH_DENSE ? accumulate_dense(e, combos, n, K, row0, row1) : accumulate_sparse(e, combos, n, K, row0, row1);
     if (e->cfg.profile) {
         (void)hipEventRecord(b, e->stream);
         (void)hipEventSynchronize(b);
@@ -385,7 +447,7 @@ int do_accumulate(fsk_engine* e, const int32_t* combos, int n, u64* K) {
         (void)hipEventDestroy(a);
         (void)hipEventDestroy(b);
     }
-    if (rc == FSK_OK) e->st.combos_done += n;
+    if (rc == FSK_OK && row1 >= e->N) e->st.combos_done += n;  // a combo is done when its last row band is
     return rc;
 }
 
@@ -551,7 +613,7 @@ void fsk_destroy(fsk_engine* e) {
     (void)hipStreamSynchronize(e->stream);
     e->d_words.release(); e->d_wstart.release(); e->d_len.release(); e->d_fstart.release(); e->d_featseq.release();
     e->d_pos.release(); e->K_store.release(); e->d_Kf64.release(); e->d_Khat.release(); e->d_prod.release();
-    e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_C.release(); e->d_C4.release(); e->d_flag.release(); e->d_flags4.release();
+    e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_C.release(); e->d_C4.release(); e->d_flag.release(); e->d_flags4.release(); e->d_tiletab.release();
     for (int b = 0; b < 2; ++b) { e->d_keys[b].release(); e->d_vals[b].release(); }
     e->d_blockhist.release(); e->d_totals.release(); e->d_estart.release(); e->d_eseq.release(); e->d_erun.release();
     e->d_rstart.release(); e->d_segtot.release(); e->d_blocksum.release(); e->d_U.release();
@@ -670,6 +732,7 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
     e->maxW = (uint32_t)(longest - g + 1);
     e->n_panels = (uint32_t)((N + fsk::PANEL - 1) / fsk::PANEL);
     e->h_len = len32; e->h_fstart = fstart; e->featseq_ready = false;
+    e->prep_valid = false; e->tab_n = 0;
     if (e->V > DENSE_MAX_KEYS) e->Vq = 1;  // unused on the sparse path
     int rc = choose_path(e);
     if (rc) return rc;
@@ -699,6 +762,7 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
     st.n_seq = N; st.n_train = n_train; st.n_test = n_test; st.n_feat = nfeat; st.n_pairs = e->pairs;
     st.alphabet = (int32_t)sigma; st.bits_per_symbol = bits; st.key_space = (int64_t)V; st.path_used = e->path;
     st.n_combos_total = (int32_t)e->ncomb;
+    st.max_windows = (double)e->maxW;
     return FSK_OK;
 }
 
@@ -739,6 +803,19 @@ int fsk_accumulate(fsk_engine* e, const int32_t* combos, int32_t n) {
     FSK_HIP(hipSetDevice(e->cfg.device));
     e->finalized = false;
     return do_accumulate(e, combos, n, e->d_K);
+}
+
+int fsk_accumulate_rows(fsk_engine* e, const int32_t* combos, int32_t n, int64_t row_begin, int64_t row_end) {
+    if (!e) return FSK_EINVAL;
+    if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
+    if (n < 0 || (n > 0 && !combos)) return e->fail(FSK_EINVAL, "bad combo list");
+    if (row_begin < 0 || row_end > e->N || row_begin > row_end || row_begin % fsk::TILE != 0 ||
+        (row_end % fsk::TILE != 0 && row_end != e->N))
+        return e->fail(FSK_EINVAL, "row band must be [a,b) with a, b multiples of %d (b may be N)", fsk::TILE);
+    if (n == 0 || row_begin == row_end) return FSK_OK;
+    FSK_HIP(hipSetDevice(e->cfg.device));
+    e->finalized = false;
+    return do_accumulate(e, combos, n, e->d_K, row_begin, row_end);
 }
 
 int fsk_synchronize(fsk_engine* e) {

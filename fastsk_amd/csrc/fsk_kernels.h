@@ -180,28 +180,23 @@ __global__ __launch_bounds__(64) void k_dense_distinct(const uint32_t* C, uint32
 // count panels as they lie in HBM. A-fragment reads are 4 addresses per wave (broadcast),
 // B-fragment reads are 16 consecutive 32-byte segments: conflict-free ds_read_b128.
 // Per key quad and lane: 4 x ds_read_b128 + 64 x v_dot4_u32_u8.
-__device__ __forceinline__ void tile_coords(uint32_t b, uint32_t* ti, uint32_t* tj) {
-    uint32_t t = (uint32_t)((sqrtf(8.0f * (float)b + 1.0f) - 1.0f) * 0.5f);
-    while ((u64)t * (t + 1) / 2 > b) --t;
-    while ((u64)(t + 1) * (t + 2) / 2 <= b) ++t;
-    *ti = t;
-    *tj = b - (uint32_t)((u64)t * (t + 1) / 2);
-}
-
 // Count panels come in two encodings written side by side by k_dense_count: 4-bit fields
 // (8 keys per dword, v_dot8_u32_u4: same issue rate as dot4, twice the multiply-adds) and u8
 // (4 keys per dword, v_dot4_u32_u8). A (panel, combo) whose counts all fit 4 bits is consumed
 // in the 4-bit form; the rare one with a count above 15 (flag byte set by k_dense_count) makes
 // the tiles that touch it fall back to the u8 form for that combo only. The choice is uniform
 // per workgroup and per combo, so there is no divergence. mixed == 0 forces u8 everywhere.
+// blockIdx.x -> tile through a host-built table (tile_tab[b] = ti << 16 | tj): the order is
+// XCD-aware (blocks b, b+8, b+16, ... share an XCD and walk 8x8 super-tiles, so the ~64
+// workgroups resident on one XCD stream 8+8 panel pairs out of its L2 instead of 1+64).
 __global__ __launch_bounds__(256, 2) void k_dense_tile(const uint32_t* C8, const uint32_t* C4, const uint8_t* flags4,
-                                                       int mixed, int n_slots, uint32_t Vq, uint32_t N, u64* K,
-                                                       int slots_per_split) {
+                                                       const uint32_t* tile_tab, int mixed, int n_slots, uint32_t Vq,
+                                                       uint32_t N, u64* K, int slots_per_split) {
     __shared__ __attribute__((aligned(16))) uint32_t As[STAGE_KQ * TILE];
     __shared__ __attribute__((aligned(16))) uint32_t Bs[STAGE_KQ * TILE];
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    uint32_t ti, tj;
-    tile_coords(blockIdx.x, &ti, &tj);
+    const uint32_t tile = tile_tab[blockIdx.x];
+    const uint32_t ti = tile >> 16, tj = tile & 0xffffu;
     const int s0 = blockIdx.y * slots_per_split;
     const int s1 = s0 + slots_per_split < n_slots ? s0 + slots_per_split : n_slots;
     if (s0 >= s1) return;
@@ -559,7 +554,8 @@ __global__ __launch_bounds__(256) void k_seg_write(const KeyT* keys, const uint3
 // per (run, pair) atomics: entry e pairs with every earlier entry of its run and itself —
 // exactly the += the reference issues (shared.cpp:316-327). U counts them.
 __global__ __launch_bounds__(256) void k_sparse_pairs(const uint32_t* totals, const uint32_t* estart, const uint32_t* eseq,
-                                                      const uint32_t* erun, const uint32_t* rstart, u64* K, u64* U) {
+                                                      const uint32_t* erun, const uint32_t* rstart, u64 row0, u64 row1,
+                                                      u64* K, u64* U) {
     const uint32_t D = totals[0];
     const uint32_t e = blockIdx.x * 256u + threadIdx.x;
     const bool active = e < D;
@@ -572,9 +568,11 @@ __global__ __launch_bounds__(256) void k_sparse_pairs(const uint32_t* totals, co
             const u64 sb = eseq[b];
             const u64 cb = estart[b + 1] - estart[b];
             const u64 i = sa > sb ? sa : sb, j = sa > sb ? sb : sa;
-            atomicAdd(&K[tri_index(i, j)], ca * cb);
+            if (i >= row0 && i < row1) {  // only the requested band of rows
+                atomicAdd(&K[tri_index(i, j)], ca * cb);
+                ++work;
+            }
         }
-        work = (u64)(e - rs + 1u);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) work += __shfl_xor(work, d);

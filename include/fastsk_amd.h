@@ -92,7 +92,9 @@ typedef struct fsk_stats {
     uint64_t dense_macs;     /* 8-bit multiply-adds issued by the tile kernel                   */
     uint64_t panel_bytes;    /* bytes of count panels written (= read at least once)            */
     double u4_tile_launches; /* tile launches that used the 4-bit panels / v_dot8_u32_u4       */
-    double reserved[5];
+    double max_windows;      /* max over sequences of (length - g + 1): bounds a cell per combo  */
+    double count_launches;   /* launches of the segment-count kernel (panel cache misses)        */
+    double reserved[3];
 } fsk_stats;
 
 /* ---- lifecycle: replaces FastSK::FastSK (fastsk.cpp:19-28) and ~nothing (the reference leaks) */
@@ -132,6 +134,11 @@ int fsk_reset_counts(fsk_engine* e);
  * the loop body of kernel_build_parallel (fastsk_kernel.cpp:188-281) for each combo, and the
  * K += Ks reduce (fastsk_kernel.cpp:286-315). Asynchronous on the engine's stream. */
 int fsk_accumulate(fsk_engine* e, const int32_t* combos, int32_t n);
+/* The same, restricted to the cells (i, j<=i) with row_begin <= i < row_end (row bounds multiples
+ * of 128, or N). Lets the host all-reduce finished row bands of the triangle while the next band
+ * is still being accumulated; the count panels of an unchanged combo list are reused between
+ * calls. fsk_accumulate(e, c, n) == fsk_accumulate_rows(e, c, n, 0, N). */
+int fsk_accumulate_rows(fsk_engine* e, const int32_t* combos, int32_t n, int64_t row_begin, int64_t row_end);
 /* wait for the engine's stream */
 int fsk_synchronize(fsk_engine* e);
 /* extract the raw diagonal for normalisation (fastsk_kernel.cpp:96-103); call after the last

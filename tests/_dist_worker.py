@@ -22,7 +22,8 @@ def main():
     lib = _native.Library(build_emu.build())
     d = np.load(fixture)
     eng, K = distributed.compute_sharded(d["tokens"], d["offsets"], int(d["n_train"]), int(d["n_test"]), int(d["g"]),
-                                         int(d["m"]), combos=d["combos"], device=torch.device("cpu"), lib=lib)
+                                         int(d["m"]), combos=d["combos"], device=torch.device("cpu"), lib=lib,
+                                         n_bands=int(sys.argv[3]), narrow=bool(int(sys.argv[4])))
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), counts=K.numpy().view(np.uint64), tri=eng.get_triangle(),
              done=eng.stats()["combos_done"], world=world)
     dist.destroy_process_group()

@@ -1,41 +1,66 @@
-"""The N>1 host path on the CPU: world_size 2 over gloo, emulated engine, against the golden
-vectors. Checks the combo partition, the single all-reduce and that every rank normalises the
-same reduced triangle."""
+"""The N>1 host path on the CPU: world_size 2 over gloo, emulated engine, against the oracle.
+Checks the combo partition, the banded all-reduce (uint64 and narrowed int32 payloads) and that
+every rank normalises the same reduced triangle."""
 import os
 import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from conftest import GOLD, ROOT, load_golden
 
 
 def test_shard_partition():
-    from fastsk_amd.distributed import shard
+    from fastsk_amd.distributed import shard, band_edges, cell
     combos = np.arange(495)
     parts = [shard(combos, r, 8) for r in range(8)]
     assert sorted(np.concatenate(parts).tolist()) == combos.tolist()
     assert [len(p) for p in parts] == [62, 62, 62, 62, 62, 62, 62, 61]
     assert shard(combos, 3, 8)[:3].tolist() == [3, 11, 19]
+    e = band_edges(100000, 8)
+    assert e[0] == 0 and e[-1] == 100000 and all(x % 128 == 0 for x in e[:-1]) and len(e) == 9
+    areas = np.diff([cell(x) for x in e])
+    assert areas.max() / areas.min() < 1.05  # equal-area bands (edges rounded to tile rows)
+    assert band_edges(300, 8) == [0, 128, 256, 300] or band_edges(300, 8)[-1] == 300
+
+
+def run_world(tmp_path, fixture, n_bands, narrow, port_no):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_no), WORLD_SIZE="2")
+    procs = []
+    for rank in range(2):
+        e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), fixture,
+                                       str(tmp_path), str(n_bands), str(int(narrow))], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\\n".join(outs)
+    return [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(2)]
 
 
 def test_two_rank_gloo_all_reduce(tmp_path):
     name = "f3_ragged_sigma7_g6m3"
     d = load_golden(name)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2")
-    procs = []
-    for rank in range(2):
-        e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"),
-                                       os.path.join(GOLD, name + ".npz"), str(tmp_path)], env=e,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
-    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     done = 0
-    for rank in range(2):
-        z = np.load(tmp_path / ("rank%d.npz" % rank))
+    for z in run_world(tmp_path, os.path.join(GOLD, name + ".npz"), 1, False, 29611):
         assert int(z["world"]) == 2
         assert np.array_equal(z["counts"], d["counts"])  # identical on every rank after the all-reduce
         assert np.array_equal(z["tri"], d["tri"])
         done += int(z["done"])
     assert done == len(d["combos"])  # every combo processed exactly once across the ranks
+
+
+@pytest.mark.parametrize("narrow", [False, True])
+def test_two_rank_banded_overlapped_reduce(tmp_path, port, narrow):
+    """Several row bands (N > 128) with the int32-narrowed and the uint64 payload."""
+    rng = np.random.default_rng(8)
+    N = 300
+    X = rng.integers(1, 5, size=(N, 40), dtype=np.int32)
+    tokens, offsets = X.reshape(-1), np.arange(N + 1, dtype=np.int64) * 40
+    combos = np.arange(0, 70, 5, dtype=np.int32)
+    fx = tmp_path / "in.npz"
+    np.savez(fx, tokens=tokens, offsets=offsets, n_train=200, n_test=100, g=8, m=4, combos=combos)
+    want, _, _ = port.raw_counts(tokens, offsets, 8, 4, combos, threads=4)
+    for z in run_world(tmp_path, str(fx), 3, narrow, 29613 + int(narrow)):
+        assert np.array_equal(z["counts"], want)
+        assert np.array_equal(z["tri"], port.normalise(want.astype(np.float64), N))

@@ -184,3 +184,39 @@ def test_emu_mixed_4bit_and_8bit_panels(emu_lib, port):
     e.finalize()
     assert np.array_equal(e.get_counts(), want)
     assert e.stats()["u4_tile_launches"] == 1
+
+
+@pytest.mark.parametrize("path", [1, 2])
+def test_emu_row_bands(emu_lib, port, path):
+    """fsk_accumulate_rows: bands of 128 rows add up to the full partial kernels; the count
+    panels are computed once per pass (dense) and each finished band is already final."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(4)
+    X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(20, 50, size=300)]
+    tok, off = _native.flatten(X)
+    combos = np.array([0, 5, 11, 33, 69], dtype=np.int32)
+    want, _, U = port.raw_counts(tok, off, 8, 4, combos, threads=4)
+    sq = tri_to_square(want, 300)
+    e = _native.Engine(8, 4, path=path, lib=emu_lib)
+    e.load_sequences(tok, off, 300, 0)
+    for lo, hi in [(0, 128), (128, 256), (256, 300)]:
+        e.accumulate_rows(combos, lo, hi)
+        e.synchronize()
+        got = e.get_counts_block(lo, hi, 0, 300)
+        assert np.array_equal(np.tril(got, lo), np.tril(sq[lo:hi], lo))  # this band is complete
+    assert np.array_equal(e.get_counts(), want)
+    st = e.stats()
+    assert st["combos_done"] == len(combos)
+    if path == 1:
+        assert st["count_launches"] == 1 and st["n_tile_launches"] == 3
+    else:
+        assert st["cell_updates"] == U
+    with pytest.raises(_native.FskError):
+        e.accumulate_rows(combos, 64, 128)
+    # a new pass starting at row 0 recounts (no stale cache across passes)
+    e.reset_counts()
+    e.accumulate(combos)
+    e.finalize()
+    assert np.array_equal(e.get_counts(), want)
+    if path == 1:
+        assert e.stats()["count_launches"] == 2
