@@ -107,6 +107,27 @@ public:
         f.add(Xtest);
         run(f, (int64_t)Xtrain.size(), (int64_t)Xtest.size());
     }
+    // Additive fast path: fixed-length sequences as 2-D int32 arrays (no per-element boxing; the
+    // list-of-lists form costs seconds at 100k x 300)
+    void compute_kernel_np(py::array_t<int32_t, py::array::c_style> Xtrain, py::array_t<int32_t, py::array::c_style> Xtest) {
+        if (Xtrain.ndim() != 2 || Xtest.ndim() != 2 || Xtrain.shape(0) == 0 || Xtest.shape(0) == 0)
+            throw py::value_error("expected non-empty 2-D int32 arrays");
+        Flat f;
+        add_array(f, Xtrain);
+        add_array(f, Xtest);
+        run(f, (int64_t)Xtrain.shape(0), (int64_t)Xtest.shape(0));
+    }
+    void compute_train_np(py::array_t<int32_t, py::array::c_style> Xtrain) {
+        if (Xtrain.ndim() != 2 || Xtrain.shape(0) == 0) throw py::value_error("expected a non-empty 2-D int32 array");
+        Flat f;
+        add_array(f, Xtrain);
+        run(f, (int64_t)Xtrain.shape(0), 0);
+    }
+    static void add_array(Flat& f, const py::array_t<int32_t, py::array::c_style>& X) {
+        const py::ssize_t n = X.shape(0), L = X.shape(1);
+        f.tokens.insert(f.tokens.end(), X.data(), X.data() + n * L);
+        for (py::ssize_t i = 0; i < n; ++i) f.offsets.push_back(f.offsets.back() + L);
+    }
     // FastSK::compute_train, fastsk.cpp:120-188
     void compute_train(std::vector<std::vector<int>> Xtrain) {
         if (Xtrain.empty()) throw py::value_error("Xtrain must be non-empty");
@@ -172,7 +193,9 @@ PYBIND11_MODULE(_fastsk, m) {
              py::arg("g"), py::arg("m"), py::arg("t") = -1, py::arg("approx") = false, py::arg("delta") = 0.025,
              py::arg("max_iters") = -1, py::arg("skip_variance") = false, py::arg("device") = 0,
              py::arg("path") = "auto", py::arg("seed") = py::none())
+        .def("compute_kernel", &FastSK::compute_kernel_np, py::arg("Xtrain").noconvert(), py::arg("Xtest").noconvert())
         .def("compute_kernel", &FastSK::compute_kernel, py::arg("Xtrain"), py::arg("Xtest"))
+        .def("compute_train", &FastSK::compute_train_np, py::arg("Xtrain").noconvert())
         .def("compute_train", &FastSK::compute_train, py::arg("Xtrain"))
         .def("get_train_kernel", &FastSK::get_train_kernel)
         .def("get_test_kernel", &FastSK::get_test_kernel)

@@ -75,6 +75,7 @@ struct fsk_engine {
     std::vector<uint32_t> h_len, h_fstart;
     bool featseq_ready = false;
     bool force_u8 = false;  // FSK_FORCE_U8=1: keep the dot4/u8 tile kernel (testing)
+    uint32_t force_chunk = 0;  // FSK_DENSE_CHUNK=n: cap the count kernel's staging chunk (testing)
 
     // combos
     std::vector<uint8_t> all_pos;  // [ncomb][k]
@@ -167,13 +168,39 @@ uint64_t splitmix64(uint64_t& s) {
 }
 
 constexpr size_t LDS_BUDGET = 150 * 1024;       // of 160 KiB per CU
-constexpr u64 DENSE_MAX_KEYS = 1024;            // beyond this the count panels are mostly zeros
+constexpr u64 DENSE_MAX_KEYS = 16384;           // count panels: alphabet^k <= this (DNA up to k = 7)
+constexpr uint32_t DENSE_HIST_QUADS = 160;      // LDS histogram sweep: 640 keys x 64 sequences x u16 = 80 KiB
 constexpr size_t SPARSE_MAX_RECORDS = 1u << 25; // records per sort batch
 
-size_t dense_lds_bytes(uint32_t Lmax, uint32_t Vq) { return (size_t)Lmax * fsk::PANEL + (size_t)Vq * 512; }
+// k_dense_count LDS: (CH + g - 1) staged symbols x 64 sequences + the u16 histogram of one key
+// sweep (512 B per key quad)
+uint32_t dense_hist_quads(uint32_t Vq) { return std::min<uint32_t>(Vq, DENSE_HIST_QUADS); }
+size_t dense_lds_bytes(uint32_t CH, int g, uint32_t Vq) {
+    return (size_t)(CH + g - 1) * fsk::PANEL + (size_t)dense_hist_quads(Vq) * 512;
+}
+// windows per staging chunk: all of them when they fit (sequences unpacked once per workgroup)
+uint32_t dense_chunk_windows(uint32_t maxW, int g, uint32_t Vq) {
+    const size_t hist = (size_t)dense_hist_quads(Vq) * 512;
+    if (hist + (size_t)(g + 63) * fsk::PANEL > LDS_BUDGET) return 0;  // not even 64 windows fit
+    const size_t room = (LDS_BUDGET - hist) / fsk::PANEL;            // symbols per sequence
+    return (uint32_t)std::min<size_t>(maxW, room - (size_t)(g - 1));
+}
+
+// Which dataflow is cheaper per combo (path = auto)? The dense one multiplies every pair of
+// sequences over the whole key space at the v_dot8 rate; the sparse one issues one scattered
+// 64-bit atomic per (run, pair). Rates measured on MI355X.
+bool dense_is_cheaper(const fsk_engine* e) {
+    const double N = (double)e->N, V = (double)e->V;
+    const double W = (double)e->nfeat / std::max(1.0, N);                 // windows per sequence
+    const double dense = 0.5 * N * N * (double)(((e->Vq + 1) / 2) * 8) / 2.4e14 + (double)e->nfeat * 4e-11;
+    const double d = N * (1.0 - std::exp(-W / V));                          // sequences holding a given key
+    const double U = V * d * (d + 1.0) / 2.0;
+    const double sparse = U / 1.6e10 + (double)e->nfeat * 3.0 / 2.0e10;
+    return dense <= sparse;
+}
 
 int choose_path(fsk_engine* e) {
-    bool dense_ok = e->V <= DENSE_MAX_KEYS && e->Lmax < 65536 && dense_lds_bytes(e->Lmax, e->Vq) <= LDS_BUDGET;
+    bool dense_ok = e->V <= DENSE_MAX_KEYS && e->Lmax < 65536 && dense_chunk_windows(e->maxW, e->cfg.g, e->Vq) > 0;
     if (e->cfg.path == FSK_PATH_DENSE) {
         if (!dense_ok)
             return e->fail(FSK_EUNSUPPORTED, "dense path needs alphabet^k <= %llu and the panel histogram to fit in LDS",
@@ -182,7 +209,7 @@ int choose_path(fsk_engine* e) {
     } else if (e->cfg.path == FSK_PATH_SPARSE) {
         e->path = FSK_PATH_SPARSE;
     } else {
-        e->path = dense_ok ? FSK_PATH_DENSE : FSK_PATH_SPARSE;
+        e->path = dense_ok && dense_is_cheaper(e) ? FSK_PATH_DENSE : FSK_PATH_SPARSE;
     }
     return FSK_OK;
 }
@@ -353,7 +380,9 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
         FSK_HIP(hipStreamSynchronize(e->stream));
         e->tab_t0 = t0; e->tab_t1 = t1; e->tab_n = (uint32_t)tab.size();
     }
-    const size_t lds = dense_lds_bytes(e->Lmax, e->Vq);
+    uint32_t CH = dense_chunk_windows(e->maxW, e->cfg.g, e->Vq);
+    if (e->force_chunk) CH = std::max(1u, std::min(CH, e->force_chunk));
+    const size_t lds = dense_lds_bytes(CH, e->cfg.g, e->Vq);
 #ifndef FSK_EMU
     FSK_HIP(hipFuncSetAttribute((const void*)fsk::k_dense_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #endif
@@ -378,7 +407,7 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
             const int n_chunks = (nb + slots_per_chunk - 1) / slots_per_chunk;
             e->tic();
             FSK_LAUNCH(fsk::k_dense_count, dim3(panels_pad, n_chunks), dim3(256), lds, e->stream, e->view(), e->cfg.g, e->k,
-                       e->sigma, e->Vq, e->Lmax, e->d_pos.p, nb, slots_per_chunk, e->d_C.p, e->d_C4.p, e->d_flags4.p,
+                       e->sigma, e->Vq, dense_hist_quads(e->Vq), e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C.p, e->d_C4.p, e->d_flags4.p,
                        e->d_flag.p);
             e->toc(&e->st.ms_count);
             e->st.count_launches += 1;
@@ -596,6 +625,7 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     if (e->ncomb > 0x7fffffff) { delete e; g_create_error = "C(g,m) >= 2^31 unsupported"; return FSK_EUNSUPPORTED; }
     enumerate_combos(cfg->g, e->k, e->all_pos);
     { const char* f = getenv("FSK_FORCE_U8"); e->force_u8 = f && *f == '1'; }
+    { const char* f = getenv("FSK_DENSE_CHUNK"); e->force_chunk = f ? (uint32_t)atoi(f) : 0u; }
     if (hipStreamCreate(&e->stream) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
         hipEventCreate(&e->ev1) != hipSuccess) {
         delete e;

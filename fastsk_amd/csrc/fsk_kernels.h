@@ -85,64 +85,83 @@ constexpr int STAGE_KQ = 32;     // key quads (4 keys = one dword of u8 counts) 
 // LDS banking: lane r touches dword (key*32 + r/2): bank depends on r only -> conflict-free for
 // any key mix; the two lanes sharing a dword add to different halves (same-address atomics).
 __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, uint32_t sigma, uint32_t Vq,
-                                                     uint32_t Lmax, const uint8_t* combo_pos, int n_slots,
-                                                     int slots_per_chunk, uint32_t* C, uint32_t* C4,
+                                                     uint32_t Vcq, uint32_t max_win, uint32_t CH, const uint8_t* combo_pos,
+                                                     int n_slots, int slots_per_chunk, uint32_t* C, uint32_t* C4,
                                                      uint8_t* flags4, uint32_t* overflow_flag) {
+    // Vcq = key quads per histogram chunk (the LDS histogram covers 4*Vcq keys at a time; key
+    // spaces beyond that are counted in several sweeps over the same staged symbols).
+    // CH = windows per staging chunk: symT holds CH + g - 1 symbols per sequence. CH >= max_win
+    // (every BASELINE config) means the sequences are unpacked once and reused by all the combos
+    // of this workgroup; longer sequences are re-staged chunk by chunk inside the combo loop.
     FSK_DYN_SHARED(unsigned char, smem);
     uint8_t* symT = smem;
-    uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (size_t)Lmax * PANEL);
+    const uint32_t sym_rows = CH + (uint32_t)g - 1u;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (size_t)sym_rows * PANEL);
     const int tid = threadIdx.x, r = tid & 63, w = tid >> 6;
     const uint32_t panel = blockIdx.x;
     const uint32_t seq = panel * PANEL + r;
     const uint32_t len = seq < S.n_seq ? S.len[seq] : 0u;
     const uint32_t wbase = seq < S.n_seq ? S.wstart[seq] : 0u;
-    for (uint32_t p = w; p < Lmax; p += 4)
-        symT[p * PANEL + r] = p < len ? (uint8_t)fetch_sym(S.words, wbase, p, S.bits) : (uint8_t)0;
     const uint32_t nwin = len >= (uint32_t)g ? len - g + 1 : 0u;
-    const uint32_t max_win = Lmax >= (uint32_t)g ? Lmax - g + 1 : 0u;
+    const bool single = CH >= max_win;
     const int slot0 = blockIdx.y * slots_per_chunk;
     const int slot1 = slot0 + slots_per_chunk < n_slots ? slot0 + slots_per_chunk : n_slots;
-    const uint32_t hist_dwords = 4u * Vq * 32u;
+    const uint32_t hist_dwords = 4u * Vcq * 32u;
     const uint32_t half = (uint32_t)(r & 1) * 16u;
     bool ovf = false, ovf4 = false;
     const uint32_t Vq8 = (Vq + 1u) >> 1;
     for (int slot = slot0; slot < slot1; ++slot) {
-        __syncthreads();  // symT complete / previous read-out finished
-        for (uint32_t i = tid; i < hist_dwords; i += 256) hist[i] = 0u;
-        __syncthreads();
         const uint8_t* pos = combo_pos + (size_t)slot * k;
-        for (uint32_t j = w; j < max_win; j += 4) {
-            if (j < nwin) {
-                uint32_t key = 0;
-                for (int c = 0; c < k; ++c) key = key * sigma + symT[(j + pos[c]) * PANEL + r];
-                atomicAdd(&hist[key * 32u + (uint32_t)(r >> 1)], 1u << half);
-            }
-        }
-        __syncthreads();
         uint32_t* out = C + ((size_t)panel * n_slots + slot) * ((size_t)Vq * PANEL);
-        for (uint32_t kq = w; kq < Vq; kq += 4) {
-            uint32_t packed = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint32_t c = (hist[(4u * kq + q) * 32u + (uint32_t)(r >> 1)] >> half) & 0xffffu;
-                ovf |= c > 255u;
-                packed |= (c & 255u) << (8 * q);
-            }
-            out[kq * PANEL + r] = packed;  // 256 B per wave, coalesced
-        }
-        // the same counts as 4-bit fields (8 keys per dword) for the v_dot8_u32_u4 tile kernel;
-        // only trusted by the host when no count exceeded 15 (flag bit 1)
         uint32_t* out4 = C4 + ((size_t)panel * n_slots + slot) * ((size_t)Vq8 * PANEL);
-        for (uint32_t k8 = w; k8 < Vq8; k8 += 4) {
-            uint32_t packed = 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const uint32_t key = 8u * k8 + q;
-                uint32_t c = key < 4u * Vq ? (hist[key * 32u + (uint32_t)(r >> 1)] >> half) & 0xffffu : 0u;
-                ovf4 |= c > 15u;
-                packed |= (c & 15u) << (4 * q);
+        for (uint32_t kc0 = 0; kc0 < Vq; kc0 += Vcq) {  // key-space sweep
+            const uint32_t key_lo = 4u * kc0, key_n = 4u * (kc0 + Vcq < Vq ? Vcq : Vq - kc0);
+            __syncthreads();  // previous read-out finished
+            for (uint32_t i = tid; i < hist_dwords; i += 256) hist[i] = 0u;
+            for (uint32_t cb = 0; cb < max_win; cb += CH) {
+                if (!single || (slot == slot0 && kc0 == 0)) {
+                    __syncthreads();  // everyone is done with the previous chunk's symbols
+                    for (uint32_t p = w; p < sym_rows; p += 4)
+                        symT[p * PANEL + r] = cb + p < len ? (uint8_t)fetch_sym(S.words, wbase, cb + p, S.bits) : (uint8_t)0;
+                }
+                __syncthreads();  // symbols staged, histogram zeroed
+                const uint32_t hi = cb + CH < max_win ? cb + CH : max_win;
+                for (uint32_t j = cb + w; j < hi; j += 4) {
+                    if (j < nwin) {
+                        uint32_t key = 0;
+                        for (int c = 0; c < k; ++c) key = key * sigma + symT[(j - cb + pos[c]) * PANEL + r];
+                        key -= key_lo;  // wraps for keys below the sweep: rejected by the compare
+                        if (key < key_n) atomicAdd(&hist[key * 32u + (uint32_t)(r >> 1)], 1u << half);
+                    }
+                }
             }
-            out4[k8 * PANEL + r] = packed;
+            __syncthreads();
+            const uint32_t nq = key_n >> 2;  // key quads in this sweep
+            for (uint32_t kq = w; kq < nq; kq += 4) {
+                uint32_t packed = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t c = (hist[(4u * kq + q) * 32u + (uint32_t)(r >> 1)] >> half) & 0xffffu;
+                    ovf |= c > 255u;
+                    packed |= (c & 255u) << (8 * q);
+                }
+                out[(size_t)(kc0 + kq) * PANEL + r] = packed;  // 256 B per wave, coalesced
+            }
+            // the same counts as 4-bit fields (8 keys per dword) for the v_dot8_u32_u4 tile
+            // kernel; valid unless flags4 says a count of this (panel, combo) exceeded 15
+            // (Vcq is even, so a sweep starts on an 8-key boundary)
+            const uint32_t n8 = (nq + 1u) >> 1;
+            for (uint32_t k8 = w; k8 < n8; k8 += 4) {
+                uint32_t packed = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const uint32_t key = 8u * k8 + q;
+                    uint32_t c = key < key_n ? (hist[key * 32u + (uint32_t)(r >> 1)] >> half) & 0xffffu : 0u;
+                    ovf4 |= c > 15u;
+                    packed |= (c & 15u) << (4 * q);
+                }
+                out4[(size_t)((kc0 >> 1) + k8) * PANEL + r] = packed;
+            }
         }
         // a count above 15: this (panel, combo) must be consumed in its u8 form (all writers
         // store the same value; the array is zeroed before the launch)

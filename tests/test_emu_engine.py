@@ -220,3 +220,40 @@ def test_emu_row_bands(emu_lib, port, path):
     assert np.array_equal(e.get_counts(), want)
     if path == 1:
         assert e.stats()["count_launches"] == 2
+
+
+@pytest.mark.parametrize("chunk", ["7", "64"])
+def test_emu_dense_count_chunked_staging(emu_lib, port, monkeypatch, chunk):
+    """Sequences too long for one LDS staging pass are counted chunk by chunk (forced small here)."""
+    from fastsk_amd import _native
+    monkeypatch.setenv("FSK_DENSE_CHUNK", chunk)
+    rng = np.random.default_rng(12)
+    X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(9, 200, size=70)]
+    tok, off = _native.flatten(X)
+    combos = np.array([0, 17, 125], dtype=np.int32)
+    want, _, _ = port.raw_counts(tok, off, 9, 5, combos, threads=2)
+    e = _native.Engine(9, 5, path=1, lib=emu_lib)
+    e.load_sequences(tok, off, 50, 20)
+    e.accumulate(combos)
+    e.finalize()
+    assert np.array_equal(e.get_counts(), want)
+
+
+@pytest.mark.parametrize("sigma,g,m", [(4, 8, 2), (5, 7, 2), (3, 9, 2)])
+def test_emu_dense_large_key_space_sweeps(emu_lib, port, sigma, g, m):
+    """Key spaces above one LDS histogram (640 keys) are counted in several sweeps: DNA k = 6
+    (4096 keys), 5 symbols k = 5 (3125), 3 symbols k = 7 (2187)."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(sigma + g)
+    X = [rng.integers(1, sigma + 1, size=int(L)).astype(np.int32) for L in rng.integers(g, 90, size=70)]
+    X[3][:] = 1  # low complexity: exercises the u8 fallback in a large key space
+    tok, off = _native.flatten(X)
+    nc = port.num_combos(g, m)
+    combos = np.array([0, nc // 2, nc - 1], dtype=np.int32)
+    want, _, _ = port.raw_counts(tok, off, g, m, combos, threads=2)
+    e = _native.Engine(g, m, path=1, lib=emu_lib)
+    e.load_sequences(tok, off, 40, 30)
+    e.accumulate(combos)
+    e.finalize()
+    assert e.stats()["key_space"] == sigma ** (g - m)
+    assert np.array_equal(e.get_counts(), want)

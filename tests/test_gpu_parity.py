@@ -127,6 +127,43 @@ def test_ragged_random_inputs_vs_oracle(native, port, sigma, g, m, n, lo, hi):
         e.close()
 
 
+def test_long_sequences_chunked_staging(native, port):
+    """DNA sequences longer than one LDS staging pass (~1800 symbols at 256 keys)."""
+    rng = np.random.default_rng(21)
+    X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(40, 5000, size=96)]
+    tokens, offsets = native.flatten(X)
+    combos = np.array([0, 100, 209], dtype=np.int32)
+    want, _, _ = port.raw_counts(tokens, offsets, 10, 6, combos, threads=8)
+    for path in (1, 2):
+        e = native.Engine(10, 6, path=path)
+        e.load_sequences(tokens, offsets, 96, 0)
+        e.accumulate(combos)
+        e.finalize()
+        assert np.array_equal(e.get_counts(), want), "path %d" % path
+        e.close()
+
+
+@pytest.mark.parametrize("sigma,g,m,L", [(4, 10, 4, 100), (4, 11, 4, 300), (5, 8, 3, 150), (4, 9, 4, 60)])
+def test_mid_size_key_spaces_dense_vs_sparse(native, port, sigma, g, m, L):
+    """k = 5..7 (1024..16384 keys): count panels built in several LDS sweeps; both dataflows and
+    the oracle agree; auto picks one of them by its cost model."""
+    rng = np.random.default_rng(g * 100 + m)
+    N = 500
+    X = rng.integers(1, sigma + 1, size=(N, L), dtype=np.int32)
+    X[7, :] = 2
+    tokens, offsets = native.flatten(X)
+    nc = port.num_combos(g, m)
+    combos = np.unique(np.linspace(0, nc - 1, 9).astype(np.int32))
+    want, _, _ = port.raw_counts(tokens, offsets, g, m, combos, threads=8)
+    for path in (0, 1, 2):
+        e = native.Engine(g, m, path=path)
+        e.load_sequences(tokens, offsets, N, 0)
+        e.accumulate(combos)
+        e.finalize()
+        assert np.array_equal(e.get_counts(), want), "path %d" % path
+        e.close()
+
+
 def test_low_complexity_counts_above_255(native, port):
     """A k-mer occurring > 255 times in one sequence does not fit the u8 count panels: the dense
     dataflow must notice and hand that batch to the general one."""
@@ -220,6 +257,10 @@ def test_pybind_surface_on_gpu(native):
     f = FastSK(g=10, m=6)
     f.compute_train(X[:60])
     assert f.get_test_kernel() == []
+    A = np.array(X, dtype=np.int32)  # EP300 rows all have length 100: the 2-D array fast path
+    f = FastSK(g=10, m=6)
+    f.compute_kernel(A[:60], A[60:])
+    assert np.array_equal(f.get_train_kernel_np(), load_golden("f4_ep300_exact")["train"])
     with pytest.raises(ValueError):
         FastSK(g=101, m=99).compute_train(X[:10])  # g > shortest (100): the reference exit(1)s
     with pytest.raises(NotImplementedError):
