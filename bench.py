@@ -60,6 +60,27 @@ def cpu_baseline(X, g, m, n_sample, budget_s):
     return kind, cores, measured, len(combos), t_main
 
 
+def other_configs(_native):
+    """BASELINE configs[1] (EP300 DNA, 2000+2000 x 100 bp, g=10 m=6 exact) on the same GPU: the
+    whole fsk_compute call, host buffers in, result resident on the device (best of 3)."""
+    path = os.path.join(ROOT, "tests", "golden", "tokens_EP300.npz")
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    tokens, offsets = z["tokens"].astype(np.int32), z["offsets"].astype(np.int64)
+    ntr, nte = int(z["n_train"]), int(z["n_test"])
+    e = _native.Engine(10, 6)
+    best = 1e9
+    for _ in range(4):
+        t0 = time.perf_counter()
+        e.compute(tokens, offsets, ntr, nte)
+        best = min(best, time.perf_counter() - t0)
+    e.close()
+    return {"config2_ep300_exact": {"n_seq": ntr + nte, "seq_len": 100, "g": 10, "m": 6, "combos": 210,
+                                    "seconds": best, "combos_per_s": 210 / best,
+                                    "reference_cpu_seconds_8_threads": 29.9}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,6 +205,8 @@ def main():
             "phases_ms_per_step": {"count": d("ms_count") / args.steps, "tile": d("ms_tile") / args.steps,
                                    "accumulate_total": d("ms_total") / args.steps},
         }
+        if world == 1:
+            out["also"] = other_configs(_native)
         if world == 1 and not args.no_cpu_baseline:
             ns = min(args.cpu_sample, N)
             kind, cores, measured, nc, secs = cpu_baseline(X, g, m, ns, args.cpu_seconds)

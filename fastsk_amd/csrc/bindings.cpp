@@ -123,6 +123,24 @@ public:
         add_array(f, Xtrain);
         run(f, (int64_t)Xtrain.shape(0), 0);
     }
+    // Additive: ragged sequences already flattened (tokens + offsets, train rows first), e.g.
+    // from FastaUtility.read_packed
+    void compute_kernel_flat(py::array_t<int32_t, py::array::c_style> tokens, py::array_t<int64_t, py::array::c_style> offsets,
+                             int64_t n_train) {
+        if (tokens.ndim() != 1 || offsets.ndim() != 1 || offsets.shape(0) < 2) throw py::value_error("expected 1-D tokens and offsets");
+        const int64_t n = (int64_t)offsets.shape(0) - 1;
+        if (n_train <= 0 || n_train > n) throw py::value_error("n_train out of range");
+        if (offsets.data()[0] != 0 || offsets.data()[n] != (int64_t)tokens.shape(0)) throw py::value_error("offsets must start at 0 and end at len(tokens)");
+        int rc;
+        {
+            py::gil_scoped_release nogil;
+            rc = fsk_compute(h_, tokens.data(), offsets.data(), n_train, n - n_train);
+        }
+        check(rc);
+        n_train_ = n_train;
+        n_test_ = n - n_train;
+        computed_ = true;
+    }
     static void add_array(Flat& f, const py::array_t<int32_t, py::array::c_style>& X) {
         const py::ssize_t n = X.shape(0), L = X.shape(1);
         f.tokens.insert(f.tokens.end(), X.data(), X.data() + n * L);
@@ -195,6 +213,8 @@ PYBIND11_MODULE(_fastsk, m) {
              py::arg("path") = "auto", py::arg("seed") = py::none())
         .def("compute_kernel", &FastSK::compute_kernel_np, py::arg("Xtrain").noconvert(), py::arg("Xtest").noconvert())
         .def("compute_kernel", &FastSK::compute_kernel, py::arg("Xtrain"), py::arg("Xtest"))
+        .def("compute_kernel_flat", &FastSK::compute_kernel_flat, py::arg("tokens").noconvert(), py::arg("offsets").noconvert(),
+             py::arg("n_train"))
         .def("compute_train", &FastSK::compute_train_np, py::arg("Xtrain").noconvert())
         .def("compute_train", &FastSK::compute_train, py::arg("Xtrain"))
         .def("get_train_kernel", &FastSK::get_train_kernel)

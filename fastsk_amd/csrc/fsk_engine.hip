@@ -435,10 +435,23 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
             if (rc) return rc;
             continue;
         }
-        // ---- tiled accumulate. Split the combo range when there are too few tiles to fill
-        // 256 CUs x 2 workgroups.
+        // ---- tiled accumulate. With few tiles (small N) the combo range is split over several
+        // workgroups per tile so that the grid fills 256 CUs x 2 resident workgroups in whole
+        // rounds: pick the split count with the least idle tail (each split still sums >= 4
+        // combos on chip before its atomics).
         int n_splits = 1;
-        if (n_tiles < 1024) n_splits = (int)std::min<u64>((u64)nb, (1024 + n_tiles - 1) / n_tiles);
+        if (n_tiles < 8192 && nb >= 8) {
+            const u64 slots = 512;
+            double best = -1.0;
+            for (int sp = 1; sp <= nb / 4; ++sp) {
+                const int per = (nb + sp - 1) / sp;
+                const int eff_sp = (nb + per - 1) / per;
+                const u64 wgs = n_tiles * (u64)eff_sp;
+                const double fill = (double)wgs / (double)(((wgs + slots - 1) / slots) * slots);
+                const double score = fill - 0.02 * (wgs < 4 * slots ? (double)(4 * slots - wgs) / (double)(4 * slots) : 0.0) - 1e-4 * sp;
+                if (score > best) { best = score; n_splits = eff_sp; }
+            }
+        }
         const int slots_per_split = (nb + n_splits - 1) / n_splits;
         n_splits = (nb + slots_per_split - 1) / slots_per_split;
         e->tic();

@@ -257,6 +257,9 @@ def test_pybind_surface_on_gpu(native):
     f = FastSK(g=10, m=6)
     f.compute_train(X[:60])
     assert f.get_test_kernel() == []
+    f = FastSK(g=10, m=6)
+    f.compute_kernel_flat(d["tokens"].astype(np.int32), d["offsets"].astype(np.int64), 60)
+    assert np.array_equal(f.get_test_kernel_np(), load_golden("f4_ep300_exact")["test"])
     A = np.array(X, dtype=np.int32)  # EP300 rows all have length 100: the 2-D array fast path
     f = FastSK(g=10, m=6)
     f.compute_kernel(A[:60], A[60:])

@@ -162,3 +162,32 @@ def test_fasta_reader_matches_reference_tokens(tmp_path):
     Xte, Yte = rd.read_data(str(te))
     assert Xtr == [[1, 2, 3, 4], [4, 4, 3, 1], [5, 1, 2, 3]] and Ytr == [1, 0, -1]
     assert Xte == [[3, 5, 1, 6]] and Yte == [0]
+
+
+def test_fast_fasta_reader_equals_slow_reader(tmp_path):
+    """FastaUtility.read_packed (vectorised) == read_data (the reference's tokenisation), incl.
+    the shared vocabulary across train and test files."""
+    import os
+    from fastsk_amd.utils import FastaUtility
+    rng = np.random.default_rng(0)
+    alpha = "ACGTNacgtn"
+
+    def write(path, n):
+        with open(path, "w") as f:
+            for i in range(n):
+                f.write(">%d\n" % int(rng.integers(0, 2)))
+                f.write("".join(rng.choice(list(alpha), size=int(rng.integers(5, 40)))) + "  \n")
+
+    files = [str(tmp_path / "a.train.fasta"), str(tmp_path / "a.test.fasta")]
+    write(files[0], 30)
+    write(files[1], 11)
+    if os.path.isdir("/root/reference/data"):
+        files += ["/root/reference/data/1.1.train.fasta", "/root/reference/data/1.1.test.fasta"]
+    slow, fast = FastaUtility(), FastaUtility()
+    for fpath in files:
+        X, Y = slow.read_data(fpath)
+        toks, offs, labels = fast.read_packed(fpath)
+        assert labels.tolist() == Y
+        assert offs.tolist() == np.concatenate([[0], np.cumsum([len(x) for x in X])]).tolist()
+        assert toks.tolist() == [t for x in X for t in x]
+    assert str(slow._vocab) == str(fast._vocab)
