@@ -75,6 +75,7 @@ struct fsk_engine {
     std::vector<uint32_t> h_len, h_fstart;
     bool featseq_ready = false;
     bool force_u8 = false;  // FSK_FORCE_U8=1: keep the dot4/u8 tile kernel (testing)
+    int force_splits = 0;      // FSK_TILE_SPLITS=n: combo splits per tile (tuning)
     uint32_t force_chunk = 0;  // FSK_DENSE_CHUNK=n: cap the count kernel's staging chunk (testing)
 
     // combos
@@ -436,22 +437,23 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
             continue;
         }
         // ---- tiled accumulate. With few tiles (small N) the combo range is split over several
-        // workgroups per tile so that the grid fills 256 CUs x 2 resident workgroups in whole
-        // rounds: pick the split count with the least idle tail (each split still sums >= 4
-        // combos on chip before its atomics).
+        // workgroups per tile to fill 256 CUs x 2 resident workgroups in whole rounds. Model
+        // (fitted on MI355X, tools/sweep_splits.py): a round costs the combos of one split at
+        // 250 T MAC/s over 512 slots plus ~3 us of workgroup start-up; the extra flushes of a
+        // split are nearly free (the atomics drain under other workgroups' dot products).
         int n_splits = 1;
-        if (n_tiles < 8192 && nb >= 8) {
-            const u64 slots = 512;
-            double best = -1.0;
-            for (int sp = 1; sp <= nb / 4; ++sp) {
+        if (n_tiles < 4096 && nb >= 2) {
+            const double t_combo = 16384.0 * (double)(Vq8 * 8) / (2.5e14 / 512.0);
+            double best = 1e300;
+            for (int sp = 1; sp <= nb; ++sp) {
                 const int per = (nb + sp - 1) / sp;
-                const int eff_sp = (nb + per - 1) / per;
-                const u64 wgs = n_tiles * (u64)eff_sp;
-                const double fill = (double)wgs / (double)(((wgs + slots - 1) / slots) * slots);
-                const double score = fill - 0.02 * (wgs < 4 * slots ? (double)(4 * slots - wgs) / (double)(4 * slots) : 0.0) - 1e-4 * sp;
-                if (score > best) { best = score; n_splits = eff_sp; }
+                if ((nb + per - 1) / per != sp || per < 2) continue;
+                const double rounds = std::ceil((double)n_tiles * sp / 512.0);
+                const double cost = rounds * (per * t_combo + 3e-6) + (double)sp * (double)n_tiles * 3e-8;
+                if (cost < best) { best = cost; n_splits = sp; }
             }
         }
+        if (e->force_splits > 0) n_splits = std::min(nb, e->force_splits);
         const int slots_per_split = (nb + n_splits - 1) / n_splits;
         n_splits = (nb + slots_per_split - 1) / slots_per_split;
         e->tic();
@@ -461,7 +463,7 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
         e->toc(&e->st.ms_tile);
         e->st.n_tile_launches += 1;
         const uint32_t rows = mixed ? Vq8 : e->Vq;  // nominal: the u8 fallback stages are rare
-        e->st.dense_macs += n_tiles * (u64)fsk::TILE * fsk::TILE * (u64)nb * ((u64)((rows + 31) / 32) * 32 * (mixed ? 8 : 4));
+        e->st.dense_macs += n_tiles * (u64)fsk::TILE * fsk::TILE * (u64)nb * ((u64)rows * (mixed ? 8 : 4));
         if (mixed) e->st.u4_tile_launches += 1;
         e->st.launches += 1;
         FSK_HIP(hipGetLastError());
@@ -638,6 +640,7 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     if (e->ncomb > 0x7fffffff) { delete e; g_create_error = "C(g,m) >= 2^31 unsupported"; return FSK_EUNSUPPORTED; }
     enumerate_combos(cfg->g, e->k, e->all_pos);
     { const char* f = getenv("FSK_FORCE_U8"); e->force_u8 = f && *f == '1'; }
+    { const char* f = getenv("FSK_TILE_SPLITS"); e->force_splits = f ? atoi(f) : 0; }
     { const char* f = getenv("FSK_DENSE_CHUNK"); e->force_chunk = f ? (uint32_t)atoi(f) : 0u; }
     if (hipStreamCreate(&e->stream) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
         hipEventCreate(&e->ev1) != hipSuccess) {

@@ -79,6 +79,14 @@ constexpr int PANEL = 64;        // sequences per count panel (= one wave of lan
 constexpr int TILE = 128;        // K tile edge (2 panels)
 constexpr int STAGE_KQ = 32;     // key quads (4 keys = one dword of u8 counts) per LDS stage
 
+// Where sequence r (0..63) of a panel sits inside each 64-dword panel row. Interleaving by 16
+// makes the four dwords a lane fetches with one ds_read_b128 belong to sequences t, t+16, t+32,
+// t+48, so that for a fixed register the 16 lanes of a row group own 16 CONSECUTIVE columns of
+// K and the flush atomics of a wave fall into 128-byte contiguous segments.
+__device__ __forceinline__ uint32_t panel_slot(uint32_t r) { return ((r & 15u) << 2) | (r >> 4); }
+// tile-local row/column (0..127) of register e (0..7) of lane group t (0..15): inverse of the above
+__device__ __forceinline__ uint32_t tile_index(uint32_t t, uint32_t e) { return (e >> 2) * 64u + t + 16u * (e & 3u); }
+
 // Per-sequence counting sort of the k-mers selected by each combo ("segment counts").
 // grid = (n_panels, n_chunks), block = 256 (wave w takes windows j = w mod 4; lane = sequence).
 // dynamic LDS: symT[Lmax][64] u8 | hist[4*Vq][32] u32 (two u16 counters per dword).
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
                     ovf |= c > 255u;
                     packed |= (c & 255u) << (8 * q);
                 }
-                out[(size_t)(kc0 + kq) * PANEL + r] = packed;  // 256 B per wave, coalesced
+                out[(size_t)(kc0 + kq) * PANEL + panel_slot(r)] = packed;  // one 256-B row per wave
             }
             // the same counts as 4-bit fields (8 keys per dword) for the v_dot8_u32_u4 tile
             // kernel; valid unless flags4 says a count of this (panel, combo) exceeded 15
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
                     ovf4 |= c > 15u;
                     packed |= (c & 15u) << (4 * q);
                 }
-                out4[(size_t)((kc0 >> 1) + k8) * PANEL + r] = packed;
+                out4[(size_t)((kc0 >> 1) + k8) * PANEL + panel_slot(r)] = packed;
             }
         }
         // a count above 15: this (panel, combo) must be consumed in its u8 form (all writers
@@ -195,9 +203,10 @@ __global__ __launch_bounds__(64) void k_dense_distinct(const uint32_t* C, uint32
 }
 
 // Output-stationary tile accumulate. grid = (n_tiles, n_splits), block = 256 = 16 x 16 lanes,
-// each lane owns an 8x8 block of a 128x128 tile of K. LDS: As/Bs[kq][128 seqs] dwords, i.e. the
-// count panels as they lie in HBM. A-fragment reads are 4 addresses per wave (broadcast),
-// B-fragment reads are 16 consecutive 32-byte segments: conflict-free ds_read_b128.
+// each lane owns 8 rows x 8 columns (interleaved by 16, see panel_slot) of a 128x128 tile of K.
+// LDS: As/Bs[kq][128 seqs] dwords, i.e. the count panels as they lie in HBM. A-fragment reads
+// are 4 addresses per wave (broadcast), B-fragment reads are 16 consecutive 16-byte segments in
+// each panel half: conflict-free ds_read_b128.
 // Per key quad and lane: 4 x ds_read_b128 + 64 x v_dot4_u32_u8.
 // Count panels come in two encodings written side by side by k_dense_count: 4-bit fields
 // (8 keys per dword, v_dot8_u32_u4: same issue rate as dot4, twice the multiply-adds) and u8
@@ -227,12 +236,11 @@ __global__ __launch_bounds__(256, 2) void k_dense_tile(const uint32_t* C8, const
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = 0u;
 
-    // a stage = up to STAGE_KQ dword-rows of one combo's panels, in one encoding
-    auto slot_is_u4 = [&](int slot) -> bool {
-        if (!mixed) return false;
-        const size_t a = (size_t)(ti * 2u) * n_slots + slot, b = (size_t)(tj * 2u) * n_slots + slot;
-        return (flags4[a] | flags4[a + n_slots] | flags4[b] | flags4[b + n_slots]) == 0;
-    };
+    // a stage = up to STAGE_KQ dword-rows of one combo's panels, in one encoding. Which encoding
+    // a combo takes for THIS tile (OR of the four panels' "count above 15" bytes) is worked out
+    // for FLAG_SLOTS combos at a time into LDS, so the stage loop never waits on a global flag.
+    constexpr int FLAG_SLOTS = 2048;
+    __shared__ uint8_t sflag[FLAG_SLOTS];
     uint4 pre[8];
     auto load_stage = [&](int slot, uint32_t kq0, bool u4) {
         const uint32_t rows = u4 ? Vq8 : Vq;
@@ -266,11 +274,19 @@ __global__ __launch_bounds__(256, 2) void k_dense_tile(const uint32_t* C8, const
         }
     };
 
-    int slot = s0;
+    for (int c0 = s0; c0 < s1; c0 += FLAG_SLOTS) {
+    const int c1 = c0 + FLAG_SLOTS < s1 ? c0 + FLAG_SLOTS : s1;
+    __syncthreads();  // the previous chunk's flags are no longer read
+    for (int sl = c0 + tid; sl < c1; sl += 256) {
+        const size_t a = (size_t)(ti * 2u) * n_slots + sl, b = (size_t)(tj * 2u) * n_slots + sl;
+        sflag[sl - c0] = mixed ? (uint8_t)(flags4[a] | flags4[a + n_slots] | flags4[b] | flags4[b + n_slots]) : (uint8_t)1;
+    }
+    __syncthreads();
+    int slot = c0;
     uint32_t kq0 = 0;
-    bool u4 = slot_is_u4(slot);
+    bool u4 = sflag[0] == 0;
     load_stage(slot, kq0, u4);
-    while (slot < s1) {
+    while (slot < c1) {
         __syncthreads();  // everyone finished reading the previous stage
         store_stage();
         __syncthreads();
@@ -281,16 +297,19 @@ __global__ __launch_bounds__(256, 2) void k_dense_tile(const uint32_t* C8, const
         if (nkq0 >= (u4 ? Vq8 : Vq)) {
             nslot = slot + 1;
             nkq0 = 0;
-            nu4 = nslot < s1 ? slot_is_u4(nslot) : false;
+            nu4 = nslot < c1 ? sflag[nslot - c0] == 0 : false;
         }
-        if (nslot < s1) load_stage(nslot, nkq0, nu4);  // in flight under the dot products
+        if (nslot < c1) load_stage(nslot, nkq0, nu4);  // in flight under the dot products
+        // rows of this stage that hold keys (the last stage of a combo may be partial)
+        const uint32_t rows_left = (u4 ? Vq8 : Vq) - kq0;
+        const int nkq = rows_left < (uint32_t)STAGE_KQ ? (int)rows_left : STAGE_KQ;
         if (u4) {
 #pragma unroll 4
-            for (int kq = 0; kq < STAGE_KQ; ++kq) {
-                const uint4 a0 = *reinterpret_cast<const uint4*>(&As[kq * TILE + ty * 8]);
-                const uint4 a1 = *reinterpret_cast<const uint4*>(&As[kq * TILE + ty * 8 + 4]);
-                const uint4 b0 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + tx * 8]);
-                const uint4 b1 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + tx * 8 + 4]);
+            for (int kq = 0; kq < nkq; ++kq) {
+                const uint4 a0 = *reinterpret_cast<const uint4*>(&As[kq * TILE + ty * 4]);
+                const uint4 a1 = *reinterpret_cast<const uint4*>(&As[kq * TILE + PANEL + ty * 4]);
+                const uint4 b0 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + tx * 4]);
+                const uint4 b1 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + PANEL + tx * 4]);
                 const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                 const uint32_t bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
@@ -300,11 +319,11 @@ __global__ __launch_bounds__(256, 2) void k_dense_tile(const uint32_t* C8, const
             }
         } else {
 #pragma unroll 2
-            for (int kq = 0; kq < STAGE_KQ; ++kq) {
-                const uint4 a0 = *reinterpret_cast<const uint4*>(&As[kq * TILE + ty * 8]);
-                const uint4 a1 = *reinterpret_cast<const uint4*>(&As[kq * TILE + ty * 8 + 4]);
-                const uint4 b0 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + tx * 8]);
-                const uint4 b1 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + tx * 8 + 4]);
+            for (int kq = 0; kq < nkq; ++kq) {
+                const uint4 a0 = *reinterpret_cast<const uint4*>(&As[kq * TILE + ty * 4]);
+                const uint4 a1 = *reinterpret_cast<const uint4*>(&As[kq * TILE + PANEL + ty * 4]);
+                const uint4 b0 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + tx * 4]);
+                const uint4 b1 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + PANEL + tx * 4]);
                 const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                 const uint32_t bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
@@ -317,15 +336,17 @@ __global__ __launch_bounds__(256, 2) void k_dense_tile(const uint32_t* C8, const
         kq0 = nkq0;
         u4 = nu4;
     }
-    // flush: one 64-bit atomicAdd per cell of the lower triangle; a wave covers 128 consecutive
-    // cells of one row per (a) step -> 1 KiB contiguous
+    }
+    // flush: one 64-bit atomicAdd per cell of the lower triangle. For a fixed register (a, b) the
+    // 16 lanes of a row group hold 16 consecutive columns (tile_index), so a wave's atomic
+    // instruction covers four rows x 128 contiguous bytes.
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
-        const u64 i = (u64)ti * TILE + (u64)(ty * 8 + a);
+        const u64 i = (u64)ti * TILE + tile_index((uint32_t)ty, (uint32_t)a);
         if (i >= N) continue;
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-            const u64 j = (u64)tj * TILE + (u64)(tx * 8 + b);
+            const u64 j = (u64)tj * TILE + tile_index((uint32_t)tx, (uint32_t)b);
             if (j <= i && acc[a][b] != 0u) atomicAdd(&K[tri_index(i, j)], (u64)acc[a][b]);
         }
     }
