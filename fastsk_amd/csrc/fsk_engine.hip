@@ -170,21 +170,28 @@ uint64_t splitmix64(uint64_t& s) {
 
 constexpr size_t LDS_BUDGET = 150 * 1024;       // of 160 KiB per CU
 constexpr u64 DENSE_MAX_KEYS = 16384;           // count panels: alphabet^k <= this (DNA up to k = 7)
-constexpr uint32_t DENSE_HIST_QUADS = 160;      // LDS histogram sweep: 640 keys x 64 sequences x u16 = 80 KiB
 constexpr size_t SPARSE_MAX_RECORDS = 1u << 25; // records per sort batch
 
-// k_dense_count LDS: (CH + g - 1) staged symbols x 64 sequences + the u16 histogram of one key
-// sweep (512 B per key quad)
-uint32_t dense_hist_quads(uint32_t Vq) { return std::min<uint32_t>(Vq, DENSE_HIST_QUADS); }
-size_t dense_lds_bytes(uint32_t CH, int g, uint32_t Vq) {
-    return (size_t)(CH + g - 1) * fsk::PANEL + (size_t)dense_hist_quads(Vq) * 512;
-}
-// windows per staging chunk: all of them when they fit (sequences unpacked once per workgroup)
-uint32_t dense_chunk_windows(uint32_t maxW, int g, uint32_t Vq) {
-    const size_t hist = (size_t)dense_hist_quads(Vq) * 512;
-    if (hist + (size_t)(g + 63) * fsk::PANEL > LDS_BUDGET) return 0;  // not even 64 windows fit
-    const size_t room = (LDS_BUDGET - hist) / fsk::PANEL;            // symbols per sequence
-    return (uint32_t)std::min<size_t>(maxW, room - (size_t)(g - 1));
+// k_dense_count LDS plan: (CH + g - 1) staged symbols x 64 sequences + the u16 histogram of one
+// key sweep (512 B per key quad). Symbols get what they need up to 64 KiB (all windows in one
+// staging pass when possible), the histogram gets the rest (fewer sweeps over large key spaces).
+struct DensePlan { uint32_t CH = 0, Vcq = 0; size_t lds = 0; };
+DensePlan dense_plan(uint32_t maxW, int g, uint32_t Vq) {
+    DensePlan p;
+    const size_t sym_cap = (size_t)64 << 10;
+    const size_t want_sym = (size_t)(maxW + g - 1) * fsk::PANEL;
+    size_t sym = std::min(want_sym, sym_cap);
+    size_t hist_room = LDS_BUDGET - sym;
+    uint32_t vcq = (uint32_t)std::min<size_t>(Vq, hist_room / 512);
+    if (vcq < Vq) {       // several sweeps: each must start on an 8-key boundary (4-bit panels
+        vcq &= ~1u;       // pack 8 keys per dword)
+        if (vcq < 2) return p;
+    }
+    if (sym / fsk::PANEL < (size_t)g) return p;
+    p.Vcq = vcq;
+    p.CH = (uint32_t)std::min<size_t>(maxW, sym / fsk::PANEL - (size_t)(g - 1));
+    p.lds = (size_t)(p.CH + g - 1) * fsk::PANEL + (size_t)p.Vcq * 512;
+    return p;
 }
 
 // Which dataflow is cheaper per combo (path = auto)? The dense one multiplies every pair of
@@ -201,7 +208,7 @@ bool dense_is_cheaper(const fsk_engine* e) {
 }
 
 int choose_path(fsk_engine* e) {
-    bool dense_ok = e->V <= DENSE_MAX_KEYS && e->Lmax < 65536 && dense_chunk_windows(e->maxW, e->cfg.g, e->Vq) > 0;
+    bool dense_ok = e->V <= DENSE_MAX_KEYS && e->Lmax < 65536 && dense_plan(e->maxW, e->cfg.g, e->Vq).CH > 0;
     if (e->cfg.path == FSK_PATH_DENSE) {
         if (!dense_ok)
             return e->fail(FSK_EUNSUPPORTED, "dense path needs alphabet^k <= %llu and the panel histogram to fit in LDS",
@@ -364,7 +371,9 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     size_t have = (e->d_C.cap + e->d_C4.cap) * sizeof(uint32_t);
-    size_t budget = std::max<size_t>(have, (size_t)((double)(free_b + have) * 0.6));
+    // panels for a few thousand combos per launch are plenty (one more launch costs one more
+    // flush per tile); larger allocations only cost hipMalloc time
+    size_t budget = std::max<size_t>(have, std::min<size_t>((size_t)((double)(free_b + have) * 0.6), (size_t)32 << 30));
     u64 by_memory = std::max<u64>(1, budget / ((slot_dwords + slot_dwords4) * sizeof(uint32_t)));
     const int chunk = (int)std::max<u64>(1, std::min<u64>({(u64)n, by_overflow, by_memory}));
     FSK_HIP(e->d_C.reserve(slot_dwords * (size_t)chunk));
@@ -381,9 +390,10 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
         FSK_HIP(hipStreamSynchronize(e->stream));
         e->tab_t0 = t0; e->tab_t1 = t1; e->tab_n = (uint32_t)tab.size();
     }
-    uint32_t CH = dense_chunk_windows(e->maxW, e->cfg.g, e->Vq);
+    DensePlan plan = dense_plan(e->maxW, e->cfg.g, e->Vq);
+    uint32_t CH = plan.CH;
     if (e->force_chunk) CH = std::max(1u, std::min(CH, e->force_chunk));
-    const size_t lds = dense_lds_bytes(CH, e->cfg.g, e->Vq);
+    const size_t lds = (size_t)(CH + e->cfg.g - 1) * fsk::PANEL + (size_t)plan.Vcq * 512;
 #ifndef FSK_EMU
     FSK_HIP(hipFuncSetAttribute((const void*)fsk::k_dense_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #endif
@@ -408,7 +418,7 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
             const int n_chunks = (nb + slots_per_chunk - 1) / slots_per_chunk;
             e->tic();
             FSK_LAUNCH(fsk::k_dense_count, dim3(panels_pad, n_chunks), dim3(256), lds, e->stream, e->view(), e->cfg.g, e->k,
-                       e->sigma, e->Vq, dense_hist_quads(e->Vq), e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C.p, e->d_C4.p, e->d_flags4.p,
+                       e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C.p, e->d_C4.p, e->d_flags4.p,
                        e->d_flag.p);
             e->toc(&e->st.ms_count);
             e->st.count_launches += 1;
