@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2000, help="sequences in the CPU baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra config-2 measurement (profiling runs)")
     ap.add_argument("--bands", type=int, default=None, help="row bands of the overlapped all-reduce (default: auto)")
     args = ap.parse_args()
 
@@ -205,7 +206,7 @@ def main():
             "phases_ms_per_step": {"count": d("ms_count") / args.steps, "tile": d("ms_tile") / args.steps,
                                    "accumulate_total": d("ms_total") / args.steps},
         }
-        if world == 1:
+        if world == 1 and not args.no_also:
             out["also"] = other_configs(_native)
         if world == 1 and not args.no_cpu_baseline:
             ns = min(args.cpu_sample, N)
