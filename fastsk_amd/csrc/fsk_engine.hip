@@ -375,7 +375,8 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
     // flush per tile); larger allocations only cost hipMalloc time
     size_t budget = std::max<size_t>(have, std::min<size_t>((size_t)((double)(free_b + have) * 0.6), (size_t)32 << 30));
     u64 by_memory = std::max<u64>(1, budget / ((slot_dwords + slot_dwords4) * sizeof(uint32_t)));
-    const int chunk = (int)std::max<u64>(1, std::min<u64>({(u64)n, by_overflow, by_memory}));
+    // (32768 combos per launch also keeps grid.y of the count and tile launches within limits)
+    const int chunk = (int)std::max<u64>(1, std::min<u64>({(u64)n, by_overflow, by_memory, (u64)32768}));
     FSK_HIP(e->d_C.reserve(slot_dwords * (size_t)chunk));
     FSK_HIP(e->d_C4.reserve(slot_dwords4 * (size_t)chunk));
     FSK_HIP(e->d_flag.reserve(2));
@@ -455,7 +456,7 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
         if (n_tiles < 4096 && nb >= 2) {
             const double t_combo = 16384.0 * (double)(Vq8 * 8) / (2.5e14 / 512.0);
             double best = 1e300;
-            for (int sp = 1; sp <= nb; ++sp) {
+            for (int sp = 1; sp <= std::min(nb, 4096); ++sp) {
                 const int per = (nb + sp - 1) / sp;
                 if ((nb + per - 1) / per != sp || per < 2) continue;
                 const double rounds = std::ceil((double)n_tiles * sp / 512.0);
@@ -463,7 +464,7 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
                 if (cost < best) { best = cost; n_splits = sp; }
             }
         }
-        if (e->force_splits > 0) n_splits = std::min(nb, e->force_splits);
+        if (e->force_splits > 0) n_splits = std::min({nb, e->force_splits, 4096});
         const int slots_per_split = (nb + n_splits - 1) / n_splits;
         n_splits = (nb + slots_per_split - 1) / slots_per_split;
         e->tic();
