@@ -17,14 +17,16 @@ def main():
     import build_emu
 
     fixture, outdir = sys.argv[1], sys.argv[2]
-    dist.init_process_group("gloo")
+    device = torch.device(sys.argv[5] if len(sys.argv) > 5 else "cpu")
+    dist.init_process_group("gloo")  # gloo also reduces CUDA tensors: two ranks may share one GPU
     rank, world = dist.get_rank(), dist.get_world_size()
-    lib = _native.Library(build_emu.build())
+    # CPU: the emulated engine (test-only). CUDA: the product library, real HIP kernels.
+    lib = _native.Library(build_emu.build()) if device.type == "cpu" else _native.library()
     d = np.load(fixture)
     eng, K = distributed.compute_sharded(d["tokens"], d["offsets"], int(d["n_train"]), int(d["n_test"]), int(d["g"]),
-                                         int(d["m"]), combos=d["combos"], device=torch.device("cpu"), lib=lib,
+                                         int(d["m"]), combos=d["combos"], device=device, lib=lib,
                                          n_bands=int(sys.argv[3]), narrow=bool(int(sys.argv[4])))
-    np.savez(os.path.join(outdir, "rank%d.npz" % rank), counts=K.numpy().view(np.uint64), tri=eng.get_triangle(),
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), counts=K.cpu().numpy().view(np.uint64), tri=eng.get_triangle(),
              done=eng.stats()["combos_done"], world=world)
     dist.destroy_process_group()
 

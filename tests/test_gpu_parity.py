@@ -219,12 +219,19 @@ def test_config5_full_size_100k(native, port):
         pytest.skip("needs ~60 GB of HBM")
     N, L, g, m = 100000, 300, 12, 8
     tokens, offsets = synthetic_dna(N, L)
+    from fastsk_amd.distributed import band_edges
     e = native.Engine(g, m)
     e.load_sequences(tokens, offsets, N, 0)
-    e.accumulate(np.arange(495, dtype=np.int32))
+    combos = np.arange(495, dtype=np.int32)
+    edges = band_edges(N, 4)  # the row-band form the multi-GPU path uses (panels counted once)
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        e.accumulate_rows(combos, lo, hi)
     e.finalize()
+    st = e.stats()
+    assert st["count_launches"] == 1 and st["n_tile_launches"] == len(edges) - 1 and st["combos_done"] == 495
     X = tokens.reshape(N, L)
-    for (a0, a1), (b0, b1) in [((99936, 100000), (0, 64)), ((46300, 46400), (46290, 46360)), ((70000, 70064), (12345, 12409))]:
+    for (a0, a1), (b0, b1) in [((99936, 100000), (0, 64)), ((46300, 46400), (46290, 46360)), ((70000, 70064), (12345, 12409)),
+                               ((edges[1] - 40, edges[1] + 40), (edges[1] - 60, edges[1] + 10))]:
         idx = np.unique(np.concatenate([np.arange(b0, b1), np.arange(a0, a1)]))
         st, so = native.flatten(X[idx])
         want, _, _ = port.raw_counts(st, so, g, m, np.arange(495), threads=8)
@@ -299,3 +306,32 @@ def test_run_check_style_auc(native):
     clf = CalibratedClassifierCV(LinearSVC(C=1), cv=5).fit(Xtr, ytr)
     auc = roc_auc_score(yte, clf.predict_proba(Xte)[:, 1])
     assert auc >= 0.9, auc
+
+
+@pytest.mark.parametrize("narrow", [0, 1])
+def test_two_ranks_sharing_the_gpu_banded_reduce(native, port, tmp_path, narrow):
+    """The multi-GPU host path with the REAL engine: two processes (gloo, both on cuda:0) shard
+    the combos, accumulate row bands on their own HIP streams and all-reduce each finished band
+    (uint64 and int32-narrowed payloads) while the next band runs. Everything but RCCL itself."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    N, L, g, m = 1500, 120, 10, 6
+    tokens, offsets = synthetic_dna(N, L, seed=7)
+    combos = np.arange(0, 210, 7, dtype=np.int32)
+    fx = tmp_path / "in.npz"
+    np.savez(fx, tokens=tokens, offsets=offsets, n_train=N, n_test=0, g=g, m=m, combos=combos)
+    want, _, _ = port.raw_counts(tokens, offsets, g, m, combos, threads=8)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29701 + narrow), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(fx), str(tmp_path), "4",
+                               str(narrow), "cuda:0"], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    done = 0
+    for r in range(2):
+        z = np.load(tmp_path / ("rank%d.npz" % r))
+        assert np.array_equal(z["counts"], want)
+        assert np.array_equal(z["tri"], port.normalise(want.astype(np.float64), N))
+        done += int(z["done"])
+    assert done == len(combos)
