@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Race/edge screen on the GPU: many random shapes through both HIP dataflows (dense with 4-bit and
+u8 panels, sparse), compared with each other every time and with the CPU oracle on a sample.
+Not part of the pytest suite (minutes of GPU time); run it after touching a kernel."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fastsk_amd import _native
+from oracle import loader
+
+def main(iters=150, seed=0):
+    rng = np.random.default_rng(seed)
+    port = loader.port()
+    t0 = time.time()
+    for it in range(iters):
+        sigma = int(rng.choice([2, 3, 4, 4, 4, 5, 20]))
+        k = int(rng.integers(1, 7 if sigma <= 5 else 4))
+        m = int(rng.integers(0, 7))
+        g = k + m
+        N = int(rng.choice([1, 2, 63, 64, 65, 127, 129, 300, 700, 1500, 3000]))
+        lo = g
+        hi = int(rng.choice([g, g + 1, 40, 120, 330, 700]))
+        hi = max(hi, lo)
+        lens = rng.integers(lo, hi + 1, size=N)
+        X = [rng.integers(1, sigma + 1, size=int(L)).astype(np.int32) for L in lens]
+        if N > 3 and rng.random() < 0.5:  # low-complexity rows: counts above 15 / 255
+            X[int(rng.integers(N))][:] = 1
+            j = int(rng.integers(N)); X[j][: len(X[j]) // 2] = 2
+        tokens, offsets = _native.flatten(X)
+        nc = _native.library().num_combos(g, m)
+        combos = np.unique(rng.integers(0, nc, size=int(rng.integers(1, 24)))).astype(np.int32)
+        ntr = int(rng.integers(1, N + 1))
+        res = {}
+        for name, path, env in (("dense4", 1, "0"), ("dense8", 1, "1"), ("sparse", 2, "0")):
+            if path == 1 and sigma ** k > 16384:
+                continue
+            os.environ["FSK_FORCE_U8"] = env
+            e = _native.Engine(g, m, path=path)
+            e.load_sequences(tokens, offsets, ntr, N - ntr)
+            if rng.random() < 0.5 or N < 256:
+                e.accumulate(combos)
+            else:
+                edges = sorted({0, N, *(int(x) // 128 * 128 for x in rng.integers(0, N, size=2))})
+                for a, b in zip(edges[:-1], edges[1:]):
+                    e.accumulate_rows(combos, a, b)
+            e.finalize()
+            res[name] = (e.get_counts(), e.get_triangle())
+            e.close()
+        names = list(res)
+        for n in names[1:]:
+            assert np.array_equal(res[names[0]][0], res[n][0]), (it, "counts", names[0], n, sigma, g, m, N, hi)
+            assert np.array_equal(res[names[0]][1], res[n][1]), (it, "tri", names[0], n, sigma, g, m, N, hi)
+        if it % 5 == 0 and N <= 700:
+            want, _, _ = port.raw_counts(tokens, offsets, g, m, combos, threads=8)
+            assert np.array_equal(res[names[0]][0], want), (it, "oracle", sigma, g, m, N, hi)
+        if it % 25 == 0:
+            print("iter %d ok (%.0fs) sigma=%d g=%d m=%d N=%d Lmax=%d paths=%s" % (it, time.time() - t0, sigma, g, m, N, hi, names), flush=True)
+    print("stress OK: %d random cases, all dataflows identical" % iters)
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 150, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
