@@ -208,7 +208,7 @@ bool dense_is_cheaper(const fsk_engine* e) {
 }
 
 int choose_path(fsk_engine* e) {
-    bool dense_ok = e->V <= DENSE_MAX_KEYS && e->Lmax < 65536 && dense_plan(e->maxW, e->cfg.g, e->Vq).CH > 0;
+    bool dense_ok = e->V <= DENSE_MAX_KEYS && e->k <= 16 && e->Lmax < 65536 && dense_plan(e->maxW, e->cfg.g, e->Vq).CH > 0;
     if (e->cfg.path == FSK_PATH_DENSE) {
         if (!dense_ok)
             return e->fail(FSK_EUNSUPPORTED, "dense path needs alphabet^k <= %llu and the panel histogram to fit in LDS",

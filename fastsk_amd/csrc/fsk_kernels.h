@@ -87,6 +87,30 @@ __device__ __forceinline__ uint32_t panel_slot(uint32_t r) { return ((r & 15u) <
 // tile-local row/column (0..127) of register e (0..7) of lane group t (0..15): inverse of the above
 __device__ __forceinline__ uint32_t tile_index(uint32_t t, uint32_t e) { return (e >> 2) * 64u + t + 16u * (e & 3u); }
 
+// One wave's share of the windows [j0, hi) of a staging chunk: key from K kept positions held
+// in registers (K is a template parameter so the K LDS byte reads of a window are independent
+// and issue back to back; K = 0 is the generic loop for k > 8), one LDS atomic per window.
+template <int K>
+__device__ __forceinline__ void count_windows(const uint8_t* symT, uint32_t* hist, const uint32_t (&pr)[16], int k,
+                                              uint32_t sigma, uint32_t j0, uint32_t hi, uint32_t cb, uint32_t nwin,
+                                              uint32_t r, uint32_t half, uint32_t key_lo, uint32_t key_n) {
+    for (uint32_t j = j0; j < hi; j += 4) {
+        if (j < nwin) {
+            uint32_t key = 0;
+            if (K > 0) {
+#pragma unroll
+                for (int c = 0; c < K; ++c) key = key * sigma + symT[(j - cb + pr[c]) * PANEL + r];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c < k) key = key * sigma + symT[(j - cb + pr[c]) * PANEL + r];
+            }
+            key -= key_lo;  // wraps for keys below the sweep: rejected by the compare
+            if (key < key_n) atomicAdd(&hist[key * 32u + (r >> 1)], 1u << half);
+        }
+    }
+}
+
 // Per-sequence counting sort of the k-mers selected by each combo ("segment counts").
 // grid = (n_panels, n_chunks), block = 256 (wave w takes windows j = w mod 4; lane = sequence).
 // dynamic LDS: symT[Lmax][64] u8 | hist[4*Vq][32] u32 (two u16 counters per dword).
@@ -119,7 +143,10 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
     bool ovf = false, ovf4 = false;
     const uint32_t Vq8 = (Vq + 1u) >> 1;
     for (int slot = slot0; slot < slot1; ++slot) {
-        const uint8_t* pos = combo_pos + (size_t)slot * k;
+        // this combo's kept positions, once per combo, into registers (k <= 16 on this path)
+        uint32_t pr[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) pr[c] = c < k ? (uint32_t)combo_pos[(size_t)slot * k + c] : 0u;
         uint32_t* out = C + ((size_t)panel * n_slots + slot) * ((size_t)Vq * PANEL);
         uint32_t* out4 = C4 + ((size_t)panel * n_slots + slot) * ((size_t)Vq8 * PANEL);
         for (uint32_t kc0 = 0; kc0 < Vq; kc0 += Vcq) {  // key-space sweep
@@ -134,13 +161,17 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
                 }
                 __syncthreads();  // symbols staged, histogram zeroed
                 const uint32_t hi = cb + CH < max_win ? cb + CH : max_win;
-                for (uint32_t j = cb + w; j < hi; j += 4) {
-                    if (j < nwin) {
-                        uint32_t key = 0;
-                        for (int c = 0; c < k; ++c) key = key * sigma + symT[(j - cb + pos[c]) * PANEL + r];
-                        key -= key_lo;  // wraps for keys below the sweep: rejected by the compare
-                        if (key < key_n) atomicAdd(&hist[key * 32u + (uint32_t)(r >> 1)], 1u << half);
-                    }
+                const uint32_t j0 = cb + (uint32_t)w, rr = (uint32_t)r;
+                switch (k) {  // workgroup-uniform
+                    case 1: count_windows<1>(symT, hist, pr, k, sigma, j0, hi, cb, nwin, rr, half, key_lo, key_n); break;
+                    case 2: count_windows<2>(symT, hist, pr, k, sigma, j0, hi, cb, nwin, rr, half, key_lo, key_n); break;
+                    case 3: count_windows<3>(symT, hist, pr, k, sigma, j0, hi, cb, nwin, rr, half, key_lo, key_n); break;
+                    case 4: count_windows<4>(symT, hist, pr, k, sigma, j0, hi, cb, nwin, rr, half, key_lo, key_n); break;
+                    case 5: count_windows<5>(symT, hist, pr, k, sigma, j0, hi, cb, nwin, rr, half, key_lo, key_n); break;
+                    case 6: count_windows<6>(symT, hist, pr, k, sigma, j0, hi, cb, nwin, rr, half, key_lo, key_n); break;
+                    case 7: count_windows<7>(symT, hist, pr, k, sigma, j0, hi, cb, nwin, rr, half, key_lo, key_n); break;
+                    case 8: count_windows<8>(symT, hist, pr, k, sigma, j0, hi, cb, nwin, rr, half, key_lo, key_n); break;
+                    default: count_windows<0>(symT, hist, pr, k, sigma, j0, hi, cb, nwin, rr, half, key_lo, key_n); break;
                 }
             }
             __syncthreads();

@@ -239,7 +239,7 @@ def test_emu_dense_count_chunked_staging(emu_lib, port, monkeypatch, chunk):
     assert np.array_equal(e.get_counts(), want)
 
 
-@pytest.mark.parametrize("sigma,g,m", [(4, 8, 2), (5, 7, 2), (3, 9, 2)])
+@pytest.mark.parametrize("sigma,g,m", [(4, 8, 2), (5, 7, 2), (3, 9, 2), (2, 12, 2), (2, 14, 1)])
 def test_emu_dense_large_key_space_sweeps(emu_lib, port, sigma, g, m):
     """Key spaces above one LDS histogram (640 keys) are counted in several sweeps: DNA k = 6
     (4096 keys), 5 symbols k = 5 (3125), 3 symbols k = 7 (2187)."""
