@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Multi-GPU exact kernel: one process per GPU, combos sharded, banded all-reduce over RCCL.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+        examples/multi_gpu.py --n-seq 100000 --seq-len 300 -g 12 -m 8
+
+Every rank ends with the reduced integer triangle; rank 0 prints a corner of the normalised
+kernel. See fastsk_amd/distributed.py.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fastsk_amd import distributed  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n-seq", type=int, default=20000)
+    ap.add_argument("--seq-len", type=int, default=300)
+    ap.add_argument("-g", type=int, default=12)
+    ap.add_argument("-m", type=int, default=8)
+    args = ap.parse_args()
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    rng = np.random.Generator(np.random.PCG64(20201214))
+    X = rng.integers(1, 5, size=(args.n_seq, args.seq_len), dtype=np.int32)
+    tokens, offsets = X.reshape(-1), np.arange(args.n_seq + 1, dtype=np.int64) * args.seq_len
+    t0 = time.time()
+    eng, K = distributed.compute_sharded(tokens, offsets, args.n_seq, 0, args.g, args.m)
+    dt = time.time() - t0
+    if not dist.is_initialized() or dist.get_rank() == 0:
+        print("exact gkm kernel, %d sequences, %d GPUs: %.2f s" % (args.n_seq, dist.get_world_size() if dist.is_initialized() else 1, dt))
+        print(eng.get_block(0, 4, 0, 4))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
