@@ -22,6 +22,9 @@ def sha(a):
 def native():
     import torch
     assert torch.cuda.is_available(), "gpu tests need a GPU"
+    import __graft_entry__ as ge
+    ge.build_engine()    # no-op when fastsk_amd/lib/libfastsk_amd.so is current
+    ge.build_bindings()
     from fastsk_amd import _native
     lib = _native.library()  # raises if the HIP library is missing: no fallback
     assert lib.device_count() >= 1
