@@ -105,6 +105,10 @@ struct fsk_engine {
     DevBuf<unsigned char> d_keys[2];
     DevBuf<uint32_t> d_vals[2], d_blockhist, d_totals, d_estart, d_eseq, d_erun, d_rstart, d_segtot;
     DevBuf<u64> d_blocksum, d_U;
+    DevBuf<uint32_t> d_bk_hist, d_bk_tot, d_slice_off;  // owner-slice pair accumulation
+    DevBuf<uint4> d_list;
+    DevBuf<uint2> d_epair;
+    int force_global_pairs = 0;  // FSK_SPARSE_GLOBAL=1: per-pair global atomics (testing)
 
     fsk_stats st{};
 
@@ -289,8 +293,38 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     e->toc(&e->st.ms_segment);
 
     e->tic();
-    FSK_LAUNCH(fsk::k_sparse_pairs, dim3((uint32_t)((nrec + 255) / 256)), dim3(256), 0, e->stream, e->d_segtot.p,
-               e->d_estart.p, e->d_eseq.p, e->d_erun.p, e->d_rstart.p, (u64)row0, (u64)row1, K, e->d_U.p);
+    // rows of K per owner slice: as many as fit 32 KiB of u32 cells (four workgroups per CU hide
+    // the latency of the partner fetches)
+    const size_t row_bytes = (size_t)e->N * sizeof(uint32_t);
+    const uint32_t rps = (uint32_t)std::min<size_t>((size_t)e->N, std::max<size_t>(1, ((size_t)32 << 10) / row_bytes));
+    const uint32_t n_slices = (uint32_t)((e->N + rps - 1) / rps);
+    const bool lds_ok = row_bytes <= LDS_BUDGET && n_slices <= (uint32_t)fsk::BK_MAX_SLICES && !e->force_global_pairs;
+    if (lds_ok) {
+        const uint32_t bk_blocks = (uint32_t)((nrec + fsk::BK_TILE - 1) / fsk::BK_TILE);
+        FSK_HIP(e->d_bk_hist.reserve((size_t)n_slices * bk_blocks));
+        FSK_HIP(e->d_bk_tot.reserve(n_slices));
+        FSK_HIP(e->d_slice_off.reserve((size_t)n_slices + 1));
+        FSK_HIP(e->d_list.reserve(nrec));
+        FSK_HIP(e->d_epair.reserve(nrec));
+        FSK_LAUNCH(fsk::k_bucket_hist, dim3(bk_blocks), dim3(256), 0, e->stream, e->d_segtot.p, e->d_estart.p, e->d_eseq.p, rps,
+                   n_slices, bk_blocks, e->d_bk_hist.p, e->d_epair.p);
+        FSK_LAUNCH(fsk::k_rs_scan_rows, dim3(n_slices), dim3(256), 0, e->stream, e->d_bk_hist.p, bk_blocks, e->d_bk_tot.p);
+        FSK_LAUNCH(fsk::k_bucket_scan_totals, dim3(1), dim3(256), 0, e->stream, e->d_bk_tot.p, n_slices, e->d_slice_off.p);
+        FSK_LAUNCH(fsk::k_bucket_scatter, dim3(bk_blocks), dim3(256), 0, e->stream, e->d_segtot.p, e->d_epair.p, e->d_erun.p,
+                   e->d_rstart.p, rps, n_slices, bk_blocks, e->d_bk_hist.p, e->d_slice_off.p, e->d_list.p);
+        const uint32_t s_lo = (uint32_t)(row0 / rps), s_hi = (uint32_t)((row1 + rps - 1) / rps);
+        const size_t lds = (size_t)rps * row_bytes;
+#ifndef FSK_EMU
+        FSK_HIP(hipFuncSetAttribute((const void*)fsk::k_slice_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#endif
+        if (s_hi > s_lo)
+            FSK_LAUNCH(fsk::k_slice_pairs, dim3(s_hi - s_lo), dim3(256), lds, e->stream, e->d_slice_off.p, e->d_list.p, e->d_epair.p,
+                       rps, (uint32_t)e->N, s_lo, (u64)row0, (u64)row1, K, e->d_U.p);
+        e->st.launches += 4;
+    } else {
+        FSK_LAUNCH(fsk::k_sparse_pairs, dim3((uint32_t)((nrec + 255) / 256)), dim3(256), 0, e->stream, e->d_segtot.p,
+                   e->d_estart.p, e->d_eseq.p, e->d_erun.p, e->d_rstart.p, (u64)row0, (u64)row1, K, e->d_U.p);
+    }
     e->toc(&e->st.ms_pairs);
     e->st.launches += 4;
     FSK_HIP(hipGetLastError());
@@ -315,6 +349,8 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     size_t per = SPARSE_MAX_RECORDS / (size_t)std::max<int64_t>(1, e->nfeat);
     int B = (int)std::max<size_t>(1, std::min<size_t>(per, (size_t)n));
     while (B > 1 && (u64)B * e->V >= ((u64)1 << 62)) B /= 2;
+    // the owner-slice accumulation sums a batch in u32 LDS cells: per cell and combo <= maxW^2
+    B = (int)std::max<u64>(1, std::min<u64>((u64)B, 0xffffffffull / std::max<u64>(1, (u64)e->maxW * e->maxW)));
     for (int s = 0; s < n; s += B) {
         const int nb = std::min(B, n - s);
         const bool wide = (u64)nb * e->V > 0xffffffffull;
@@ -651,6 +687,7 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     if (e->ncomb > 0x7fffffff) { delete e; g_create_error = "C(g,m) >= 2^31 unsupported"; return FSK_EUNSUPPORTED; }
     enumerate_combos(cfg->g, e->k, e->all_pos);
     { const char* f = getenv("FSK_FORCE_U8"); e->force_u8 = f && *f == '1'; }
+    { const char* f = getenv("FSK_SPARSE_GLOBAL"); e->force_global_pairs = f ? atoi(f) : 0; }
     { const char* f = getenv("FSK_TILE_SPLITS"); e->force_splits = f ? atoi(f) : 0; }
     { const char* f = getenv("FSK_DENSE_CHUNK"); e->force_chunk = f ? (uint32_t)atoi(f) : 0u; }
     if (hipStreamCreate(&e->stream) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
@@ -674,6 +711,7 @@ void fsk_destroy(fsk_engine* e) {
     for (int b = 0; b < 2; ++b) { e->d_keys[b].release(); e->d_vals[b].release(); }
     e->d_blockhist.release(); e->d_totals.release(); e->d_estart.release(); e->d_eseq.release(); e->d_erun.release();
     e->d_rstart.release(); e->d_segtot.release(); e->d_blocksum.release(); e->d_U.release();
+    e->d_bk_hist.release(); e->d_bk_tot.release(); e->d_slice_off.release(); e->d_list.release(); e->d_epair.release();
     (void)hipEventDestroy(e->ev0);
     (void)hipEventDestroy(e->ev1);
     (void)hipStreamDestroy(e->stream);

@@ -21,7 +21,9 @@
 //     k_rs_*            LDS-staged 8-bit LSD radix sort (wave64 ballot match ranking, stable)
 //     k_seg_*           run heads by neighbour compare, wave prefix sums -> distinct (k-mer,seq)
 //                       entries with multiplicities and run starts
-//     k_sparse_pairs    per (run, pair) 64-bit atomicAdd into K
+//     k_bucket_* + k_slice_pairs  (run, pair) updates summed in LDS by the workgroup that owns the
+//                       rows, non-zero cells flushed with 64-bit atomicAdd (k_sparse_pairs: direct
+//                       per-pair atomics, used when a row band of K does not fit in LDS)
 //
 // Everything is written for 64-wide wavefronts; lane = threadIdx.x & 63.
 #pragma once
@@ -648,6 +650,129 @@ __global__ __launch_bounds__(256) void k_sparse_pairs(const uint32_t* totals, co
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) work += __shfl_xor(work, d);
     if ((threadIdx.x & 63) == 0 && work) atomicAdd(U, work);
+}
+
+// ---- owner-slice pair accumulation -----------------------------------------------------------
+// Scattered 64-bit atomics run at the chip's per-request rate (~16 G/s) and the protein configs
+// issue ~450 of them per cell of K over a full run. When a band of `rps` rows of K fits in LDS
+// (rps * N u32 cells), the entries are bucketed by the slice that owns their row (an LDS-
+// privatised counting sort, any order inside a bucket), every slice is owned by ONE workgroup,
+// the (run, pair) updates of a whole batch of combos are summed with LDS atomics, and only the
+// non-zero cells are flushed, row-contiguous, with one 64-bit atomicAdd each.
+constexpr int BK_TILE = 2048;       // entries per bucketing workgroup
+constexpr int BK_MAX_SLICES = 8192; // LDS histogram / cursor size
+
+// pass A: per-workgroup slice histogram -> blockhist[slice][block]; also packs (seq, multiplicity)
+// per entry so that the pair loop fetches a partner with one 8-byte load
+__global__ __launch_bounds__(256) void k_bucket_hist(const uint32_t* totals, const uint32_t* estart, const uint32_t* eseq,
+                                                     uint32_t rps, uint32_t n_slices, uint32_t nblocks, uint32_t* blockhist,
+                                                     uint2* epair) {
+    __shared__ uint32_t h[BK_MAX_SLICES];
+    const uint32_t D = totals[0];
+    const int tid = threadIdx.x;
+    for (uint32_t i = tid; i < n_slices; i += 256) h[i] = 0u;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * BK_TILE;
+    for (int it = 0; it < BK_TILE / 256; ++it) {
+        const uint32_t e = base + (uint32_t)it * 256u + (uint32_t)tid;
+        if (e < D) {
+            const uint32_t sq = eseq[e];
+            atomicAdd(&h[sq / rps], 1u);
+            epair[e] = make_uint2(sq, estart[e + 1] - estart[e]);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n_slices; i += 256) blockhist[(size_t)i * nblocks + blockIdx.x] = h[i];
+}
+
+// pass C: exclusive scan of the slice totals (single workgroup), slice_off[n_slices] = D
+__global__ __launch_bounds__(256) void k_bucket_scan_totals(const uint32_t* totals_in, uint32_t n_slices, uint32_t* slice_off) {
+    __shared__ uint32_t tmp[4];
+    const int tid = threadIdx.x;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_slices; base += 256) {
+        const uint32_t i = base + (uint32_t)tid;
+        const uint32_t v = i < n_slices ? totals_in[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_256<uint32_t>(v, tmp, &tot) + carry;
+        if (i < n_slices) slice_off[i] = ex;
+        carry += tot;
+    }
+    if (tid == 0) slice_off[n_slices] = carry;
+}
+
+// pass D: scatter a self-contained work record per entry {seq, multiplicity, first entry of its
+// run, entry} into its slice's bucket (LDS cursors; the order inside a bucket is free). The
+// dependent lookups (run -> run start) are paid here, where thousands of workgroups hide them.
+__global__ __launch_bounds__(256) void k_bucket_scatter(const uint32_t* totals, const uint2* epair, const uint32_t* erun,
+                                                        const uint32_t* rstart, uint32_t rps, uint32_t n_slices,
+                                                        uint32_t nblocks, const uint32_t* blockhist, const uint32_t* slice_off,
+                                                        uint4* list) {
+    __shared__ uint32_t cur[BK_MAX_SLICES];
+    const uint32_t D = totals[0];
+    const int tid = threadIdx.x;
+    for (uint32_t i = tid; i < n_slices; i += 256) cur[i] = slice_off[i] + blockhist[(size_t)i * nblocks + blockIdx.x];
+    __syncthreads();
+    const uint32_t base = blockIdx.x * BK_TILE;
+    for (int it = 0; it < BK_TILE / 256; ++it) {
+        const uint32_t e = base + (uint32_t)it * 256u + (uint32_t)tid;
+        if (e < D) {
+            const uint2 sc = epair[e];
+            const uint32_t rs = rstart[erun[e]];
+            const uint32_t dst = atomicAdd(&cur[sc.x / rps], 1u);
+            list[dst] = make_uint4(sc.x, sc.y, rs, e);
+        }
+    }
+}
+
+// One workgroup per slice of `rps` rows: sums every (run, pair) update whose row it owns in LDS,
+// then flushes the non-zero cells. dynamic LDS: rps * N u32. Partners are fetched four at a time
+// so that their loads overlap.
+__global__ __launch_bounds__(256) void k_slice_pairs(const uint32_t* slice_off, const uint4* list, const uint2* epair,
+                                                     uint32_t rps, uint32_t N, uint32_t slice0, u64 row0, u64 row1, u64* K,
+                                                     u64* U) {
+    FSK_DYN_SHARED(uint32_t, sk);
+    const int tid = threadIdx.x;
+    const uint32_t slice = slice0 + blockIdx.x;
+    const uint32_t r_lo = slice * rps;
+    const uint32_t cells = rps * N;
+    for (uint32_t i = tid; i < cells; i += 256) sk[i] = 0u;
+    __syncthreads();
+    const uint32_t lo = slice_off[slice], hi = slice_off[slice + 1];
+    u64 work = 0;
+    for (uint32_t base = lo; base < hi; base += 256) {
+        const uint32_t t = base + (uint32_t)tid;
+        if (t < hi) {
+            const uint4 rec = list[t];  // {seq_a, cnt_a, run start, entry}
+            if (rec.x >= row0 && rec.x < row1) {
+                uint32_t* row = sk + (size_t)(rec.x - r_lo) * N;
+                uint32_t b = rec.z;
+                for (; b + 3 <= rec.w; b += 4) {
+                    const uint2 p0 = epair[b], p1 = epair[b + 1], p2 = epair[b + 2], p3 = epair[b + 3];
+                    atomicAdd(&row[p0.x], rec.y * p0.y);  // seq_b <= seq_a
+                    atomicAdd(&row[p1.x], rec.y * p1.y);
+                    atomicAdd(&row[p2.x], rec.y * p2.y);
+                    atomicAdd(&row[p3.x], rec.y * p3.y);
+                }
+                for (; b <= rec.w; ++b) {
+                    const uint2 p = epair[b];
+                    atomicAdd(&row[p.x], rec.y * p.y);
+                }
+                work += (u64)(rec.w - rec.z + 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < cells; i += 256) {
+        const uint32_t v = sk[i];
+        if (v) {
+            const u64 r = (u64)r_lo + i / N, c = i % N;
+            atomicAdd(&K[tri_index(r, c)], (u64)v);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) work += __shfl_xor(work, d);
+    if ((tid & 63) == 0 && work) atomicAdd(U, work);
 }
 
 // =============================================================================================

@@ -257,3 +257,20 @@ def test_emu_dense_large_key_space_sweeps(emu_lib, port, sigma, g, m):
     e.finalize()
     assert e.stats()["key_space"] == sigma ** (g - m)
     assert np.array_equal(e.get_counts(), want)
+
+
+@pytest.mark.parametrize("global_pairs", ["0", "1"])
+def test_emu_sparse_pair_accumulation_variants(emu_lib, port, monkeypatch, global_pairs):
+    """Sparse dataflow: owner-slice LDS accumulation (default when a row band of K fits in LDS)
+    and direct per-pair global atomics (large N) issue the same updates."""
+    from fastsk_amd import _native
+    monkeypatch.setenv("FSK_SPARSE_GLOBAL", global_pairs)
+    d = load_golden("f5_prot11_exact")
+    combos = np.arange(0, 210, 30, dtype=np.int32)
+    want, _, U = port.raw_counts(d["tokens"], d["offsets"], d["g"], d["m"], combos)
+    e = _native.Engine(d["g"], d["m"], path=2, lib=emu_lib)
+    e.load_sequences(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+    e.accumulate(combos)
+    e.finalize()
+    assert np.array_equal(e.get_counts(), want)
+    assert e.stats()["cell_updates"] == U

@@ -338,3 +338,30 @@ def test_two_ranks_sharing_the_gpu_banded_reduce(native, port, tmp_path, narrow)
         assert np.array_equal(z["tri"], port.normalise(want.astype(np.float64), N))
         done += int(z["done"])
     assert done == len(combos)
+
+
+@pytest.mark.parametrize("global_pairs", ["0", "1"])
+def test_sparse_pair_accumulation_variants(native, port, monkeypatch, global_pairs):
+    """Protein-like input through the sparse dataflow with owner-slice LDS accumulation and with
+    direct per-pair atomics, whole and in row bands; U equals the oracle's count of `+=`."""
+    monkeypatch.setenv("FSK_SPARSE_GLOBAL", global_pairs)
+    rng = np.random.default_rng(31)
+    N = 900
+    X = [rng.integers(1, 21, size=int(L)).astype(np.int32) for L in rng.integers(20, 400, size=N)]
+    for i in range(0, N, 7):
+        X[i][:18] = X[0][:18]  # shared prefixes: runs with many sequences
+    tokens, offsets = native.flatten(X)
+    combos = np.arange(0, 210, 11, dtype=np.int32)
+    want, _, U = port.raw_counts(tokens, offsets, 10, 6, combos, threads=8)
+    e = native.Engine(10, 6, path=2)
+    e.load_sequences(tokens, offsets, 600, 300)
+    e.accumulate(combos)
+    e.finalize()
+    assert np.array_equal(e.get_counts(), want)
+    assert e.stats()["cell_updates"] == U
+    e.reset_counts()
+    for lo, hi in [(0, 256), (256, 768), (768, 900)]:
+        e.accumulate_rows(combos, lo, hi)
+    e.finalize()
+    assert np.array_equal(e.get_counts(), want)
+    e.close()

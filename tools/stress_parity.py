@@ -32,10 +32,11 @@ def main(iters=150, seed=0):
         combos = np.unique(rng.integers(0, nc, size=int(rng.integers(1, 24)))).astype(np.int32)
         ntr = int(rng.integers(1, N + 1))
         res = {}
-        for name, path, env in (("dense4", 1, "0"), ("dense8", 1, "1"), ("sparse", 2, "0")):
-            if path == 1 and sigma ** k > 16384:
+        for name, path, env in (("dense4", 1, "0"), ("dense8", 1, "1"), ("sparse", 2, "0"), ("sparse_global", 2, "1")):
+            if path == 1 and (sigma ** k > 16384 or k > 16):
                 continue
-            os.environ["FSK_FORCE_U8"] = env
+            os.environ["FSK_FORCE_U8"] = env if path == 1 else "0"
+            os.environ["FSK_SPARSE_GLOBAL"] = env if path == 2 else "0"
             e = _native.Engine(g, m, path=path)
             e.load_sequences(tokens, offsets, ntr, N - ntr)
             if rng.random() < 0.5 or N < 256:
