@@ -572,7 +572,18 @@ int run_variance_mode(fsk_engine* e, int T) {
     FSK_HIP(e->d_Khat.reserve((size_t)pairs));
     FSK_HIP(e->d_prod.reserve((size_t)std::max<int64_t>(1, train_pairs)));
     FSK_HIP(hipMemsetAsync(e->d_Kf64.p, 0, (size_t)pairs * sizeof(double), e->stream));
-    std::vector<double> prod((size_t)train_pairs);
+    // pinned host buffer, copied in chunks so that the sequential host sum of chunk c overlaps
+    // the D2H copy of chunk c+1
+    const int64_t CHUNK = (int64_t)1 << 20;
+    const int n_chunks = (int)std::max<int64_t>(1, (train_pairs + CHUNK - 1) / CHUNK);
+    double* prod = nullptr;
+    FSK_HIP(hipHostMalloc((void**)&prod, (size_t)std::max<int64_t>(1, train_pairs) * sizeof(double)));
+    std::vector<hipEvent_t> evs((size_t)n_chunks);
+    for (auto& ev : evs) (void)hipEventCreate(&ev);
+    struct Cleanup {
+        double* p; std::vector<hipEvent_t>* e;
+        ~Cleanup() { for (auto& ev : *e) (void)hipEventDestroy(ev); (void)hipHostFree(p); }
+    } cleanup{prod, &evs};
     const uint32_t blocks = (uint32_t)((pairs + 255) / 256);
     const int n_order = (int)e->order.size();
     e->stdevs.clear();
@@ -587,12 +598,20 @@ int run_variance_mode(fsk_engine* e, int T) {
             if (rc) return rc;
             FSK_LAUNCH(fsk::k_welford, dim3(blocks), dim3(256), 0, e->stream, e->d_K, e->d_Khat.p, e->d_prod.p, (u64)pairs,
                        (u64)train_pairs, (double)iter);
-            FSK_HIP(hipMemcpyAsync(prod.data(), e->d_prod.p, (size_t)train_pairs * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-            FSK_HIP(hipStreamSynchronize(e->stream));
+            for (int c = 0; c < n_chunks; ++c) {
+                const int64_t lo = (int64_t)c * CHUNK, cnt = std::min(CHUNK, train_pairs - lo);
+                if (cnt > 0)
+                    FSK_HIP(hipMemcpyAsync(prod + lo, e->d_prod.p + lo, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+                FSK_HIP(hipEventRecord(evs[(size_t)c], e->stream));
+            }
             // the reference's avg_variance is a sequential fp64 sum in triangle-index order
             // (fastsk_kernel.cpp:116-131); keep that order so stdevs match to the last bit
             double avg = 0;
-            for (int64_t i = 0; i < train_pairs; ++i) avg += prod[(size_t)i];
+            for (int c = 0; c < n_chunks; ++c) {
+                FSK_HIP(hipEventSynchronize(evs[(size_t)c]));
+                const int64_t lo = (int64_t)c * CHUNK, hi = std::min(lo + CHUNK, train_pairs);
+                for (int64_t i = lo; i < hi; ++i) avg += prod[i];
+            }
             avg /= (double)train_pairs;
             if (iter == 1) avg = 9999999;
             else avg /= iter - 1;
