@@ -97,6 +97,12 @@ struct fsk_engine {
     // dense scratch
     DevBuf<uint32_t> d_C, d_C4, d_flag;
     DevBuf<uint8_t> d_flags4;
+    DevBuf<uint32_t> d_keybits;   // key compaction: per-combo bitmap of the keys that occur
+    DevBuf<uint16_t> d_lut, d_vc; //                  rank table and key count per combo
+    bool compact = false;         // decided at load: the alphabet has a rare symbol
+    std::vector<uint16_t> h_vc_cache;
+    double vc_sum = 0, vc_n = 0;
+    int force_compact = -1;       // FSK_COMPACT=0/1 overrides (testing)
     DevBuf<uint32_t> d_tiletab;
     uint32_t tab_t0 = 0, tab_t1 = 0, tab_n = 0;   // tile-row range the table on the device covers
     std::vector<int32_t> prep_combos;              // combos whose count panels are resident
@@ -180,12 +186,13 @@ constexpr size_t SPARSE_MAX_RECORDS = 1u << 25; // records per sort batch
 // key sweep (512 B per key quad). Symbols get what they need up to 64 KiB (all windows in one
 // staging pass when possible), the histogram gets the rest (fewer sweeps over large key spaces).
 struct DensePlan { uint32_t CH = 0, Vcq = 0; size_t lds = 0; };
-DensePlan dense_plan(uint32_t maxW, int g, uint32_t Vq) {
+DensePlan dense_plan(uint32_t maxW, int g, uint32_t Vq, size_t extra = 0) {
     DensePlan p;
     const size_t sym_cap = (size_t)64 << 10;
     const size_t want_sym = (size_t)(maxW + g - 1) * fsk::PANEL;
     size_t sym = std::min(want_sym, sym_cap);
-    size_t hist_room = LDS_BUDGET - sym;
+    if (sym + extra + 1024 > LDS_BUDGET) return p;
+    size_t hist_room = LDS_BUDGET - sym - extra;
     uint32_t vcq = (uint32_t)std::min<size_t>(Vq, hist_room / 512);
     if (vcq < Vq) {       // several sweeps: each must start on an 8-key boundary (4-bit panels
         vcq &= ~1u;       // pack 8 keys per dword)
@@ -194,7 +201,7 @@ DensePlan dense_plan(uint32_t maxW, int g, uint32_t Vq) {
     if (sym / fsk::PANEL < (size_t)g) return p;
     p.Vcq = vcq;
     p.CH = (uint32_t)std::min<size_t>(maxW, sym / fsk::PANEL - (size_t)(g - 1));
-    p.lds = (size_t)(p.CH + g - 1) * fsk::PANEL + (size_t)p.Vcq * 512;
+    p.lds = (size_t)(p.CH + g - 1) * fsk::PANEL + (size_t)p.Vcq * 512 + extra;
     return p;
 }
 
@@ -427,13 +434,29 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
         FSK_HIP(hipStreamSynchronize(e->stream));
         e->tab_t0 = t0; e->tab_t1 = t1; e->tab_n = (uint32_t)tab.size();
     }
-    DensePlan plan = dense_plan(e->maxW, e->cfg.g, e->Vq);
+    const bool compact = e->compact;
+    const uint32_t Vkeys = (uint32_t)e->V, Vw = (Vkeys + 31u) / 32u;
+    DensePlan plan = dense_plan(e->maxW, e->cfg.g, e->Vq, compact ? (size_t)Vkeys * 2 : 0);
+    if (plan.CH == 0) return e->fail(FSK_EUNSUPPORTED, "dense path: LDS plan does not fit");
     uint32_t CH = plan.CH;
     if (e->force_chunk) CH = std::max(1u, std::min(CH, e->force_chunk));
-    const size_t lds = (size_t)(CH + e->cfg.g - 1) * fsk::PANEL + (size_t)plan.Vcq * 512;
+    const size_t lds = (size_t)(CH + e->cfg.g - 1) * fsk::PANEL + (size_t)plan.Vcq * 512 + (compact ? (size_t)Vkeys * 2 : 0);
 #ifndef FSK_EMU
-    FSK_HIP(hipFuncSetAttribute((const void*)fsk::k_dense_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        auto k0 = fsk::k_dense_count<false, false>;
+        auto k1 = fsk::k_dense_count<false, true>;
+        auto k2 = fsk::k_dense_count<true, false>;
+        FSK_HIP(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FSK_HIP(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FSK_HIP(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
 #endif
+    if (compact) {
+        FSK_HIP(e->d_keybits.reserve((size_t)chunk * Vw));
+        FSK_HIP(e->d_lut.reserve((size_t)chunk * Vkeys));
+        FSK_HIP(e->d_vc.reserve((size_t)chunk));
+    }
+    std::vector<uint16_t> h_vc;
     std::vector<uint8_t> pos;
     for (int s = 0; s < n; s += chunk) {
         const int nb = std::min(chunk, n - s);
@@ -454,9 +477,36 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
             const int slots_per_chunk = std::max(1, std::min(nb, 16));
             const int n_chunks = (nb + slots_per_chunk - 1) / slots_per_chunk;
             e->tic();
-            FSK_LAUNCH(fsk::k_dense_count, dim3(panels_pad, n_chunks), dim3(256), lds, e->stream, e->view(), e->cfg.g, e->k,
-                       e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C.p, e->d_C4.p, e->d_flags4.p,
-                       e->d_flag.p);
+            const dim3 cgrid(panels_pad, n_chunks);
+            // (function pointers: a template-id with a comma cannot pass through the launch macro)
+            auto k_mark = fsk::k_dense_count<true, false>;
+            auto k_count_lut = fsk::k_dense_count<false, true>;
+            auto k_count = fsk::k_dense_count<false, false>;
+            if (compact) {  // which keys occur per combo -> rank tables -> compacted panels
+                FSK_HIP(hipMemsetAsync(e->d_keybits.p, 0, (size_t)nb * Vw * sizeof(uint32_t), e->stream));
+                FSK_LAUNCH(k_mark, cgrid, dim3(256), lds, e->stream, e->view(), e->cfg.g,
+                           e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C.p, e->d_C4.p,
+                           e->d_flags4.p, e->d_flag.p, Vkeys, (const uint16_t*)nullptr, (const uint16_t*)nullptr, e->d_keybits.p);
+                FSK_LAUNCH(fsk::k_dense_keylut, dim3(nb), dim3(256), 0, e->stream, e->d_keybits.p, Vkeys, e->d_lut.p, e->d_vc.p);
+                FSK_LAUNCH(k_count_lut, cgrid, dim3(256), lds, e->stream, e->view(), e->cfg.g,
+                           e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C.p, e->d_C4.p,
+                           e->d_flags4.p, e->d_flag.p, Vkeys, e->d_lut.p, e->d_vc.p, (uint32_t*)nullptr);
+                h_vc.resize((size_t)nb);
+                FSK_HIP(hipMemcpyAsync(h_vc.data(), e->d_vc.p, (size_t)nb * sizeof(uint16_t), hipMemcpyDeviceToHost, e->stream));
+                FSK_HIP(hipStreamSynchronize(e->stream));
+                e->st.launches += 2;
+                e->h_vc_cache = h_vc;
+                {   // running mean of the compacted key counts (stats)
+                    double sum = 0;
+                    for (uint16_t v : h_vc) sum += v;
+                    e->vc_sum += sum; e->vc_n += (double)nb;
+                    e->st.compact_keys_avg = e->vc_sum / e->vc_n;
+                }
+            } else {
+                FSK_LAUNCH(k_count, cgrid, dim3(256), lds, e->stream, e->view(), e->cfg.g,
+                           e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C.p, e->d_C4.p,
+                           e->d_flags4.p, e->d_flag.p, Vkeys, (const uint16_t*)nullptr, (const uint16_t*)nullptr, (uint32_t*)nullptr);
+            }
             e->toc(&e->st.ms_count);
             e->st.count_launches += 1;
             e->st.launches += 1;
@@ -471,7 +521,8 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
                 e->prep_overflow = (flag & 1u) != 0;
             }
             if (e->cfg.profile && !e->prep_overflow) {  // exact algorithmic update count U
-                FSK_LAUNCH(fsk::k_dense_distinct, dim3(e->Vq, nb), dim3(64), 0, e->stream, e->d_C.p, panels_pad, nb, e->Vq, e->d_U.p);
+                FSK_LAUNCH(fsk::k_dense_distinct, dim3(e->Vq, nb), dim3(64), 0, e->stream, e->d_C.p, panels_pad, nb, e->Vq, e->d_U.p,
+                           compact ? (const uint16_t*)e->d_vc.p : (const uint16_t*)nullptr);
             }
             if (nb == n) {
                 e->prep_combos.assign(combos, combos + n);
@@ -505,12 +556,22 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
         n_splits = (nb + slots_per_split - 1) / slots_per_split;
         e->tic();
         const int mixed = e->force_u8 ? 0 : 1;
-        FSK_LAUNCH(fsk::k_dense_tile, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C.p, e->d_C4.p,
-                   e->d_flags4.p, e->d_tiletab.p, mixed, nb, e->Vq, (uint32_t)e->N, K, slots_per_split);
+        if (compact)
+            FSK_LAUNCH(fsk::k_dense_tile_compact, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C.p,
+                       e->d_C4.p, e->d_flags4.p, e->d_tiletab.p, mixed, nb, e->Vq, (uint32_t)e->N, K, slots_per_split,
+                       (const uint16_t*)e->d_vc.p);
+        else
+            FSK_LAUNCH(fsk::k_dense_tile, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C.p,
+                       e->d_C4.p, e->d_flags4.p, e->d_tiletab.p, mixed, nb, e->Vq, (uint32_t)e->N, K, slots_per_split);
         e->toc(&e->st.ms_tile);
         e->st.n_tile_launches += 1;
         const uint32_t rows = mixed ? Vq8 : e->Vq;  // nominal: the u8 fallback stages are rare
-        e->st.dense_macs += n_tiles * (u64)fsk::TILE * fsk::TILE * (u64)nb * ((u64)rows * (mixed ? 8 : 4));
+        u64 row_sum = (u64)rows * (u64)nb;         // dword rows multiplied per tile
+        if (compact && (int)e->h_vc_cache.size() == nb) {
+            row_sum = 0;
+            for (uint16_t v : e->h_vc_cache) row_sum += mixed ? (v + 7u) / 8u : (v + 3u) / 4u;
+        }
+        e->st.dense_macs += n_tiles * (u64)fsk::TILE * fsk::TILE * row_sum * (mixed ? 8 : 4);
         if (mixed) e->st.u4_tile_launches += 1;
         e->st.launches += 1;
         FSK_HIP(hipGetLastError());
@@ -706,6 +767,7 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     if (e->ncomb > 0x7fffffff) { delete e; g_create_error = "C(g,m) >= 2^31 unsupported"; return FSK_EUNSUPPORTED; }
     enumerate_combos(cfg->g, e->k, e->all_pos);
     { const char* f = getenv("FSK_FORCE_U8"); e->force_u8 = f && *f == '1'; }
+    { const char* f = getenv("FSK_COMPACT"); e->force_compact = f ? atoi(f) : -1; }
     { const char* f = getenv("FSK_SPARSE_GLOBAL"); e->force_global_pairs = f ? atoi(f) : 0; }
     { const char* f = getenv("FSK_TILE_SPLITS"); e->force_splits = f ? atoi(f) : 0; }
     { const char* f = getenv("FSK_DENSE_CHUNK"); e->force_chunk = f ? (uint32_t)atoi(f) : 0u; }
@@ -726,7 +788,7 @@ void fsk_destroy(fsk_engine* e) {
     (void)hipStreamSynchronize(e->stream);
     e->d_words.release(); e->d_wstart.release(); e->d_len.release(); e->d_fstart.release(); e->d_featseq.release();
     e->d_pos.release(); e->K_store.release(); e->d_Kf64.release(); e->d_Khat.release(); e->d_prod.release();
-    e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_C.release(); e->d_C4.release(); e->d_flag.release(); e->d_flags4.release(); e->d_tiletab.release();
+    e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_C.release(); e->d_C4.release(); e->d_flag.release(); e->d_flags4.release(); e->d_tiletab.release(); e->d_keybits.release(); e->d_lut.release(); e->d_vc.release();
     for (int b = 0; b < 2; ++b) { e->d_keys[b].release(); e->d_vals[b].release(); }
     e->d_blockhist.release(); e->d_totals.release(); e->d_estart.release(); e->d_eseq.release(); e->d_erun.release();
     e->d_rstart.release(); e->d_segtot.release(); e->d_blocksum.release(); e->d_U.release();
@@ -819,6 +881,7 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
     }
     fstart[N] = fcount;
     std::vector<uint32_t> words((size_t)nwords + 4, 0u);
+    std::vector<int64_t> sym_freq(256, 0);
     {
         const int32_t base = distinct.empty() ? 0 : distinct.front();
         const bool direct = !distinct.empty() && (int64_t)distinct.back() - base < (1 << 20);
@@ -835,6 +898,7 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
                                     : (uint32_t)(std::lower_bound(distinct.begin(), distinct.end(), s[p]) - distinct.begin());
                 const uint32_t bitpos = p * (uint32_t)bits;
                 w[bitpos >> 5] |= r << (bitpos & 31u);
+                sym_freq[r]++;
             }
         }
     }
@@ -846,10 +910,17 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
     e->maxW = (uint32_t)(longest - g + 1);
     e->n_panels = (uint32_t)((N + fsk::PANEL - 1) / fsk::PANEL);
     e->h_len = len32; e->h_fstart = fstart; e->featseq_ready = false;
-    e->prep_valid = false; e->tab_n = 0;
+    e->prep_valid = false; e->tab_n = 0; e->vc_sum = 0; e->vc_n = 0;
     if (e->V > DENSE_MAX_KEYS) e->Vq = 1;  // unused on the sparse path
     int rc = choose_path(e);
     if (rc) return rc;
+    {   // key compaction pays when a symbol is rare (DNA with a few 'n'): most of the sigma^k key
+        // space is then empty and need not be multiplied
+        int64_t rarest = INT64_MAX;
+        for (uint32_t r = 0; r < sigma; ++r) rarest = std::min(rarest, sym_freq[r]);
+        e->compact = sigma >= 3 && V >= 64 && V <= 4096 && rarest * 50 < total;
+        if (e->force_compact >= 0) e->compact = e->force_compact != 0 && V <= 4096;
+    }
     FSK_HIP(e->d_words.reserve(words.size()));
     FSK_HIP(e->d_wstart.reserve((size_t)N));
     FSK_HIP(e->d_len.reserve((size_t)N));

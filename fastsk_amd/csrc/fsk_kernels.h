@@ -91,10 +91,12 @@ __device__ __forceinline__ uint32_t tile_index(uint32_t t, uint32_t e) { return 
 
 // One wave's share of the windows [j0, hi) of a staging chunk: key from K kept positions held
 // in registers (K is a template parameter so the K LDS byte reads of a window are independent
-// and issue back to back; K = 0 is the generic loop for k > 8), one LDS atomic per window.
-template <int K>
-__device__ __forceinline__ void count_windows(const uint8_t* symT, uint32_t* hist, const uint32_t (&pr)[16], int k,
-                                              uint32_t sigma, uint32_t j0, uint32_t hi, uint32_t cb, uint32_t nwin,
+// and issue back to back; K = 0 is the generic loop for k > 8). MARK: only record which keys
+// occur (bitmap pre-pass of the key compaction); else one LDS atomic per window, the key first
+// mapped through the combo's compaction table when LUT.
+template <int K, bool MARK, bool LUT>
+__device__ __forceinline__ void count_windows(const uint8_t* symT, uint32_t* hist, const uint16_t* lut, const uint32_t (&pr)[16],
+                                              int k, uint32_t sigma, uint32_t j0, uint32_t hi, uint32_t cb, uint32_t nwin,
                                               uint32_t r, uint32_t half, uint32_t key_lo, uint32_t key_n) {
     for (uint32_t j = j0; j < hi; j += 4) {
         if (j < nwin) {
@@ -107,21 +109,50 @@ __device__ __forceinline__ void count_windows(const uint8_t* symT, uint32_t* his
                 for (int c = 0; c < 16; ++c)
                     if (c < k) key = key * sigma + symT[(j - cb + pr[c]) * PANEL + r];
             }
-            key -= key_lo;  // wraps for keys below the sweep: rejected by the compare
-            if (key < key_n) atomicAdd(&hist[key * 32u + (r >> 1)], 1u << half);
+            if (MARK) {
+                atomicOr(&hist[key >> 5], 1u << (key & 31u));  // hist doubles as the key bitmap
+            } else {
+                if (LUT) key = lut[key];
+                key -= key_lo;  // wraps for keys below the sweep: rejected by the compare
+                if (key < key_n) atomicAdd(&hist[key * 32u + (r >> 1)], 1u << half);
+            }
         }
+    }
+}
+
+template <bool MARK, bool LUT>
+__device__ __forceinline__ void count_windows_k(const uint8_t* symT, uint32_t* hist, const uint16_t* lut, const uint32_t (&pr)[16],
+                                                int k, uint32_t sigma, uint32_t j0, uint32_t hi, uint32_t cb, uint32_t nwin,
+                                                uint32_t r, uint32_t half, uint32_t key_lo, uint32_t key_n) {
+    switch (k) {  // workgroup-uniform
+        case 1: count_windows<1, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n); break;
+        case 2: count_windows<2, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n); break;
+        case 3: count_windows<3, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n); break;
+        case 4: count_windows<4, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n); break;
+        case 5: count_windows<5, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n); break;
+        case 6: count_windows<6, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n); break;
+        case 7: count_windows<7, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n); break;
+        case 8: count_windows<8, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n); break;
+        default: count_windows<0, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n); break;
     }
 }
 
 // Per-sequence counting sort of the k-mers selected by each combo ("segment counts").
 // grid = (n_panels, n_chunks), block = 256 (wave w takes windows j = w mod 4; lane = sequence).
-// dynamic LDS: symT[Lmax][64] u8 | hist[4*Vq][32] u32 (two u16 counters per dword).
+// dynamic LDS: symT[CH+g-1][64] u8 | hist[4*Vcq][32] u32 (two u16 counters per dword) | lut[V] u16.
 // LDS banking: lane r touches dword (key*32 + r/2): bank depends on r only -> conflict-free for
 // any key mix; the two lanes sharing a dword add to different halves (same-address atomics).
+//
+// Key compaction (alphabets with rare symbols, e.g. DNA with a few 'n'): a first launch with
+// MARK = true only records, per combo, which of the sigma^k keys occur anywhere (keybits);
+// k_dense_keylut turns that into a rank table, and the counting launch (LUT = true) maps every
+// key through it, so panels and the tile kernel only carry the keys that exist (vc[slot] of them).
+template <bool MARK, bool LUT>
 __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, uint32_t sigma, uint32_t Vq,
                                                      uint32_t Vcq, uint32_t max_win, uint32_t CH, const uint8_t* combo_pos,
                                                      int n_slots, int slots_per_chunk, uint32_t* C, uint32_t* C4,
-                                                     uint8_t* flags4, uint32_t* overflow_flag) {
+                                                     uint8_t* flags4, uint32_t* overflow_flag, uint32_t V,
+                                                     const uint16_t* lut_g, const uint16_t* vc, uint32_t* keybits) {
     // Vcq = key quads per histogram chunk (the LDS histogram covers 4*Vcq keys at a time; key
     // spaces beyond that are counted in several sweeps over the same staged symbols).
     // CH = windows per staging chunk: symT holds CH + g - 1 symbols per sequence. CH >= max_win
@@ -131,6 +162,7 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
     uint8_t* symT = smem;
     const uint32_t sym_rows = CH + (uint32_t)g - 1u;
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (size_t)sym_rows * PANEL);
+    uint16_t* lut = reinterpret_cast<uint16_t*>(smem + (size_t)sym_rows * PANEL + (size_t)Vcq * 512);
     const int tid = threadIdx.x, r = tid & 63, w = tid >> 6;
     const uint32_t panel = blockIdx.x;
     const uint32_t seq = panel * PANEL + r;
@@ -140,19 +172,27 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
     const bool single = CH >= max_win;
     const int slot0 = blockIdx.y * slots_per_chunk;
     const int slot1 = slot0 + slots_per_chunk < n_slots ? slot0 + slots_per_chunk : n_slots;
-    const uint32_t hist_dwords = 4u * Vcq * 32u;
     const uint32_t half = (uint32_t)(r & 1) * 16u;
-    bool ovf = false, ovf4 = false;
     const uint32_t Vq8 = (Vq + 1u) >> 1;
+    const uint32_t Vw = (V + 31u) >> 5;  // words of the key bitmap
+    bool ovf = false, ovf4 = false;
     for (int slot = slot0; slot < slot1; ++slot) {
         // this combo's kept positions, once per combo, into registers (k <= 16 on this path)
         uint32_t pr[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) pr[c] = c < k ? (uint32_t)combo_pos[(size_t)slot * k + c] : 0u;
+        // rows (key quads) this combo really has: all of them, or the compacted count
+        const uint32_t Vq_s = LUT ? ((uint32_t)vc[slot] + 3u) >> 2 : Vq;
+        if (LUT) {
+            __syncthreads();  // previous combo's table no longer read
+            for (uint32_t i = tid; i < V; i += 256) lut[i] = lut_g[(size_t)slot * V + i];
+        }
         uint32_t* out = C + ((size_t)panel * n_slots + slot) * ((size_t)Vq * PANEL);
         uint32_t* out4 = C4 + ((size_t)panel * n_slots + slot) * ((size_t)Vq8 * PANEL);
-        for (uint32_t kc0 = 0; kc0 < Vq; kc0 += Vcq) {  // key-space sweep
-            const uint32_t key_lo = 4u * kc0, key_n = 4u * (kc0 + Vcq < Vq ? Vcq : Vq - kc0);
+        const uint32_t sweep_end = MARK ? 1u : Vq_s;
+        for (uint32_t kc0 = 0; kc0 < sweep_end; kc0 += Vcq) {  // key-space sweep
+            const uint32_t key_lo = 4u * kc0, key_n = 4u * (kc0 + Vcq < Vq_s ? Vcq : Vq_s - kc0);
+            const uint32_t hist_dwords = MARK ? Vw : 4u * Vcq * 32u;
             __syncthreads();  // previous read-out finished
             for (uint32_t i = tid; i < hist_dwords; i += 256) hist[i] = 0u;
             for (uint32_t cb = 0; cb < max_win; cb += CH) {
@@ -161,22 +201,16 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
                     for (uint32_t p = w; p < sym_rows; p += 4)
                         symT[p * PANEL + r] = cb + p < len ? (uint8_t)fetch_sym(S.words, wbase, cb + p, S.bits) : (uint8_t)0;
                 }
-                __syncthreads();  // symbols staged, histogram zeroed
+                __syncthreads();  // symbols staged, histogram zeroed, table loaded
                 const uint32_t hi = cb + CH < max_win ? cb + CH : max_win;
-                const uint32_t j0 = cb + (uint32_t)w, rr = (uint32_t)r;
-                switch (k) {  // workgroup-uniform
-                    case 1: count_windows<1>(symT, hist, pr, k, sigma, j0, hi, cb, nwin, rr, half, key_lo, key_n); break;
-                    case 2: count_windows<2>(symT, hist, pr, k, sigma, j0, hi, cb, nwin, rr, half, key_lo, key_n); break;
-                    case 3: count_windows<3>(symT, hist, pr, k, sigma, j0, hi, cb, nwin, rr, half, key_lo, key_n); break;
-                    case 4: count_windows<4>(symT, hist, pr, k, sigma, j0, hi, cb, nwin, rr, half, key_lo, key_n); break;
-                    case 5: count_windows<5>(symT, hist, pr, k, sigma, j0, hi, cb, nwin, rr, half, key_lo, key_n); break;
-                    case 6: count_windows<6>(symT, hist, pr, k, sigma, j0, hi, cb, nwin, rr, half, key_lo, key_n); break;
-                    case 7: count_windows<7>(symT, hist, pr, k, sigma, j0, hi, cb, nwin, rr, half, key_lo, key_n); break;
-                    case 8: count_windows<8>(symT, hist, pr, k, sigma, j0, hi, cb, nwin, rr, half, key_lo, key_n); break;
-                    default: count_windows<0>(symT, hist, pr, k, sigma, j0, hi, cb, nwin, rr, half, key_lo, key_n); break;
-                }
+                count_windows_k<MARK, LUT>(symT, hist, lut, pr, k, sigma, cb + (uint32_t)w, hi, cb, nwin, (uint32_t)r, half, key_lo, key_n);
             }
             __syncthreads();
+            if (MARK) {  // merge this panel's key bitmap into the combo's
+                for (uint32_t i = tid; i < Vw; i += 256)
+                    if (hist[i]) atomicOr(&keybits[(size_t)slot * Vw + i], hist[i]);
+                continue;
+            }
             const uint32_t nq = key_n >> 2;  // key quads in this sweep
             for (uint32_t kq = w; kq < nq; kq += 4) {
                 uint32_t packed = 0;
@@ -206,18 +240,38 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
         }
         // a count above 15: this (panel, combo) must be consumed in its u8 form (all writers
         // store the same value; the array is zeroed before the launch)
-        if (ovf4) flags4[(size_t)panel * n_slots + slot] = 1;
+        if (!MARK && ovf4) flags4[(size_t)panel * n_slots + slot] = 1;
         ovf4 = false;
     }
-    if (ovf) atomicOr(overflow_flag, 1u);
+    if (!MARK && ovf) atomicOr(overflow_flag, 1u);
+}
+
+// Key compaction table of one combo: rank of every key that occurs, 0xFFFF otherwise; vc = how
+// many occur. grid = n_slots, block = 256. V <= 8192 (256 bitmap words).
+__global__ __launch_bounds__(256) void k_dense_keylut(const uint32_t* keybits, uint32_t V, uint16_t* lut_g, uint16_t* vc) {
+    __shared__ uint32_t tmp[4];
+    const uint32_t slot = blockIdx.x, tid = threadIdx.x;
+    const uint32_t Vw = (V + 31u) >> 5;
+    const uint32_t word = tid < Vw ? keybits[(size_t)slot * Vw + tid] : 0u;
+    uint32_t tot;
+    uint32_t rank = block_excl_scan_256<uint32_t>((uint32_t)__popc(word), tmp, &tot);
+    if (tid < Vw) {
+        for (uint32_t b = 0; b < 32u; ++b) {
+            const uint32_t key = tid * 32u + b;
+            if (key < V) lut_g[(size_t)slot * V + key] = (word >> b) & 1u ? (uint16_t)rank++ : (uint16_t)0xffff;
+        }
+    }
+    if (tid == 0) vc[slot] = (uint16_t)tot;
 }
 
 // U = sum over (combo, key) of d(d+1)/2, d = number of sequences in which the key occurs: the
 // number of `+=` the reference's countAndUpdateTri issues (shared.cpp:316-327), i.e. the
 // algorithmic update count the roofline is priced on. Read straight off the count
 // panels; profiling aid only. grid = (Vq, n_slots), block = 64 (lane = sequence within panel).
-__global__ __launch_bounds__(64) void k_dense_distinct(const uint32_t* C, uint32_t n_panels, int n_slots, uint32_t Vq, u64* U) {
+__global__ __launch_bounds__(64) void k_dense_distinct(const uint32_t* C, uint32_t n_panels, int n_slots, uint32_t Vq, u64* U,
+                                                       const uint16_t* vc) {
     const uint32_t kq = blockIdx.x, slot = blockIdx.y, r = threadIdx.x;
+    if (vc && kq >= ((uint32_t)vc[slot] + 3u) >> 2) return;  // rows beyond the compacted keys are not written
     uint32_t d[4] = {0u, 0u, 0u, 0u};
     for (uint32_t p = 0; p < n_panels; ++p) {
         const uint32_t v = C[((size_t)p * n_slots + slot) * ((size_t)Vq * PANEL) + (size_t)kq * PANEL + r];
@@ -250,140 +304,16 @@ __global__ __launch_bounds__(64) void k_dense_distinct(const uint32_t* C, uint32
 // blockIdx.x -> tile through a host-built table (tile_tab[b] = ti << 16 | tj): the order is
 // XCD-aware (blocks b, b+8, b+16, ... share an XCD and walk 8x8 super-tiles, so the ~64
 // workgroups resident on one XCD stream 8+8 panel pairs out of its L2 instead of 1+64).
-__global__ __launch_bounds__(256, 2) void k_dense_tile(const uint32_t* C8, const uint32_t* C4, const uint8_t* flags4,
-                                                       const uint32_t* tile_tab, int mixed, int n_slots, uint32_t Vq,
-                                                       uint32_t N, u64* K, int slots_per_split) {
-    __shared__ __attribute__((aligned(16))) uint32_t As[STAGE_KQ * TILE];
-    __shared__ __attribute__((aligned(16))) uint32_t Bs[STAGE_KQ * TILE];
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    const uint32_t tile = tile_tab[blockIdx.x];
-    const uint32_t ti = tile >> 16, tj = tile & 0xffffu;
-    const int s0 = blockIdx.y * slots_per_split;
-    const int s1 = s0 + slots_per_split < n_slots ? s0 + slots_per_split : n_slots;
-    if (s0 >= s1) return;
-    const uint32_t Vq8 = (Vq + 1u) >> 1;
-
-    uint32_t acc[8][8];
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) acc[a][b] = 0u;
-
-    // a stage = up to STAGE_KQ dword-rows of one combo's panels, in one encoding. Which encoding
-    // a combo takes for THIS tile (OR of the four panels' "count above 15" bytes) is worked out
-    // for FLAG_SLOTS combos at a time into LDS, so the stage loop never waits on a global flag.
-    constexpr int FLAG_SLOTS = 2048;
-    __shared__ uint8_t sflag[FLAG_SLOTS];
-    uint4 pre[8];
-    auto load_stage = [&](int slot, uint32_t kq0, bool u4) {
-        const uint32_t rows = u4 ? Vq8 : Vq;
-        const uint32_t* C = u4 ? C4 : C8;
-        const size_t slot_stride = (size_t)rows * PANEL;
-        const size_t panel_stride = (size_t)n_slots * slot_stride;
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const uint32_t idx = (uint32_t)it * 256u + (uint32_t)tid;  // [0,2048) uint4s
-            const uint32_t which = idx >> 9;                            // A0 A1 B0 B1
-            const uint32_t within = idx & 511u;
-            const uint32_t kq = within >> 4, r4 = within & 15u;
-            const uint32_t panel = (which < 2 ? ti : tj) * 2u + (which & 1u);
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (kq0 + kq < rows) {
-                const uint32_t* src = C + panel * panel_stride + (size_t)slot * slot_stride + (size_t)(kq0 + kq) * PANEL + r4 * 4u;
-                v = *reinterpret_cast<const uint4*>(src);
-            }
-            pre[it] = v;
-        }
-    };
-    auto store_stage = [&]() {
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const uint32_t idx = (uint32_t)it * 256u + (uint32_t)tid;
-            const uint32_t which = idx >> 9;
-            const uint32_t within = idx & 511u;
-            const uint32_t kq = within >> 4, r4 = within & 15u;
-            uint32_t* dst = (which < 2 ? As : Bs) + kq * TILE + (which & 1u) * PANEL + r4 * 4u;
-            *reinterpret_cast<uint4*>(dst) = pre[it];
-        }
-    };
-
-    for (int c0 = s0; c0 < s1; c0 += FLAG_SLOTS) {
-    const int c1 = c0 + FLAG_SLOTS < s1 ? c0 + FLAG_SLOTS : s1;
-    __syncthreads();  // the previous chunk's flags are no longer read
-    for (int sl = c0 + tid; sl < c1; sl += 256) {
-        const size_t a = (size_t)(ti * 2u) * n_slots + sl, b = (size_t)(tj * 2u) * n_slots + sl;
-        sflag[sl - c0] = mixed ? (uint8_t)(flags4[a] | flags4[a + n_slots] | flags4[b] | flags4[b + n_slots]) : (uint8_t)1;
-    }
-    __syncthreads();
-    int slot = c0;
-    uint32_t kq0 = 0;
-    bool u4 = sflag[0] == 0;
-    load_stage(slot, kq0, u4);
-    while (slot < c1) {
-        __syncthreads();  // everyone finished reading the previous stage
-        store_stage();
-        __syncthreads();
-        // next stage: the rest of this combo's rows, else the next combo
-        int nslot = slot;
-        uint32_t nkq0 = kq0 + STAGE_KQ;
-        bool nu4 = u4;
-        if (nkq0 >= (u4 ? Vq8 : Vq)) {
-            nslot = slot + 1;
-            nkq0 = 0;
-            nu4 = nslot < c1 ? sflag[nslot - c0] == 0 : false;
-        }
-        if (nslot < c1) load_stage(nslot, nkq0, nu4);  // in flight under the dot products
-        // rows of this stage that hold keys (the last stage of a combo may be partial)
-        const uint32_t rows_left = (u4 ? Vq8 : Vq) - kq0;
-        const int nkq = rows_left < (uint32_t)STAGE_KQ ? (int)rows_left : STAGE_KQ;
-        if (u4) {
-#pragma unroll 4
-            for (int kq = 0; kq < nkq; ++kq) {
-                const uint4 a0 = *reinterpret_cast<const uint4*>(&As[kq * TILE + ty * 4]);
-                const uint4 a1 = *reinterpret_cast<const uint4*>(&As[kq * TILE + PANEL + ty * 4]);
-                const uint4 b0 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + tx * 4]);
-                const uint4 b1 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + PANEL + tx * 4]);
-                const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                const uint32_t bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-                for (int a = 0; a < 8; ++a)
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) acc[a][b] = __builtin_amdgcn_udot8(av[a], bv[b], acc[a][b], false);
-            }
-        } else {
-#pragma unroll 2
-            for (int kq = 0; kq < nkq; ++kq) {
-                const uint4 a0 = *reinterpret_cast<const uint4*>(&As[kq * TILE + ty * 4]);
-                const uint4 a1 = *reinterpret_cast<const uint4*>(&As[kq * TILE + PANEL + ty * 4]);
-                const uint4 b0 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + tx * 4]);
-                const uint4 b1 = *reinterpret_cast<const uint4*>(&Bs[kq * TILE + PANEL + tx * 4]);
-                const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                const uint32_t bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-                for (int a = 0; a < 8; ++a)
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) acc[a][b] = __builtin_amdgcn_udot4(av[a], bv[b], acc[a][b], false);
-            }
-        }
-        slot = nslot;
-        kq0 = nkq0;
-        u4 = nu4;
-    }
-    }
-    // flush: one 64-bit atomicAdd per cell of the lower triangle. For a fixed register (a, b) the
-    // 16 lanes of a row group hold 16 consecutive columns (tile_index), so a wave's atomic
-    // instruction covers four rows x 128 contiguous bytes.
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        const u64 i = (u64)ti * TILE + tile_index((uint32_t)ty, (uint32_t)a);
-        if (i >= N) continue;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const u64 j = (u64)tj * TILE + tile_index((uint32_t)tx, (uint32_t)b);
-            if (j <= i && acc[a][b] != 0u) atomicAdd(&K[tri_index(i, j)], (u64)acc[a][b]);
-        }
-    }
-}
+#define FSK_TILE_KERNEL k_dense_tile
+#define FSK_TILE_COMPACT 0
+#include "fsk_tile_kernel.inc"
+#undef FSK_TILE_KERNEL
+#undef FSK_TILE_COMPACT
+#define FSK_TILE_KERNEL k_dense_tile_compact
+#define FSK_TILE_COMPACT 1
+#include "fsk_tile_kernel.inc"
+#undef FSK_TILE_KERNEL
+#undef FSK_TILE_COMPACT
 
 // =============================================================================================
 // SPARSE PATH

@@ -94,7 +94,8 @@ typedef struct fsk_stats {
     double u4_tile_launches; /* tile launches that used the 4-bit panels / v_dot8_u32_u4       */
     double max_windows;      /* max over sequences of (length - g + 1): bounds a cell per combo  */
     double count_launches;   /* launches of the segment-count kernel (panel cache misses)        */
-    double reserved[3];
+    double compact_keys_avg; /* key compaction on: mean keys per combo that really occur (else 0) */
+    double reserved[2];
 } fsk_stats;
 
 /* ---- lifecycle: replaces FastSK::FastSK (fastsk.cpp:19-28) and ~nothing (the reference leaks) */

@@ -13,7 +13,7 @@ OUT = os.path.join(HERE, "libfastsk_emu.so")
 
 def build(force=False):
     deps = [SRC, os.path.join(HERE, "hip_emu.h"), os.path.join(ROOT, "include", "fastsk_amd.h")]
-    deps += [os.path.join(ROOT, "fastsk_amd", "csrc", f) for f in ("fsk_kernels.h", "fsk_platform.h")]
+    deps += [os.path.join(ROOT, "fastsk_amd", "csrc", f) for f in ("fsk_kernels.h", "fsk_tile_kernel.inc", "fsk_platform.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     cmd = ["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-DFSK_EMU", "-ffp-contract=off",

@@ -274,3 +274,30 @@ def test_emu_sparse_pair_accumulation_variants(emu_lib, port, monkeypatch, globa
     e.finalize()
     assert np.array_equal(e.get_counts(), want)
     assert e.stats()["cell_updates"] == U
+
+
+@pytest.mark.parametrize("g,m,force", [(8, 4, None), (9, 4, None), (8, 4, "1"), (7, 5, "1")])
+def test_emu_key_compaction_rare_symbol(emu_lib, port, monkeypatch, g, m, force):
+    """DNA with a few 'n': the 5^k key space is mostly empty; the dense dataflow counts only the
+    keys that occur (per-combo rank table) and must still match the oracle bit for bit."""
+    from fastsk_amd import _native
+    if force is not None:
+        monkeypatch.setenv("FSK_COMPACT", force)
+    rng = np.random.default_rng(g * 7 + m)
+    X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(g, 80, size=150)]
+    for i in (3, 70, 149):
+        X[i][len(X[i]) // 2] = 5        # a single 'n'
+    X[10][:6] = 5                        # a short run of 'n'
+    X[20][:] = 1                         # low complexity: exercises the u8 fallback with compaction
+    tok, off = _native.flatten(X)
+    nc = port.num_combos(g, m)
+    combos = np.unique(np.linspace(0, nc - 1, 7).astype(np.int32))
+    want, _, _ = port.raw_counts(tok, off, g, m, combos, threads=4)
+    e = _native.Engine(g, m, path=1, lib=emu_lib, profile=True)
+    e.load_sequences(tok, off, 100, 50)
+    e.accumulate(combos[:3])
+    e.accumulate(combos[3:])
+    e.finalize()
+    assert np.array_equal(e.get_counts(), want)
+    st = e.stats()
+    assert st["key_space"] == 5 ** (g - m) and st["compact_keys_avg"] > 0 and st["compact_keys_avg"] < st["key_space"]

@@ -365,3 +365,32 @@ def test_sparse_pair_accumulation_variants(native, port, monkeypatch, global_pai
     e.finalize()
     assert np.array_equal(e.get_counts(), want)
     e.close()
+
+
+@pytest.mark.parametrize("force", [None, "0", "1"])
+def test_key_compaction_rare_symbol(native, port, monkeypatch, force):
+    """DNA with a few 'n' (config-3-like): key compaction on (auto / forced) and off give the
+    oracle's counts; with compaction the tile kernel multiplies far fewer keys than 5^4."""
+    if force is not None:
+        monkeypatch.setenv("FSK_COMPACT", force)
+    rng = np.random.default_rng(77)
+    N, L = 1100, 160
+    X = rng.integers(1, 5, size=(N, L), dtype=np.int32)
+    for i in rng.choice(N, size=40, replace=False):
+        X[i, rng.integers(0, L, size=3)] = 5
+    X[5, :30] = 5
+    X[9, :] = 3
+    tokens, offsets = native.flatten(X)
+    combos = np.arange(0, 210, 9, dtype=np.int32)
+    want, _, _ = port.raw_counts(tokens, offsets, 10, 6, combos, threads=8)
+    e = native.Engine(10, 6, path=1)
+    e.load_sequences(tokens, offsets, 800, 300)
+    e.accumulate(combos)
+    e.finalize()
+    assert np.array_equal(e.get_counts(), want)
+    st = e.stats()
+    if force == "0":
+        assert st["compact_keys_avg"] == 0
+    else:
+        assert 256 <= st["compact_keys_avg"] < 625
+    e.close()
