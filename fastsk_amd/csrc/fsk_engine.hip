@@ -74,7 +74,6 @@ struct fsk_engine {
     DevBuf<uint32_t> d_words, d_wstart, d_len, d_fstart, d_featseq;
     std::vector<uint32_t> h_len, h_fstart;
     bool featseq_ready = false;
-    bool force_u8 = false;  // FSK_FORCE_U8=1: keep the dot4/u8 tile kernel (testing)
     int force_splits = 0;      // FSK_TILE_SPLITS=n: combo splits per tile (tuning)
     uint32_t force_chunk = 0;  // FSK_DENSE_CHUNK=n: cap the count kernel's staging chunk (testing)
 
@@ -95,8 +94,7 @@ struct fsk_engine {
     DevBuf<u64> d_stage_u64;
 
     // dense scratch
-    DevBuf<uint32_t> d_C, d_C4, d_flag;
-    DevBuf<uint8_t> d_flags4;
+    DevBuf<uint32_t> d_C4, d_C4H, d_rowmask, d_flag;  // lo / hi nibble planes, per-row hi masks
     DevBuf<uint32_t> d_keybits;   // key compaction: per-combo bitmap of the keys that occur
     DevBuf<uint16_t> d_lut, d_vc; //                  rank table and key count per combo
     bool compact = false;         // decided at load: the alphabet has a rare symbol
@@ -403,27 +401,27 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
     if (t1 > 0xffffu) return e->fail(FSK_EUNSUPPORTED, "more than 65535 tile rows");
     const u64 n_tiles = (u64)t1 * (t1 + 1) / 2 - (u64)t0 * (t0 + 1) / 2;
     if (n_tiles == 0) return FSK_OK;
-    const uint32_t Vq8 = (e->Vq + 1u) / 2u;                               // dwords of 4-bit counts
-    const size_t slot_dwords = (size_t)panels_pad * e->Vq * fsk::PANEL;   // u8 panel dwords per combo
-    const size_t slot_dwords4 = (size_t)panels_pad * Vq8 * fsk::PANEL;    // u4 panel dwords per combo
+    const uint32_t Vq8 = (e->Vq + 1u) / 2u;                               // dword rows: 8 keys (nibbles) each
+    const uint32_t nst = (Vq8 + fsk::STAGE_KQ - 1) / fsk::STAGE_KQ;      // 32-row stages per combo
+    const size_t slot_dwords4 = (size_t)panels_pad * Vq8 * fsk::PANEL;    // dwords of one plane per combo
     // combos per launch: u32 accumulators must not wrap (per cell and combo <= maxW^2), and the
-    // count panels must fit in the memory we are willing to take
+    // count panels (lo + hi plane) must fit in the memory we are willing to take
     const u64 w2 = std::max<u64>(1, (u64)e->maxW * e->maxW);
     u64 by_overflow = 0xffffffffull / w2;
     if (by_overflow == 0) return e->fail(FSK_EUNSUPPORTED, "sequence too long for the dense path");
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    size_t have = (e->d_C.cap + e->d_C4.cap) * sizeof(uint32_t);
+    size_t have = (e->d_C4.cap + e->d_C4H.cap) * sizeof(uint32_t);
     // panels for a few thousand combos per launch are plenty (one more launch costs one more
     // flush per tile); larger allocations only cost hipMalloc time
     size_t budget = std::max<size_t>(have, std::min<size_t>((size_t)((double)(free_b + have) * 0.6), (size_t)32 << 30));
-    u64 by_memory = std::max<u64>(1, budget / ((slot_dwords + slot_dwords4) * sizeof(uint32_t)));
+    u64 by_memory = std::max<u64>(1, budget / (2 * slot_dwords4 * sizeof(uint32_t)));
     // (32768 combos per launch also keeps grid.y of the count and tile launches within limits)
     const int chunk = (int)std::max<u64>(1, std::min<u64>({(u64)n, by_overflow, by_memory, (u64)32768}));
-    FSK_HIP(e->d_C.reserve(slot_dwords * (size_t)chunk));
     FSK_HIP(e->d_C4.reserve(slot_dwords4 * (size_t)chunk));
+    FSK_HIP(e->d_C4H.reserve(slot_dwords4 * (size_t)chunk));
+    FSK_HIP(e->d_rowmask.reserve((size_t)panels_pad * chunk * nst));
     FSK_HIP(e->d_flag.reserve(2));
-    FSK_HIP(e->d_flags4.reserve((size_t)panels_pad * chunk));
     FSK_HIP(e->d_pos.reserve((size_t)chunk * e->k));
     if (e->tab_t0 != t0 || e->tab_t1 != t1 || e->tab_n == 0) {
         std::vector<uint32_t> tab;
@@ -471,7 +469,6 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
                 memcpy(&pos[(size_t)q * e->k], &e->all_pos[(size_t)combos[s + q] * e->k], e->k);
             FSK_HIP(hipMemcpyAsync(e->d_pos.p, pos.data(), pos.size(), hipMemcpyHostToDevice, e->stream));
             FSK_HIP(hipMemsetAsync(e->d_flag.p, 0, sizeof(uint32_t), e->stream));
-            FSK_HIP(hipMemsetAsync(e->d_flags4.p, 0, (size_t)panels_pad * nb, e->stream));
             FSK_HIP(hipStreamSynchronize(e->stream));  // `pos` is a pageable temporary
             // ---- segment counts
             const int slots_per_chunk = std::max(1, std::min(nb, 16));
@@ -485,12 +482,12 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
             if (compact) {  // which keys occur per combo -> rank tables -> compacted panels
                 FSK_HIP(hipMemsetAsync(e->d_keybits.p, 0, (size_t)nb * Vw * sizeof(uint32_t), e->stream));
                 FSK_LAUNCH(k_mark, cgrid, dim3(256), lds, e->stream, e->view(), e->cfg.g,
-                           e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C.p, e->d_C4.p,
-                           e->d_flags4.p, e->d_flag.p, Vkeys, (const uint16_t*)nullptr, (const uint16_t*)nullptr, e->d_keybits.p);
+                           e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C4.p, e->d_C4H.p,
+                           e->d_rowmask.p, nst, e->d_flag.p, Vkeys, (const uint16_t*)nullptr, (const uint16_t*)nullptr, e->d_keybits.p);
                 FSK_LAUNCH(fsk::k_dense_keylut, dim3(nb), dim3(256), 0, e->stream, e->d_keybits.p, Vkeys, e->d_lut.p, e->d_vc.p);
                 FSK_LAUNCH(k_count_lut, cgrid, dim3(256), lds, e->stream, e->view(), e->cfg.g,
-                           e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C.p, e->d_C4.p,
-                           e->d_flags4.p, e->d_flag.p, Vkeys, e->d_lut.p, e->d_vc.p, (uint32_t*)nullptr);
+                           e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C4.p, e->d_C4H.p,
+                           e->d_rowmask.p, nst, e->d_flag.p, Vkeys, e->d_lut.p, e->d_vc.p, (uint32_t*)nullptr);
                 h_vc.resize((size_t)nb);
                 FSK_HIP(hipMemcpyAsync(h_vc.data(), e->d_vc.p, (size_t)nb * sizeof(uint16_t), hipMemcpyDeviceToHost, e->stream));
                 FSK_HIP(hipStreamSynchronize(e->stream));
@@ -504,13 +501,13 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
                 }
             } else {
                 FSK_LAUNCH(k_count, cgrid, dim3(256), lds, e->stream, e->view(), e->cfg.g,
-                           e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C.p, e->d_C4.p,
-                           e->d_flags4.p, e->d_flag.p, Vkeys, (const uint16_t*)nullptr, (const uint16_t*)nullptr, (uint32_t*)nullptr);
+                           e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C4.p, e->d_C4H.p,
+                           e->d_rowmask.p, nst, e->d_flag.p, Vkeys, (const uint16_t*)nullptr, (const uint16_t*)nullptr, (uint32_t*)nullptr);
             }
             e->toc(&e->st.ms_count);
             e->st.count_launches += 1;
             e->st.launches += 1;
-            e->st.panel_bytes += (slot_dwords + slot_dwords4) * sizeof(uint32_t) * (u64)nb;
+            e->st.panel_bytes += 2 * slot_dwords4 * sizeof(uint32_t) * (u64)nb;
             // a count above 255 does not fit the u8 panels either: take the general dataflow
             // for this batch (only possible when a sequence has more than 255 windows)
             e->prep_overflow = false;
@@ -521,7 +518,7 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
                 e->prep_overflow = (flag & 1u) != 0;
             }
             if (e->cfg.profile && !e->prep_overflow) {  // exact algorithmic update count U
-                FSK_LAUNCH(fsk::k_dense_distinct, dim3(e->Vq, nb), dim3(64), 0, e->stream, e->d_C.p, panels_pad, nb, e->Vq, e->d_U.p,
+                FSK_LAUNCH(fsk::k_dense_distinct, dim3(Vq8, nb), dim3(64), 0, e->stream, e->d_C4.p, e->d_C4H.p, panels_pad, nb, Vq8, e->d_U.p,
                            compact ? (const uint16_t*)e->d_vc.p : (const uint16_t*)nullptr);
             }
             if (nb == n) {
@@ -555,24 +552,22 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
         const int slots_per_split = (nb + n_splits - 1) / n_splits;
         n_splits = (nb + slots_per_split - 1) / slots_per_split;
         e->tic();
-        const int mixed = e->force_u8 ? 0 : 1;
         if (compact)
-            FSK_LAUNCH(fsk::k_dense_tile_compact, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C.p,
-                       e->d_C4.p, e->d_flags4.p, e->d_tiletab.p, mixed, nb, e->Vq, (uint32_t)e->N, K, slots_per_split,
+            FSK_LAUNCH(fsk::k_dense_tile_compact, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C4.p,
+                       e->d_C4H.p, e->d_rowmask.p, e->d_tiletab.p, nb, Vq8, nst, (uint32_t)e->N, K, slots_per_split,
                        (const uint16_t*)e->d_vc.p);
         else
-            FSK_LAUNCH(fsk::k_dense_tile, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C.p,
-                       e->d_C4.p, e->d_flags4.p, e->d_tiletab.p, mixed, nb, e->Vq, (uint32_t)e->N, K, slots_per_split);
+            FSK_LAUNCH(fsk::k_dense_tile, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C4.p, e->d_C4H.p,
+                       e->d_rowmask.p, e->d_tiletab.p, nb, Vq8, nst, (uint32_t)e->N, K, slots_per_split);
         e->toc(&e->st.ms_tile);
         e->st.n_tile_launches += 1;
-        const uint32_t rows = mixed ? Vq8 : e->Vq;  // nominal: the u8 fallback stages are rare
-        u64 row_sum = (u64)rows * (u64)nb;         // dword rows multiplied per tile
+        u64 row_sum = (u64)Vq8 * (u64)nb;  // dword rows multiplied per tile (flagged-row remainders not counted)
         if (compact && (int)e->h_vc_cache.size() == nb) {
             row_sum = 0;
-            for (uint16_t v : e->h_vc_cache) row_sum += mixed ? (v + 7u) / 8u : (v + 3u) / 4u;
+            for (uint16_t v : e->h_vc_cache) row_sum += (v + 7u) / 8u;
         }
-        e->st.dense_macs += n_tiles * (u64)fsk::TILE * fsk::TILE * row_sum * (mixed ? 8 : 4);
-        if (mixed) e->st.u4_tile_launches += 1;
+        e->st.dense_macs += n_tiles * (u64)fsk::TILE * fsk::TILE * row_sum * 8;
+        e->st.u4_tile_launches += 1;
         e->st.launches += 1;
         FSK_HIP(hipGetLastError());
     }
@@ -766,7 +761,6 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     e->ncomb = n_choose_k(cfg->g, cfg->m);
     if (e->ncomb > 0x7fffffff) { delete e; g_create_error = "C(g,m) >= 2^31 unsupported"; return FSK_EUNSUPPORTED; }
     enumerate_combos(cfg->g, e->k, e->all_pos);
-    { const char* f = getenv("FSK_FORCE_U8"); e->force_u8 = f && *f == '1'; }
     { const char* f = getenv("FSK_COMPACT"); e->force_compact = f ? atoi(f) : -1; }
     { const char* f = getenv("FSK_SPARSE_GLOBAL"); e->force_global_pairs = f ? atoi(f) : 0; }
     { const char* f = getenv("FSK_TILE_SPLITS"); e->force_splits = f ? atoi(f) : 0; }
@@ -788,7 +782,7 @@ void fsk_destroy(fsk_engine* e) {
     (void)hipStreamSynchronize(e->stream);
     e->d_words.release(); e->d_wstart.release(); e->d_len.release(); e->d_fstart.release(); e->d_featseq.release();
     e->d_pos.release(); e->K_store.release(); e->d_Kf64.release(); e->d_Khat.release(); e->d_prod.release();
-    e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_C.release(); e->d_C4.release(); e->d_flag.release(); e->d_flags4.release(); e->d_tiletab.release(); e->d_keybits.release(); e->d_lut.release(); e->d_vc.release();
+    e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_C4.release(); e->d_C4H.release(); e->d_rowmask.release(); e->d_flag.release(); e->d_tiletab.release(); e->d_keybits.release(); e->d_lut.release(); e->d_vc.release();
     for (int b = 0; b < 2; ++b) { e->d_keys[b].release(); e->d_vals[b].release(); }
     e->d_blockhist.release(); e->d_totals.release(); e->d_estart.release(); e->d_eseq.release(); e->d_erun.release();
     e->d_rstart.release(); e->d_segtot.release(); e->d_blocksum.release(); e->d_U.release();

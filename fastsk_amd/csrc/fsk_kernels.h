@@ -150,9 +150,15 @@ __device__ __forceinline__ void count_windows_k(const uint8_t* symT, uint32_t* h
 template <bool MARK, bool LUT>
 __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, uint32_t sigma, uint32_t Vq,
                                                      uint32_t Vcq, uint32_t max_win, uint32_t CH, const uint8_t* combo_pos,
-                                                     int n_slots, int slots_per_chunk, uint32_t* C, uint32_t* C4,
-                                                     uint8_t* flags4, uint32_t* overflow_flag, uint32_t V,
+                                                     int n_slots, int slots_per_chunk, uint32_t* C4, uint32_t* C4H,
+                                                     uint32_t* rowmask, uint32_t nst, uint32_t* overflow_flag, uint32_t V,
                                                      const uint16_t* lut_g, const uint16_t* vc, uint32_t* keybits) {
+    // Counts leave as two 4-bit planes, count = lo + 16 * hi (8 keys per dword): C4 holds lo and
+    // is all the tile kernel multiplies for almost every key; C4H holds hi, zero unless a k-mer
+    // occurs more than 15 times in one sequence (poly-A, runs of 'n'); rowmask[panel][slot][..]
+    // has one bit per dword row saying whether any of the panel's 64 sequences has hi != 0 there.
+    // Counts above 255 raise overflow_flag (the host then takes the sparse dataflow).
+    __shared__ uint32_t srowmask[64];
     // Vcq = key quads per histogram chunk (the LDS histogram covers 4*Vcq keys at a time; key
     // spaces beyond that are counted in several sweeps over the same staged symbols).
     // CH = windows per staging chunk: symT holds CH + g - 1 symbols per sequence. CH >= max_win
@@ -175,8 +181,12 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
     const uint32_t half = (uint32_t)(r & 1) * 16u;
     const uint32_t Vq8 = (Vq + 1u) >> 1;
     const uint32_t Vw = (V + 31u) >> 5;  // words of the key bitmap
-    bool ovf = false, ovf4 = false;
+    bool ovf = false;
     for (int slot = slot0; slot < slot1; ++slot) {
+        if (!MARK) {
+            __syncthreads();  // previous combo's mask written out
+            if (tid < 64) srowmask[tid] = 0u;
+        }
         // this combo's kept positions, once per combo, into registers (k <= 16 on this path)
         uint32_t pr[16];
 #pragma unroll
@@ -187,8 +197,8 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
             __syncthreads();  // previous combo's table no longer read
             for (uint32_t i = tid; i < V; i += 256) lut[i] = lut_g[(size_t)slot * V + i];
         }
-        uint32_t* out = C + ((size_t)panel * n_slots + slot) * ((size_t)Vq * PANEL);
         uint32_t* out4 = C4 + ((size_t)panel * n_slots + slot) * ((size_t)Vq8 * PANEL);
+        uint32_t* out4h = C4H + ((size_t)panel * n_slots + slot) * ((size_t)Vq8 * PANEL);
         const uint32_t sweep_end = MARK ? 1u : Vq_s;
         for (uint32_t kc0 = 0; kc0 < sweep_end; kc0 += Vcq) {  // key-space sweep
             const uint32_t key_lo = 4u * kc0, key_n = 4u * (kc0 + Vcq < Vq_s ? Vcq : Vq_s - kc0);
@@ -211,37 +221,29 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
                     if (hist[i]) atomicOr(&keybits[(size_t)slot * Vw + i], hist[i]);
                 continue;
             }
-            const uint32_t nq = key_n >> 2;  // key quads in this sweep
-            for (uint32_t kq = w; kq < nq; kq += 4) {
-                uint32_t packed = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    uint32_t c = (hist[(4u * kq + q) * 32u + (uint32_t)(r >> 1)] >> half) & 0xffffu;
-                    ovf |= c > 255u;
-                    packed |= (c & 255u) << (8 * q);
-                }
-                out[(size_t)(kc0 + kq) * PANEL + panel_slot(r)] = packed;  // one 256-B row per wave
-            }
-            // the same counts as 4-bit fields (8 keys per dword) for the v_dot8_u32_u4 tile
-            // kernel; valid unless flags4 says a count of this (panel, combo) exceeded 15
-            // (Vcq is even, so a sweep starts on an 8-key boundary)
-            const uint32_t n8 = (nq + 1u) >> 1;
+            // read-out: 8 keys per dword row, lo and hi nibbles (Vcq is even, so a sweep starts on
+            // an 8-key boundary); one 256-B row per wave and plane
+            const uint32_t n8 = ((key_n >> 2) + 1u) >> 1;
             for (uint32_t k8 = w; k8 < n8; k8 += 4) {
-                uint32_t packed = 0;
+                uint32_t plo = 0, phi = 0;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const uint32_t key = 8u * k8 + q;
-                    uint32_t c = key < key_n ? (hist[key * 32u + (uint32_t)(r >> 1)] >> half) & 0xffffu : 0u;
-                    ovf4 |= c > 15u;
-                    packed |= (c & 15u) << (4 * q);
+                    const uint32_t c = key < key_n ? (hist[key * 32u + (uint32_t)(r >> 1)] >> half) & 0xffffu : 0u;
+                    ovf |= c > 255u;
+                    plo |= (c & 15u) << (4 * q);
+                    phi |= ((c >> 4) & 15u) << (4 * q);
                 }
-                out4[(size_t)((kc0 >> 1) + k8) * PANEL + panel_slot(r)] = packed;
+                const uint32_t row = (kc0 >> 1) + k8;
+                out4[(size_t)row * PANEL + panel_slot(r)] = plo;
+                out4h[(size_t)row * PANEL + panel_slot(r)] = phi;
+                if (__ballot(phi != 0u) != 0ull && r == 0) atomicOr(&srowmask[row >> 5], 1u << (row & 31u));
             }
         }
-        // a count above 15: this (panel, combo) must be consumed in its u8 form (all writers
-        // store the same value; the array is zeroed before the launch)
-        if (!MARK && ovf4) flags4[(size_t)panel * n_slots + slot] = 1;
-        ovf4 = false;
+        if (!MARK) {
+            __syncthreads();
+            if ((uint32_t)tid < nst) rowmask[((size_t)panel * n_slots + slot) * nst + tid] = srowmask[tid];
+        }
     }
     if (!MARK && ovf) atomicOr(overflow_flag, 1u);
 }
@@ -267,20 +269,22 @@ __global__ __launch_bounds__(256) void k_dense_keylut(const uint32_t* keybits, u
 // U = sum over (combo, key) of d(d+1)/2, d = number of sequences in which the key occurs: the
 // number of `+=` the reference's countAndUpdateTri issues (shared.cpp:316-327), i.e. the
 // algorithmic update count the roofline is priced on. Read straight off the count
-// panels; profiling aid only. grid = (Vq, n_slots), block = 64 (lane = sequence within panel).
-__global__ __launch_bounds__(64) void k_dense_distinct(const uint32_t* C, uint32_t n_panels, int n_slots, uint32_t Vq, u64* U,
-                                                       const uint16_t* vc) {
-    const uint32_t kq = blockIdx.x, slot = blockIdx.y, r = threadIdx.x;
-    if (vc && kq >= ((uint32_t)vc[slot] + 3u) >> 2) return;  // rows beyond the compacted keys are not written
-    uint32_t d[4] = {0u, 0u, 0u, 0u};
+// panels (a key occurs in a sequence iff its lo or hi nibble is non-zero); profiling aid only.
+// grid = (Vq8, n_slots), block = 64 (lane = sequence within panel).
+__global__ __launch_bounds__(64) void k_dense_distinct(const uint32_t* C4, const uint32_t* C4H, uint32_t n_panels, int n_slots,
+                                                       uint32_t Vq8, u64* U, const uint16_t* vc) {
+    const uint32_t k8 = blockIdx.x, slot = blockIdx.y, r = threadIdx.x;
+    if (vc && k8 >= ((uint32_t)vc[slot] + 7u) >> 3) return;  // rows beyond the compacted keys are not written
+    uint32_t d[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     for (uint32_t p = 0; p < n_panels; ++p) {
-        const uint32_t v = C[((size_t)p * n_slots + slot) * ((size_t)Vq * PANEL) + (size_t)kq * PANEL + r];
+        const size_t o = ((size_t)p * n_slots + slot) * ((size_t)Vq8 * PANEL) + (size_t)k8 * PANEL + r;
+        const uint32_t v = C4[o] | C4H[o];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) d[q] += ((v >> (8 * q)) & 255u) ? 1u : 0u;
+        for (int q = 0; q < 8; ++q) d[q] += ((v >> (4 * q)) & 15u) ? 1u : 0u;
     }
     u64 u = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 8; ++q) {
         uint32_t x = d[q];
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) x += __shfl_xor(x, s);
@@ -289,21 +293,6 @@ __global__ __launch_bounds__(64) void k_dense_distinct(const uint32_t* C, uint32
     if (r == 0 && u) atomicAdd(U, u);
 }
 
-// Output-stationary tile accumulate. grid = (n_tiles, n_splits), block = 256 = 16 x 16 lanes,
-// each lane owns 8 rows x 8 columns (interleaved by 16, see panel_slot) of a 128x128 tile of K.
-// LDS: As/Bs[kq][128 seqs] dwords, i.e. the count panels as they lie in HBM. A-fragment reads
-// are 4 addresses per wave (broadcast), B-fragment reads are 16 consecutive 16-byte segments in
-// each panel half: conflict-free ds_read_b128.
-// Per key quad and lane: 4 x ds_read_b128 + 64 x v_dot4_u32_u8.
-// Count panels come in two encodings written side by side by k_dense_count: 4-bit fields
-// (8 keys per dword, v_dot8_u32_u4: same issue rate as dot4, twice the multiply-adds) and u8
-// (4 keys per dword, v_dot4_u32_u8). A (panel, combo) whose counts all fit 4 bits is consumed
-// in the 4-bit form; the rare one with a count above 15 (flag byte set by k_dense_count) makes
-// the tiles that touch it fall back to the u8 form for that combo only. The choice is uniform
-// per workgroup and per combo, so there is no divergence. mixed == 0 forces u8 everywhere.
-// blockIdx.x -> tile through a host-built table (tile_tab[b] = ti << 16 | tj): the order is
-// XCD-aware (blocks b, b+8, b+16, ... share an XCD and walk 8x8 super-tiles, so the ~64
-// workgroups resident on one XCD stream 8+8 panel pairs out of its L2 instead of 1+64).
 #define FSK_TILE_KERNEL k_dense_tile
 #define FSK_TILE_COMPACT 0
 #include "fsk_tile_kernel.inc"

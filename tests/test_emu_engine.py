@@ -301,3 +301,24 @@ def test_emu_key_compaction_rare_symbol(emu_lib, port, monkeypatch, g, m, force)
     assert np.array_equal(e.get_counts(), want)
     st = e.stats()
     assert st["key_space"] == 5 ** (g - m) and st["compact_keys_avg"] > 0 and st["compact_keys_avg"] < st["key_space"]
+
+
+def test_emu_many_flagged_rows_in_one_stage(emu_lib, port):
+    """More k-mers with counts above 15 in one 32-row stage than hi-plane rows ride along with
+    the prefetch (4): the tile kernel fetches the rest in extra rounds."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(3)
+    L = 90
+    X = [rng.integers(1, 5, size=L).astype(np.int32) for _ in range(140)]
+    pats = [[1], [2], [3], [4], [1, 2], [3, 4], [1, 3], [2, 4], [1, 2, 3], [4, 3, 2, 1]]
+    for i, pat in enumerate(pats):
+        X[3 + 13 * i] = np.array((pat * L)[:L], dtype=np.int32)   # spread over three panels
+    X[70] = np.array([1] * 45 + [2] * 45, dtype=np.int32)
+    tok, off = _native.flatten(X)
+    combos = np.array([0, 1, 34, 69], dtype=np.int32)
+    want, _, _ = port.raw_counts(tok, off, 8, 4, combos, threads=4)
+    e = _native.Engine(8, 4, path=1, lib=emu_lib)
+    e.load_sequences(tok, off, 100, 40)
+    e.accumulate(combos)
+    e.finalize()
+    assert np.array_equal(e.get_counts(), want)

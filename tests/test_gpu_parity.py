@@ -90,11 +90,8 @@ def test_baseline_configs_full_size(native, name):
     e.close()
 
 
-@pytest.mark.parametrize("force_u8", ["0", "1"])
-def test_dense_equals_sparse_on_seeded_dna(native, port, monkeypatch, force_u8):
-    """Two independent HIP dataflows and the oracle agree on config-5-shaped data (smaller N);
-    the dense one with 4-bit panels / v_dot8_u32_u4 (counts <= 15) and with u8 / v_dot4_u32_u8."""
-    monkeypatch.setenv("FSK_FORCE_U8", force_u8)
+def test_dense_equals_sparse_on_seeded_dna(native, port):
+    """Two independent HIP dataflows and the oracle agree on config-5-shaped data (smaller N)."""
     tokens, offsets = synthetic_dna(700, 300)
     combos = np.arange(0, 495, 33, dtype=np.int32)
     out = []
@@ -110,7 +107,6 @@ def test_dense_equals_sparse_on_seeded_dna(native, port, monkeypatch, force_u8):
     assert np.array_equal(out[0][1], out[1][1])
     assert np.array_equal(out[0][1], port.normalise(want.astype(np.float64), 700))
     assert out[1][2]["cell_updates"] == U
-    assert out[0][2]["u4_tile_launches"] == (0 if force_u8 == "1" else 1)
 
 
 @pytest.mark.parametrize("sigma,g,m,n,lo,hi", [(4, 8, 4, 257, 8, 90), (5, 10, 6, 130, 10, 400), (20, 7, 3, 300, 7, 120),
@@ -393,4 +389,25 @@ def test_key_compaction_rare_symbol(native, port, monkeypatch, force):
         assert st["compact_keys_avg"] == 0
     else:
         assert 256 <= st["compact_keys_avg"] < 625
+    e.close()
+
+
+def test_many_high_count_kmers(native, port):
+    """Low-complexity sequences of many kinds in the same panels: more rows with counts above 15
+    per 32-row stage than the 4 whose hi plane rides along with the prefetch."""
+    rng = np.random.default_rng(3)
+    L, N = 180, 700
+    X = rng.integers(1, 5, size=(N, L), dtype=np.int32)
+    pats = [[1], [2], [3], [4], [1, 2], [3, 4], [1, 3], [2, 4], [1, 2, 3], [4, 3, 2, 1], [1, 1, 2], [3, 3, 4, 4]]
+    for i, pat in enumerate(pats):
+        for rep in range(4):
+            X[7 + 53 * i + rep * 3] = np.array((pat * L)[:L], dtype=np.int32)
+    tokens, offsets = native.flatten(X)
+    combos = np.arange(0, 210, 13, dtype=np.int32)
+    want, _, _ = port.raw_counts(tokens, offsets, 10, 6, combos, threads=8)
+    e = native.Engine(10, 6, path=1)
+    e.load_sequences(tokens, offsets, 500, 200)
+    e.accumulate(combos)
+    e.finalize()
+    assert np.array_equal(e.get_counts(), want)
     e.close()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Race/edge screen on the GPU: many random shapes through both HIP dataflows (dense with 4-bit and
-u8 panels, sparse), compared with each other every time and with the CPU oracle on a sample.
+"""Race/edge screen on the GPU: many random shapes through both HIP dataflows (dense with and without
+key compaction, sparse with LDS-owned and global pair accumulation), compared with each other every time and with the CPU oracle on a sample.
 Not part of the pytest suite (minutes of GPU time); run it after touching a kernel."""
 import os, sys, time
 import numpy as np
@@ -32,10 +32,12 @@ def main(iters=150, seed=0):
         combos = np.unique(rng.integers(0, nc, size=int(rng.integers(1, 24)))).astype(np.int32)
         ntr = int(rng.integers(1, N + 1))
         res = {}
-        for name, path, env in (("dense4", 1, "0"), ("dense8", 1, "1"), ("sparse", 2, "0"), ("sparse_global", 2, "1")):
+        for name, path, env in (("dense", 1, "0"), ("dense_compact", 1, "1"), ("sparse", 2, "0"), ("sparse_global", 2, "1")):
             if path == 1 and (sigma ** k > 16384 or k > 16):
                 continue
-            os.environ["FSK_FORCE_U8"] = env if path == 1 else "0"
+            if name == "dense_compact" and sigma ** k > 4096:
+                continue
+            os.environ["FSK_COMPACT"] = env if path == 1 else "0"
             os.environ["FSK_SPARSE_GLOBAL"] = env if path == 2 else "0"
             e = _native.Engine(g, m, path=path)
             e.load_sequences(tokens, offsets, ntr, N - ntr)
