@@ -188,7 +188,7 @@ def main():
             "metric": "gkm kernel build: mismatch-combos/s", "value": value, "unit": "combos/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "u4/u8 counts, u32 accumulate, u64 atomics", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u4 count planes (v_dot8_u32_u4), u32 accumulate, u64 atomics", "data": "synthetic",
             "config": {"workload": "config5: synthetic DNA %d x %d bp, g=%d m=%d exact, %d combos" % (N, L, g, m, ncomb),
                        "n_seq": N, "seq_len": L, "g": g, "m": m, "combos": int(ncomb),
                        "parallelism": "combo-sharded x%d + RCCL all-reduce of the triangle in row bands" % world if world > 1 else "single GPU",

@@ -10,10 +10,11 @@
 //   DENSE  (small key space, e.g. DNA with k=4: 256 keys, every key present in most sequences)
 //     k_dense_count  per-sequence counting sort in LDS: 64 sequences per workgroup, symbols
 //                    unpacked once from bit-packed HBM, one LDS atomic per g-mer; the segment
-//                    counts leave as u8 "count panels" laid out [panel][combo][key/4][64 seqs]
-//                    so that the tile kernel streams them with 16-byte coalesced loads.
+//                    counts leave as 4-bit "count panels" (count = lo + 16*hi, two nibble planes)
+//                    laid out [panel][combo][key/8][64 seqs] so that the tile kernel streams
+//                    them with 16-byte coalesced loads.
 //     k_dense_tile   output-stationary 128x128 tile of K per workgroup: panels staged through
-//                    LDS, 8x8 register block per lane, v_dot4_u32_u8 multiply-adds summed in
+//                    LDS, 8x8 register block per lane, v_dot8_u32_u4 multiply-adds summed in
 //                    registers over ALL combos of the launch, then ONE 64-bit atomicAdd per cell.
 //
 //   SPARSE (large key space, e.g. protein: 24^4 keys, runs of 3-5) — the reference's dataflow

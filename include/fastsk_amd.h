@@ -43,8 +43,9 @@ enum {
 /* accumulate dataflow */
 enum {
     FSK_PATH_AUTO = 0,
-    FSK_PATH_DENSE = 1,  /* per-sequence LDS counting sort -> u8 count panels -> LDS-tiled
-                            integer co-occurrence accumulate, one 64-bit atomicAdd per cell      */
+    FSK_PATH_DENSE = 1,  /* per-sequence LDS counting sort -> 4-bit count panels (lo + 16*hi) ->
+                            LDS-tiled integer co-occurrence accumulate (v_dot8_u32_u4), one
+                            64-bit atomicAdd per cell                                            */
     FSK_PATH_SPARSE = 2  /* radix sort of (k-mer, seq) -> run-length segments -> 64-bit atomicAdd
                             per (run, pair): the reference's dataflow, cntsrtna+countAndUpdateTri */
 };
@@ -91,7 +92,7 @@ typedef struct fsk_stats {
     int64_t n_tile_launches; /* launches of the tile kernel (for per-launch averages)           */
     uint64_t dense_macs;     /* 8-bit multiply-adds issued by the tile kernel                   */
     uint64_t panel_bytes;    /* bytes of count panels written (= read at least once)            */
-    double u4_tile_launches; /* tile launches that used the 4-bit panels / v_dot8_u32_u4       */
+    double u4_tile_launches; /* launches of the 4-bit tile kernel (v_dot8_u32_u4)                */
     double max_windows;      /* max over sequences of (length - g + 1): bounds a cell per combo  */
     double count_launches;   /* launches of the segment-count kernel (panel cache misses)        */
     double compact_keys_avg; /* key compaction on: mean keys per combo that really occur (else 0) */
