@@ -309,9 +309,10 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         FSK_HIP(e->d_bk_hist.reserve((size_t)n_slices * bk_blocks));
         FSK_HIP(e->d_bk_tot.reserve(n_slices));
         FSK_HIP(e->d_slice_off.reserve((size_t)n_slices + 1));
-        FSK_HIP(e->d_list.reserve(nrec));
+        FSK_HIP(e->d_list.reserve(nrec * (size_t)4));  // up to BK_SPLIT work records per entry
         FSK_HIP(e->d_epair.reserve(nrec));
-        FSK_LAUNCH(fsk::k_bucket_hist, dim3(bk_blocks), dim3(256), 0, e->stream, e->d_segtot.p, e->d_estart.p, e->d_eseq.p, rps,
+        FSK_LAUNCH(fsk::k_bucket_hist, dim3(bk_blocks), dim3(256), 0, e->stream, e->d_segtot.p, e->d_estart.p, e->d_eseq.p,
+                   e->d_erun.p, e->d_rstart.p, rps,
                    n_slices, bk_blocks, e->d_bk_hist.p, e->d_epair.p);
         FSK_LAUNCH(fsk::k_rs_scan_rows, dim3(n_slices), dim3(256), 0, e->stream, e->d_bk_hist.p, bk_blocks, e->d_bk_tot.p);
         FSK_LAUNCH(fsk::k_bucket_scan_totals, dim3(1), dim3(256), 0, e->stream, e->d_bk_tot.p, n_slices, e->d_slice_off.p);

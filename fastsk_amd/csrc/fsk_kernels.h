@@ -580,13 +580,21 @@ __global__ __launch_bounds__(256) void k_sparse_pairs(const uint32_t* totals, co
 // the (run, pair) updates of a whole batch of combos are summed with LDS atomics, and only the
 // non-zero cells are flushed, row-contiguous, with one 64-bit atomicAdd each.
 constexpr int BK_TILE = 2048;       // entries per bucketing workgroup
+constexpr uint32_t BK_SPLIT = 4;    // an entry with many partners becomes up to this many work records
+constexpr uint32_t BK_CHUNK = 8;    // partners per record (at least)
+// partners per record for an entry with P partners, and the number of records that makes
+__device__ __forceinline__ uint32_t bk_chunk(uint32_t P) {
+    const uint32_t c = (P + BK_SPLIT - 1u) / BK_SPLIT;
+    return c > BK_CHUNK ? c : BK_CHUNK;
+}
+__device__ __forceinline__ uint32_t bk_records(uint32_t P) { return (P + bk_chunk(P) - 1u) / bk_chunk(P); }
 constexpr int BK_MAX_SLICES = 8192; // LDS histogram / cursor size
 
 // pass A: per-workgroup slice histogram -> blockhist[slice][block]; also packs (seq, multiplicity)
 // per entry so that the pair loop fetches a partner with one 8-byte load
 __global__ __launch_bounds__(256) void k_bucket_hist(const uint32_t* totals, const uint32_t* estart, const uint32_t* eseq,
-                                                     uint32_t rps, uint32_t n_slices, uint32_t nblocks, uint32_t* blockhist,
-                                                     uint2* epair) {
+                                                     const uint32_t* erun, const uint32_t* rstart, uint32_t rps,
+                                                     uint32_t n_slices, uint32_t nblocks, uint32_t* blockhist, uint2* epair) {
     __shared__ uint32_t h[BK_MAX_SLICES];
     const uint32_t D = totals[0];
     const int tid = threadIdx.x;
@@ -597,7 +605,8 @@ __global__ __launch_bounds__(256) void k_bucket_hist(const uint32_t* totals, con
         const uint32_t e = base + (uint32_t)it * 256u + (uint32_t)tid;
         if (e < D) {
             const uint32_t sq = eseq[e];
-            atomicAdd(&h[sq / rps], 1u);
+            const uint32_t P = e - rstart[erun[e]] + 1u;  // partners: earlier entries of the run + itself
+            atomicAdd(&h[sq / rps], bk_records(P));
             epair[e] = make_uint2(sq, estart[e + 1] - estart[e]);
         }
     }
@@ -621,9 +630,11 @@ __global__ __launch_bounds__(256) void k_bucket_scan_totals(const uint32_t* tota
     if (tid == 0) slice_off[n_slices] = carry;
 }
 
-// pass D: scatter a self-contained work record per entry {seq, multiplicity, first entry of its
-// run, entry} into its slice's bucket (LDS cursors; the order inside a bucket is free). The
-// dependent lookups (run -> run start) are paid here, where thousands of workgroups hide them.
+// pass D: scatter self-contained work records {seq, multiplicity, first partner, last partner}
+// into the slice's bucket (LDS cursors; the order inside a bucket is free). An entry with many
+// partners is split into up to BK_SPLIT records so that the lanes of the pair kernel carry
+// similar loads. The dependent lookups (run -> run start) are paid here, where thousands of
+// workgroups hide them.
 __global__ __launch_bounds__(256) void k_bucket_scatter(const uint32_t* totals, const uint2* epair, const uint32_t* erun,
                                                         const uint32_t* rstart, uint32_t rps, uint32_t n_slices,
                                                         uint32_t nblocks, const uint32_t* blockhist, const uint32_t* slice_off,
@@ -639,8 +650,12 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(const uint32_t* totals, 
         if (e < D) {
             const uint2 sc = epair[e];
             const uint32_t rs = rstart[erun[e]];
-            const uint32_t dst = atomicAdd(&cur[sc.x / rps], 1u);
-            list[dst] = make_uint4(sc.x, sc.y, rs, e);
+            const uint32_t P = e - rs + 1u, ch = bk_chunk(P), nr = bk_records(P);
+            const uint32_t dst = atomicAdd(&cur[sc.x / rps], nr);
+            for (uint32_t q = 0; q < nr; ++q) {  // {seq, multiplicity, first partner, last partner}
+                const uint32_t lo = rs + q * ch, hi = lo + ch - 1u < e ? lo + ch - 1u : e;
+                list[dst + q] = make_uint4(sc.x, sc.y, lo, hi);
+            }
         }
     }
 }
@@ -663,7 +678,7 @@ __global__ __launch_bounds__(256) void k_slice_pairs(const uint32_t* slice_off, 
     for (uint32_t base = lo; base < hi; base += 256) {
         const uint32_t t = base + (uint32_t)tid;
         if (t < hi) {
-            const uint4 rec = list[t];  // {seq_a, cnt_a, run start, entry}
+            const uint4 rec = list[t];  // {seq_a, cnt_a, first partner, last partner}
             if (rec.x >= row0 && rec.x < row1) {
                 uint32_t* row = sk + (size_t)(rec.x - r_lo) * N;
                 uint32_t b = rec.z;
