@@ -435,11 +435,25 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
     }
     const bool compact = e->compact;
     const uint32_t Vkeys = (uint32_t)e->V, Vw = (Vkeys + 31u) / 32u;
-    DensePlan plan = dense_plan(e->maxW, e->cfg.g, e->Vq, compact ? (size_t)Vkeys * 2 : 0);
+    DensePlan plan = dense_plan(e->maxW, e->cfg.g, e->Vq, compact ? (size_t)Vkeys * 2 : 0);  // may be re-planned below
     if (plan.CH == 0) return e->fail(FSK_EUNSUPPORTED, "dense path: LDS plan does not fit");
     uint32_t CH = plan.CH;
     if (e->force_chunk) CH = std::max(1u, std::min(CH, e->force_chunk));
-    const size_t lds = (size_t)(CH + e->cfg.g - 1) * fsk::PANEL + (size_t)plan.Vcq * 512 + (compact ? (size_t)Vkeys * 2 : 0);
+    size_t lds = (size_t)(CH + e->cfg.g - 1) * fsk::PANEL + (size_t)plan.Vcq * 512 + (compact ? (size_t)Vkeys * 2 : 0);
+    // several histogram sweeps over one staging pass: cache the window keys in LDS (u16 each) when
+    // they fit next to everything else, so that only the first sweep computes them
+    uint32_t kc_rows = 0;
+    if (plan.Vcq < e->Vq && CH >= e->maxW && !e->force_chunk) {
+        // re-plan with the cache carved out first
+        const size_t cache = (size_t)e->maxW * fsk::PANEL * sizeof(uint16_t);
+        DensePlan p2 = dense_plan(e->maxW, e->cfg.g, e->Vq, (compact ? (size_t)Vkeys * 2 : 0) + cache);
+        if (p2.CH >= e->maxW && p2.Vcq >= 64) {
+            plan = p2;
+            CH = plan.CH;
+            kc_rows = e->maxW;
+            lds = plan.lds;
+        }
+    }
 #ifndef FSK_EMU
     {
         auto k0 = fsk::k_dense_count<false, false>;
@@ -484,11 +498,11 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
                 FSK_HIP(hipMemsetAsync(e->d_keybits.p, 0, (size_t)nb * Vw * sizeof(uint32_t), e->stream));
                 FSK_LAUNCH(k_mark, cgrid, dim3(256), lds, e->stream, e->view(), e->cfg.g,
                            e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C4.p, e->d_C4H.p,
-                           e->d_rowmask.p, nst, e->d_flag.p, Vkeys, (const uint16_t*)nullptr, (const uint16_t*)nullptr, e->d_keybits.p);
+                           e->d_rowmask.p, nst, e->d_flag.p, Vkeys, (const uint16_t*)nullptr, (const uint16_t*)nullptr, e->d_keybits.p, kc_rows);
                 FSK_LAUNCH(fsk::k_dense_keylut, dim3(nb), dim3(256), 0, e->stream, e->d_keybits.p, Vkeys, e->d_lut.p, e->d_vc.p);
                 FSK_LAUNCH(k_count_lut, cgrid, dim3(256), lds, e->stream, e->view(), e->cfg.g,
                            e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C4.p, e->d_C4H.p,
-                           e->d_rowmask.p, nst, e->d_flag.p, Vkeys, e->d_lut.p, e->d_vc.p, (uint32_t*)nullptr);
+                           e->d_rowmask.p, nst, e->d_flag.p, Vkeys, e->d_lut.p, e->d_vc.p, (uint32_t*)nullptr, kc_rows);
                 h_vc.resize((size_t)nb);
                 FSK_HIP(hipMemcpyAsync(h_vc.data(), e->d_vc.p, (size_t)nb * sizeof(uint16_t), hipMemcpyDeviceToHost, e->stream));
                 FSK_HIP(hipStreamSynchronize(e->stream));
@@ -503,7 +517,7 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
             } else {
                 FSK_LAUNCH(k_count, cgrid, dim3(256), lds, e->stream, e->view(), e->cfg.g,
                            e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C4.p, e->d_C4H.p,
-                           e->d_rowmask.p, nst, e->d_flag.p, Vkeys, (const uint16_t*)nullptr, (const uint16_t*)nullptr, (uint32_t*)nullptr);
+                           e->d_rowmask.p, nst, e->d_flag.p, Vkeys, (const uint16_t*)nullptr, (const uint16_t*)nullptr, (uint32_t*)nullptr, kc_rows);
             }
             e->toc(&e->st.ms_count);
             e->st.count_launches += 1;

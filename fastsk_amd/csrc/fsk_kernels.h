@@ -95,13 +95,22 @@ __device__ __forceinline__ uint32_t tile_index(uint32_t t, uint32_t e) { return 
 // and issue back to back; K = 0 is the generic loop for k > 8). MARK: only record which keys
 // occur (bitmap pre-pass of the key compaction); else one LDS atomic per window, the key first
 // mapped through the combo's compaction table when LUT.
+// kcache (several key sweeps over one staging pass): the first sweep stores every window's
+// (compacted) key in LDS, kmode 1; the later sweeps read it back instead of recomputing, kmode 2.
 template <int K, bool MARK, bool LUT>
 __device__ __forceinline__ void count_windows(const uint8_t* symT, uint32_t* hist, const uint16_t* lut, const uint32_t (&pr)[16],
                                               int k, uint32_t sigma, uint32_t j0, uint32_t hi, uint32_t cb, uint32_t nwin,
-                                              uint32_t r, uint32_t half, uint32_t key_lo, uint32_t key_n) {
+                                              uint32_t r, uint32_t half, uint32_t key_lo, uint32_t key_n, uint16_t* kcache,
+                                              int kmode) {
     for (uint32_t j = j0; j < hi; j += 4) {
         if (j < nwin) {
             uint32_t key = 0;
+            if (!MARK && kmode == 2) {  // workgroup-uniform
+                key = kcache[j * PANEL + r];
+                key -= key_lo;
+                if (key < key_n) atomicAdd(&hist[key * 32u + (r >> 1)], 1u << half);
+                continue;
+            }
             if (K > 0) {
 #pragma unroll
                 for (int c = 0; c < K; ++c) key = key * sigma + symT[(j - cb + pr[c]) * PANEL + r];
@@ -114,6 +123,7 @@ __device__ __forceinline__ void count_windows(const uint8_t* symT, uint32_t* his
                 atomicOr(&hist[key >> 5], 1u << (key & 31u));  // hist doubles as the key bitmap
             } else {
                 if (LUT) key = lut[key];
+                if (kmode == 1) kcache[j * PANEL + r] = (uint16_t)key;
                 key -= key_lo;  // wraps for keys below the sweep: rejected by the compare
                 if (key < key_n) atomicAdd(&hist[key * 32u + (r >> 1)], 1u << half);
             }
@@ -124,17 +134,18 @@ __device__ __forceinline__ void count_windows(const uint8_t* symT, uint32_t* his
 template <bool MARK, bool LUT>
 __device__ __forceinline__ void count_windows_k(const uint8_t* symT, uint32_t* hist, const uint16_t* lut, const uint32_t (&pr)[16],
                                                 int k, uint32_t sigma, uint32_t j0, uint32_t hi, uint32_t cb, uint32_t nwin,
-                                                uint32_t r, uint32_t half, uint32_t key_lo, uint32_t key_n) {
+                                                uint32_t r, uint32_t half, uint32_t key_lo, uint32_t key_n, uint16_t* kcache,
+                                                int kmode) {
     switch (k) {  // workgroup-uniform
-        case 1: count_windows<1, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n); break;
-        case 2: count_windows<2, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n); break;
-        case 3: count_windows<3, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n); break;
-        case 4: count_windows<4, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n); break;
-        case 5: count_windows<5, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n); break;
-        case 6: count_windows<6, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n); break;
-        case 7: count_windows<7, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n); break;
-        case 8: count_windows<8, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n); break;
-        default: count_windows<0, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n); break;
+        case 1: count_windows<1, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n, kcache, kmode); break;
+        case 2: count_windows<2, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n, kcache, kmode); break;
+        case 3: count_windows<3, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n, kcache, kmode); break;
+        case 4: count_windows<4, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n, kcache, kmode); break;
+        case 5: count_windows<5, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n, kcache, kmode); break;
+        case 6: count_windows<6, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n, kcache, kmode); break;
+        case 7: count_windows<7, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n, kcache, kmode); break;
+        case 8: count_windows<8, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n, kcache, kmode); break;
+        default: count_windows<0, MARK, LUT>(symT, hist, lut, pr, k, sigma, j0, hi, cb, nwin, r, half, key_lo, key_n, kcache, kmode); break;
     }
 }
 
@@ -153,7 +164,8 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
                                                      uint32_t Vcq, uint32_t max_win, uint32_t CH, const uint8_t* combo_pos,
                                                      int n_slots, int slots_per_chunk, uint32_t* C4, uint32_t* C4H,
                                                      uint32_t* rowmask, uint32_t nst, uint32_t* overflow_flag, uint32_t V,
-                                                     const uint16_t* lut_g, const uint16_t* vc, uint32_t* keybits) {
+                                                     const uint16_t* lut_g, const uint16_t* vc, uint32_t* keybits,
+                                                     uint32_t kc_rows) {
     // Counts leave as two 4-bit planes, count = lo + 16 * hi (8 keys per dword): C4 holds lo and
     // is all the tile kernel multiplies for almost every key; C4H holds hi, zero unless a k-mer
     // occurs more than 15 times in one sequence (poly-A, runs of 'n'); rowmask[panel][slot][..]
@@ -170,6 +182,8 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
     const uint32_t sym_rows = CH + (uint32_t)g - 1u;
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (size_t)sym_rows * PANEL);
     uint16_t* lut = reinterpret_cast<uint16_t*>(smem + (size_t)sym_rows * PANEL + (size_t)Vcq * 512);
+    // window-key cache [kc_rows][64] u16 behind the table (kc_rows = max_win when the host enabled it)
+    uint16_t* kcache = lut + (LUT ? V : 0u);
     const int tid = threadIdx.x, r = tid & 63, w = tid >> 6;
     const uint32_t panel = blockIdx.x;
     const uint32_t seq = panel * PANEL + r;
@@ -214,7 +228,9 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
                 }
                 __syncthreads();  // symbols staged, histogram zeroed, table loaded
                 const uint32_t hi = cb + CH < max_win ? cb + CH : max_win;
-                count_windows_k<MARK, LUT>(symT, hist, lut, pr, k, sigma, cb + (uint32_t)w, hi, cb, nwin, (uint32_t)r, half, key_lo, key_n);
+                const int kmode = (MARK || kc_rows == 0u) ? 0 : (kc0 == 0u ? 1 : 2);
+                count_windows_k<MARK, LUT>(symT, hist, lut, pr, k, sigma, cb + (uint32_t)w, hi, cb, nwin, (uint32_t)r, half, key_lo, key_n,
+                                           kcache, kmode);
             }
             __syncthreads();
             if (MARK) {  // merge this panel's key bitmap into the combo's
