@@ -51,7 +51,7 @@ class Stats(C.Structure):
 SYMBOLS = ["fsk_create", "fsk_destroy", "fsk_last_error", "fsk_abi_version", "fsk_device_count", "fsk_compute",
            "fsk_set_combo_order", "fsk_set_seed", "fsk_load_sequences", "fsk_bind_counts",
            "fsk_counts_device_ptr", "fsk_reset_counts", "fsk_accumulate", "fsk_accumulate_rows", "fsk_synchronize", "fsk_finalize",
-           "fsk_get_block", "fsk_get_train", "fsk_get_test", "fsk_get_triangle", "fsk_get_counts",
+           "fsk_get_block", "fsk_get_block_device", "fsk_get_train", "fsk_get_test", "fsk_get_triangle", "fsk_get_counts",
            "fsk_get_counts_block", "fsk_get_stdevs", "fsk_save_kernel", "fsk_get_stats", "fsk_num_combos",
            "fsk_combo_positions"]
 
@@ -86,6 +86,7 @@ class Library:
             "fsk_synchronize": ([vp], C.c_int),
             "fsk_finalize": ([vp], C.c_int),
             "fsk_get_block": ([vp, i64, i64, i64, i64, vp], C.c_int),
+            "fsk_get_block_device": ([vp, i64, i64, i64, i64, vp], C.c_int),
             "fsk_get_train": ([vp, vp], C.c_int),
             "fsk_get_test": ([vp, vp], C.c_int),
             "fsk_get_triangle": ([vp, vp], C.c_int),
@@ -232,6 +233,14 @@ class Engine:
     def get_block(self, i0, i1, j0, j1):
         out = np.empty((i1 - i0, j1 - j0), dtype=np.float64)
         self._ck(self.lib.L.fsk_get_block(self.h, i0, i1, j0, j1, out.ctypes.data))
+        return out
+
+    def get_block_torch(self, i0, i1, j0, j1):
+        """The normalised block as a float64 torch tensor ON THE GPU (no host round trip)."""
+        import torch
+        out = torch.empty((i1 - i0, j1 - j0), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        self._ck(self.lib.L.fsk_get_block_device(self.h, i0, i1, j0, j1, C.c_void_p(out.data_ptr())))
         return out
 
     def get_train(self):

@@ -1065,6 +1065,30 @@ int fsk_get_block(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1,
     FSK_HIP(hipSetDevice(e->cfg.device));
     return fetch_block(e, i0, i1, j0, j1, out);
 }
+int fsk_get_block_device(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1, double* device_out) {
+    if (!e) return FSK_EINVAL;
+    if (!e->finalized) return e->fail(FSK_ESTATE, "no finalized kernel: call fsk_compute or fsk_finalize first");
+    if (i0 < 0 || j0 < 0 || i1 > e->N || j1 > e->N || i0 > i1 || j0 > j1) return e->fail(FSK_EINVAL, "block out of range");
+    const u64 rows = (u64)(i1 - i0), cols = (u64)(j1 - j0);
+    if (rows == 0 || cols == 0) return FSK_OK;
+    if (!device_out) return e->fail(FSK_EINVAL, "null output");
+    FSK_HIP(hipSetDevice(e->cfg.device));
+    const u64 max_cells = (u64)1 << 31;  // grid.x limit: launch in row chunks
+    const u64 rows_per = std::max<u64>(1, std::min<u64>(rows, max_cells / cols));
+    for (u64 r = 0; r < rows; r += rows_per) {
+        const u64 nr = std::min(rows_per, rows - r), cells = nr * cols;
+        const uint32_t blocks = (uint32_t)((cells + 255) / 256);
+        if (e->result_f64)
+            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_block<double>), dim3(blocks), dim3(256), 0, e->stream, e->d_Kf64.p, e->d_diag.p,
+                       (u64)i0 + r, nr, (u64)j0, cols, device_out + r * cols);
+        else
+            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_block<u64>), dim3(blocks), dim3(256), 0, e->stream, e->d_K, e->d_diag.p,
+                       (u64)i0 + r, nr, (u64)j0, cols, device_out + r * cols);
+    }
+    FSK_HIP(hipStreamSynchronize(e->stream));
+    return FSK_OK;
+}
+
 int fsk_get_train(fsk_engine* e, double* out) {
     if (!e) return FSK_EINVAL;
     FSK_HIP(hipSetDevice(e->cfg.device));

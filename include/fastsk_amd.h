@@ -150,6 +150,9 @@ int fsk_finalize(fsk_engine* e);
 /* ---- results: replace the getters of fastsk.cpp:190-221 ---------------------------------- */
 /* normalised K[i0:i1, j0:j1] as row-major doubles, any sub-block of the symmetric N x N matrix */
 int fsk_get_block(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1, double* out);
+/* the same block written to DEVICE memory owned by the caller (e.g. a torch tensor): no host copy,
+ * for consumers that keep the kernel matrix on the GPU */
+int fsk_get_block_device(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1, double* device_out);
 int fsk_get_train(fsk_engine* e, double* out);      /* n_train x n_train, get_train_kernel()   */
 int fsk_get_test(fsk_engine* e, double* out);       /* n_test  x n_train, get_test_kernel()    */
 int fsk_get_triangle(fsk_engine* e, double* out);   /* double[N(N+1)/2], the reference's K     */

@@ -276,6 +276,18 @@ def test_pybind_surface_on_gpu(native):
         f.fit()
 
 
+def test_device_resident_block_getter(native):
+    """fsk_get_block_device: the normalised block straight into a torch tensor on the GPU."""
+    d = load_golden("f4_ep300_exact")
+    e = engine_for(native, d)
+    e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+    t = e.get_block_torch(0, d["n_train"], 0, d["n_train"])
+    assert t.is_cuda and np.array_equal(t.cpu().numpy(), d["train"])
+    t = e.get_block_torch(d["n_train"], d["n_train"] + d["n_test"], 0, d["n_train"])
+    assert np.array_equal(t.cpu().numpy(), d["test"])
+    e.close()
+
+
 def test_save_kernel_format(native, tmp_path):
     d = load_golden("f3_ragged_sigma7_g6m3")
     e = engine_for(native, d)
