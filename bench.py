@@ -3,10 +3,15 @@
 
 A "step" is one pass of the hot path over the whole workload: BASELINE config 5, synthetic
 100,000 x 300 bp DNA, g=12, m=8, exact, all C(12,8)=495 mismatch combinations, with the packed
-sequences already resident in HBM when the timed region starts. With N GPUs the 495 combos are
-sharded c = rank (mod N) (STRONG scaling: total work fixed), every rank accumulates a private
-integer triangle, ONE RCCL all-reduce over xGMI merges them, then the diagonal is extracted for
-normalisation. value = combos/s of the whole job = 495 * steps / max-over-ranks seconds.
+sequences already resident in HBM when the timed region starts. With N GPUs the job is the same
+(STRONG scaling: total work fixed) and is sharded one of two ways (fastsk_amd/distributed.py):
+  rows    (default at this size) every rank owns an equal-area band of rows of the triangle and runs
+          all 495 combos over it; no cell is shared, the only exchange is the 0.8 MB diagonal, and
+          the kernel matrix stays distributed over the GPUs;
+  combos  the reference's decomposition: combos c = rank (mod N), every rank accumulates a private
+          triangle, RCCL all-reduces it over xGMI in row bands under the next band's kernels.
+The other of the two is timed for one step afterwards and reported as "alt".
+value = combos/s of the whole job = 495 * steps / max-over-ranks seconds.
 
 One JSON line on rank 0. Extra objects:
   roofline      the dominant kernel (k_dense_tile) priced on SURVEY 8d's algorithmic bytes
@@ -81,6 +86,16 @@ def other_configs(_native):
                                     "reference_cpu_seconds_8_threads": 29.9}}
 
 
+def describe(mode, world, replicate):
+    if world == 1:
+        return "single GPU"
+    if mode == "rows":
+        return ("row-band sharded x%d: every rank runs all combos over its own equal-area band of rows of the triangle; "
+                "exchange = the N-entry diagonal only%s" % (world, "; finished bands broadcast to every rank" if replicate
+                                                            else "; the kernel matrix stays distributed"))
+    return "combo-sharded x%d + RCCL all-reduce of the triangle in row bands under the next band's kernels" % world
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,6 +110,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra config-2 measurement (profiling runs)")
     ap.add_argument("--bands", type=int, default=None, help="row bands of the overlapped all-reduce (default: auto)")
+    ap.add_argument("--shard", choices=["auto", "rows", "combos"], default="auto", help="multi-GPU decomposition")
+    ap.add_argument("--replicate", action="store_true", help="rows: broadcast finished bands so every rank holds all of K")
+    ap.add_argument("--no-alt", action="store_true", help="multi-GPU: do not time the other decomposition")
     args = ap.parse_args()
 
     import torch
@@ -126,7 +144,16 @@ def main():
     eng.load_sequences(tokens, offsets, N, 0)  # host packing + H2D: outside the timed region
     eng.synchronize()
     t_load = time.perf_counter() - t_load
-    mine = np.arange(rank, ncomb, world, dtype=np.int32)
+    every = np.arange(ncomb, dtype=np.int32)
+    edges = distributed.owner_edges(N, world)
+    dense = eng.stats()["path_used"] == 1
+    mode = args.shard
+    if mode == "auto":
+        mode = "rows" if (world > 1 and dense and edges is not None) else "combos"
+    if mode == "rows" and edges is None:
+        raise SystemExit("--shard rows needs one 128-row band per rank")
+    my_rows = (edges[rank], edges[rank + 1]) if mode == "rows" else (0, N)
+    mine = every if mode == "rows" else np.arange(rank, ncomb, world, dtype=np.int32)
 
     def barrier():
         torch.cuda.synchronize()
@@ -134,31 +161,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
+    def step(how=mode):
         eng.reset_counts()
-        if use_dist:
+        if use_dist and how == "rows":
+            # every combo over this rank's rows; only the diagonal is exchanged
+            distributed.accumulate_owned_rows(eng, K, every, replicate=args.replicate, n_sub=args.bands, edges=edges)
+        elif use_dist:
             # combos sharded; the all-reduce of the partial triangles runs band by band on RCCL's
-            # stream under the next band's kernels (fastsk_amd/distributed.py)
-            distributed.accumulate_and_reduce(eng, K, mine, n_combos_total=ncomb, n_bands=args.bands, force=world == 1)
+            # stream under the next band's kernels
+            distributed.accumulate_and_reduce(eng, K, np.arange(rank, ncomb, world, dtype=np.int32), n_combos_total=ncomb,
+                                              n_bands=args.bands, force=world == 1)
         else:
             eng.accumulate(mine)
             eng.synchronize()
         eng.finalize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    s0 = eng.stats()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    s1 = eng.stats()
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    def timed(how, warmup, steps):
+        for _ in range(warmup):
+            step(how)
+        barrier()
+        a = eng.stats()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(how)
+        barrier()
+        dt = time.perf_counter() - t0
+        b = eng.stats()
+        if use_dist:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, a, b
+
+    elapsed, s0, s1 = timed(mode, args.warmup, args.steps)
+    alt = None
+    if world > 1 and not args.no_alt and (mode == "combos" and dense and edges is not None or mode == "rows"):
+        other = "combos" if mode == "rows" else "rows"
+        dt, _, _ = timed(other, 1, 1)
+        alt = {"parallelism": describe(other, world, args.replicate), "value": ncomb / dt, "unit": "combos/s",
+               "ms_per_step": 1e3 * dt, "steps": 1, "warmup": 1}
 
     if rank == 0:
         combos_rank = len(mine) * args.steps
@@ -167,7 +208,9 @@ def main():
         # ---- roofline of the dominant kernel (tile accumulate), per launch
         launches = max(1, d("n_tile_launches"))
         tile_ms = d("ms_tile") / launches
-        U = d("cell_updates") / launches            # exact, from the count panels
+        # exact, from the count panels (whole triangle); a row-band launch owns its share of the cells
+        share = ((my_rows[1] * (my_rows[1] + 1) - my_rows[0] * (my_rows[0] + 1)) // 2) / pairs
+        U = d("cell_updates") / launches * share
         nfeat = s1["n_feat"]
         combos_per_launch = combos_rank / launches
         b_in = (N * L * s1["bits_per_symbol"] + 7) // 8
@@ -191,7 +234,7 @@ def main():
             "vs_baseline": None, "dtype": "u4 count planes (v_dot8_u32_u4), u32 accumulate, u64 atomics", "data": "synthetic",
             "config": {"workload": "config5: synthetic DNA %d x %d bp, g=%d m=%d exact, %d combos" % (N, L, g, m, ncomb),
                        "n_seq": N, "seq_len": L, "g": g, "m": m, "combos": int(ncomb),
-                       "parallelism": "combo-sharded x%d + RCCL all-reduce of the triangle in row bands" % world if world > 1 else "single GPU",
+                       "parallelism": describe(mode, world, args.replicate),
                        "path": "dense" if s1["path_used"] == 1 else "sparse"},
             "roofline": {"bound": "hbm", "kernel": "k_dense_tile", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -206,6 +249,8 @@ def main():
             "phases_ms_per_step": {"count": d("ms_count") / args.steps, "tile": d("ms_tile") / args.steps,
                                    "accumulate_total": d("ms_total") / args.steps},
         }
+        if alt is not None:
+            out["alt"] = alt
         if world == 1 and not args.no_also:
             out["also"] = other_configs(_native)
         if world == 1 and not args.no_cpu_baseline:

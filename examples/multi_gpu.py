@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Multi-GPU exact kernel: one process per GPU, combos sharded, banded all-reduce over RCCL.
+"""Multi-GPU exact kernel: one process per GPU, row-band (or combo) sharded over RCCL.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
         examples/multi_gpu.py --n-seq 100000 --seq-len 300 -g 12 -m 8
 
-Every rank ends with the reduced integer triangle; rank 0 prints a corner of the normalised
-kernel. See fastsk_amd/distributed.py.
+--shard rows (default): every rank runs all combos over its own band of rows, the kernel stays
+distributed and blocks are assembled on demand; --shard combos: combos dealt round-robin and the
+triangle all-reduced. Rank 0 prints a corner of the normalised kernel. See fastsk_amd/distributed.py.
 """
 import argparse
 import os
@@ -26,6 +27,7 @@ def main():
     ap.add_argument("--seq-len", type=int, default=300)
     ap.add_argument("-g", type=int, default=12)
     ap.add_argument("-m", type=int, default=8)
+    ap.add_argument("--shard", choices=["rows", "combos"], default="rows")
     args = ap.parse_args()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
@@ -35,11 +37,13 @@ def main():
     X = rng.integers(1, 5, size=(args.n_seq, args.seq_len), dtype=np.int32)
     tokens, offsets = X.reshape(-1), np.arange(args.n_seq + 1, dtype=np.int64) * args.seq_len
     t0 = time.time()
-    eng, K = distributed.compute_sharded(tokens, offsets, args.n_seq, 0, args.g, args.m)
+    eng, K = distributed.compute_sharded(tokens, offsets, args.n_seq, 0, args.g, args.m, shard_by=args.shard,
+                                         replicate=False)
     dt = time.time() - t0
+    corner = distributed.get_block_distributed(eng, 0, 4, 0, 4, device="cuda")  # collective: every rank calls it
     if not dist.is_initialized() or dist.get_rank() == 0:
         print("exact gkm kernel, %d sequences, %d GPUs: %.2f s" % (args.n_seq, dist.get_world_size() if dist.is_initialized() else 1, dt))
-        print(eng.get_block(0, 4, 0, 4))
+        print(corner.cpu().numpy())
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -986,6 +986,7 @@ int fsk_reset_counts(fsk_engine* e) {
     FSK_HIP(hipMemsetAsync(e->d_K, 0, (size_t)e->pairs * sizeof(u64), e->stream));
     e->finalized = false; e->result_f64 = false;
     e->st.combos_done = 0;
+    e->prep_valid = false;  // a new pass recounts its panels even when its first band starts at row > 0
     return FSK_OK;
 }
 

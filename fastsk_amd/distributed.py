@@ -1,4 +1,12 @@
-"""Multi-GPU host path: one process per GPU, combos sharded, ONE all-reduce of the integer triangle.
+"""Multi-GPU host path: one process per GPU over torch.distributed (RCCL), two ways to shard.
+
+``shard="rows"`` (large N): rank r OWNS an equal-area band of rows of the triangle and runs ALL
+combos over it (``fsk_accumulate_rows``). No cell is shared, so the only exchange is the N-entry
+diagonal the cosine normalisation needs (0.8 MB at N = 100k); the kernel matrix stays distributed
+(each rank serves its rows; ``get_block_distributed`` assembles any rectangle) unless
+``replicate=True`` broadcasts the finished bands under the next band's kernels.
+
+``shard="combos"`` (small N, and the reference's own decomposition):
 
 The C(g,m) mismatch combinations are independent units (the reference shards them round-robin over
 host threads, ``fastsk_kernel.cpp:148,275``, and sum-reduces once, ``:286-315``). Here rank r of R
@@ -43,6 +51,110 @@ def cell(i):
     return i * (i + 1) // 2
 
 
+def owner_edges(N, world):
+    """Row ownership for shard="rows": world+1 tile-aligned edges of equal-area bands, or None when
+    N is too small to give every rank a band."""
+    e = band_edges(N, world)
+    return e if len(e) == world + 1 else None
+
+
+def sub_edges(lo, hi, n):
+    """Equal-area split of rows [lo, hi) of the lower triangle into <= n tile-aligned sub-bands."""
+    e = {lo, hi}
+    for k in range(1, n):
+        r = int(round(math.sqrt(lo * lo + (hi * hi - lo * lo) * k / n) / TILE)) * TILE
+        if lo < r < hi:
+            e.add(r)
+    return sorted(e)
+
+
+def diag_index(N, device):
+    import torch
+    i = torch.arange(N, dtype=torch.int64, device=device)
+    return i * (i + 3) // 2  # tri_index(i, i)
+
+
+def accumulate_owned_rows(eng, K, combos, group=None, replicate=False, n_sub=None, narrow=None, edges=None):
+    """One pass of shard="rows": all ``combos`` over this rank's band of rows, then the diagonal
+    exchange. With ``replicate`` every finished sub-band is broadcast from its owner (int32 when it
+    provably fits) while the next sub-band is computed, so every rank ends with the whole triangle.
+    Returns this rank's (row_begin, row_end)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    N = eng.N
+    if edges is None:
+        edges = owner_edges(N, world)
+    if edges is None:
+        raise ValueError("shard='rows' needs at least one 128-row tile band per rank")
+    lo, hi = edges[rank], edges[rank + 1]
+    if world == 1:
+        eng.accumulate_rows(combos, lo, hi)
+        eng.synchronize()
+        return lo, hi
+    if not replicate:
+        eng.accumulate_rows(combos, lo, hi)
+        eng.synchronize()
+        idx = diag_index(N, K.device)
+        d = K[idx]  # zero outside [lo, hi): the sum over ranks is the full diagonal
+        dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)
+        K[idx] = d
+        if K.is_cuda:
+            torch.cuda.synchronize(K.device)
+        return lo, hi
+    if n_sub is None:
+        n_sub = 4
+    if narrow is None:
+        narrow = len(combos) * eng.stats()["max_windows"] ** 2 < 2 ** 31
+    subs = [sub_edges(edges[r], edges[r + 1], n_sub) for r in range(world)]
+    pending = []
+
+    def drain(keep):
+        while len(pending) > keep:
+            work, seg, seg32, mine = pending.pop(0)
+            work.wait()
+            if seg32 is not None and not mine:
+                seg.copy_(seg32)
+
+    for k in range(max(len(s) for s in subs) - 1):
+        if k < len(subs[rank]) - 1:
+            eng.accumulate_rows(combos, subs[rank][k], subs[rank][k + 1])
+            eng.synchronize()
+        for r in range(world):  # same order on every rank
+            if k >= len(subs[r]) - 1:
+                continue
+            seg = K[cell(subs[r][k]):cell(subs[r][k + 1])]
+            seg32 = None
+            if narrow:
+                seg32 = seg.to(torch.int32) if r == rank else torch.empty(seg.shape, dtype=torch.int32, device=K.device)
+            src = dist.get_global_rank(group, r) if group is not None else r
+            work = dist.broadcast(seg32 if narrow else seg, src=src, group=group, async_op=True)
+            pending.append((work, seg, seg32, r == rank))
+        drain(2 * world)
+    drain(0)
+    if K.is_cuda:
+        torch.cuda.synchronize(K.device)
+    return lo, hi
+
+
+def get_block_distributed(eng, i0, i1, j0, j1, group=None, device=None):
+    """Normalised block [i0,i1) x [j0,j1) of a row-sharded kernel, on every rank: an off-diagonal
+    cell is non-zero only on the owner of row max(i,j), the (exchanged) diagonal is the same
+    everywhere and nothing is negative, so an element-wise MAX assembles the block exactly."""
+    import torch
+    import torch.distributed as dist
+
+    if device is not None and torch.device(device).type == "cuda":
+        blk = eng.get_block_torch(i0, i1, j0, j1)
+    else:
+        blk = torch.from_numpy(eng.get_block(i0, i1, j0, j1))
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(blk, op=dist.ReduceOp.MAX, group=group)
+    return blk
+
+
 def accumulate_and_reduce(eng, K, combos, group=None, n_bands=None, narrow=None, n_combos_total=None, force=False):
     """One pass: accumulate this rank's ``combos`` into the bound triangle ``K`` and sum it over
     the ranks of ``group``, band by band, overlapping RCCL with the next band's kernels."""
@@ -85,12 +197,17 @@ def accumulate_and_reduce(eng, K, combos, group=None, n_bands=None, narrow=None,
 
 
 def compute_sharded(tokens, offsets, n_train, n_test, g, m, combos=None, group=None, device=None, lib=None,
-                    path=_native.PATH_AUTO, profile=False, n_bands=None, narrow=None):
+                    path=_native.PATH_AUTO, profile=False, n_bands=None, narrow=None, shard_by="combos",
+                    replicate=True):
     """Exact (or explicit-combo-list) kernel over the ranks of ``group``.
 
     Returns ``(engine, K)``: the finalized engine of this rank (use ``get_block`` / ``get_train`` /
-    ``get_test``) and the torch tensor that holds the reduced integer triangle (int64 view of the
-    uint64 counts). ``device`` is a torch device (defaults to the current CUDA device); ``lib`` is
+    ``get_test``) and the torch tensor that holds the integer triangle (int64 view of the uint64
+    counts). ``shard_by="combos"``: combos dealt round-robin, triangle all-reduced, every rank holds
+    all of it. ``shard_by="rows"``: every rank runs all combos over its own band of rows
+    (``owner_edges``); with ``replicate=False`` the triangle stays distributed (cells outside the
+    rank's rows are zero; assemble blocks with ``get_block_distributed``). "rows" falls back to
+    "combos" when N is too small for one tile band per rank or the sparse dataflow is in use. ``device`` is a torch device (defaults to the current CUDA device); ``lib`` is
     only overridden by the CPU test-suite, which runs this same code over gloo against the
     emulated library.
     """
@@ -114,7 +231,14 @@ def compute_sharded(tokens, offsets, n_train, n_test, g, m, combos=None, group=N
         torch.cuda.synchronize(device)
     eng.bind_counts(K.data_ptr(), pairs, keepalive=K)
     eng.load_sequences(tokens, offsets, n_train, n_test)
-    accumulate_and_reduce(eng, K, shard(combos, rank, world), group=group, n_bands=n_bands, narrow=narrow,
-                          n_combos_total=len(combos))
+    if shard_by not in ("combos", "rows"):
+        raise ValueError("shard_by must be 'combos' or 'rows'")
+    dense = eng.stats()["path_used"] == _native.PATH_DENSE  # (the sparse dataflow would repeat its sort on every rank)
+    if shard_by == "rows" and dense and owner_edges(N, world) is not None and world > 1:
+        accumulate_owned_rows(eng, K, np.ascontiguousarray(combos, dtype=np.int32), group=group, replicate=replicate,
+                              n_sub=n_bands, narrow=narrow)
+    else:
+        accumulate_and_reduce(eng, K, shard(combos, rank, world), group=group, n_bands=n_bands, narrow=narrow,
+                              n_combos_total=len(combos))
     eng.finalize()
     return eng, K

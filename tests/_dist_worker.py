@@ -25,9 +25,13 @@ def main():
     d = np.load(fixture)
     eng, K = distributed.compute_sharded(d["tokens"], d["offsets"], int(d["n_train"]), int(d["n_test"]), int(d["g"]),
                                          int(d["m"]), combos=d["combos"], device=device, lib=lib,
-                                         n_bands=int(sys.argv[3]), narrow=bool(int(sys.argv[4])))
+                                         n_bands=int(sys.argv[3]), narrow=bool(int(sys.argv[4])),
+                                         shard_by=sys.argv[6] if len(sys.argv) > 6 else "combos",
+                                         replicate=bool(int(sys.argv[7])) if len(sys.argv) > 7 else True)
+    N = int(d["n_train"]) + int(d["n_test"])
+    full = distributed.get_block_distributed(eng, 0, N, 0, N, device=device).cpu().numpy()  # == local block when replicated
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), counts=K.cpu().numpy().view(np.uint64), tri=eng.get_triangle(),
-             done=eng.stats()["combos_done"], world=world)
+             done=eng.stats()["combos_done"], world=world, full=full)
     dist.destroy_process_group()
 
 

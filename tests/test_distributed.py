@@ -25,13 +25,14 @@ def test_shard_partition():
     assert band_edges(300, 8) == [0, 128, 256, 300] or band_edges(300, 8)[-1] == 300
 
 
-def run_world(tmp_path, fixture, n_bands, narrow, port_no):
+def run_world(tmp_path, fixture, n_bands, narrow, port_no, shard_by="combos", replicate=True):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_no), WORLD_SIZE="2")
     procs = []
     for rank in range(2):
         e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), fixture,
-                                       str(tmp_path), str(n_bands), str(int(narrow))], env=e,
+                                       str(tmp_path), str(n_bands), str(int(narrow)), "cpu", shard_by,
+                                       str(int(replicate))], env=e,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\\n".join(outs)
@@ -64,3 +65,49 @@ def test_two_rank_banded_overlapped_reduce(tmp_path, port, narrow):
     for z in run_world(tmp_path, str(fx), 3, narrow, 29613 + int(narrow)):
         assert np.array_equal(z["counts"], want)
         assert np.array_equal(z["tri"], port.normalise(want.astype(np.float64), N))
+
+
+def test_owner_edges():
+    from fastsk_amd.distributed import owner_edges, sub_edges, cell
+    e = owner_edges(100000, 8)
+    assert len(e) == 9 and e[0] == 0 and e[-1] == 100000
+    assert owner_edges(300, 8) is None and owner_edges(300, 2) == [0, 256, 300]
+    s = sub_edges(e[3], e[4], 4)
+    assert s[0] == e[3] and s[-1] == e[4] and all(x % 128 == 0 for x in s[:-1])
+    areas = np.diff([cell(x) for x in s])
+    assert areas.max() / areas.min() < 1.2
+
+
+@pytest.mark.parametrize("replicate,narrow", [(False, False), (True, False), (True, True)])
+def test_two_rank_row_sharded(tmp_path, port, replicate, narrow):
+    """shard_by="rows": each rank runs all combos over its own rows; only the diagonal is exchanged
+    (or the finished bands are broadcast when replicate=True)."""
+    from fastsk_amd.distributed import owner_edges, cell
+    rng = np.random.default_rng(9)
+    N = 420
+    X = rng.integers(1, 5, size=(N, 36), dtype=np.int32)
+    tokens, offsets = X.reshape(-1), np.arange(N + 1, dtype=np.int64) * 36
+    combos = np.arange(0, 70, 6, dtype=np.int32)
+    fx = tmp_path / "in.npz"
+    np.savez(fx, tokens=tokens, offsets=offsets, n_train=300, n_test=120, g=8, m=4, combos=combos)
+    want, _, _ = port.raw_counts(tokens, offsets, 8, 4, combos, threads=4)
+    tri = port.normalise(want.astype(np.float64), N)
+    full = np.zeros((N, N))
+    il = np.tril_indices(N)
+    full[il] = tri
+    full = full + full.T - np.diag(np.diag(full))
+    zs = run_world(tmp_path, str(fx), 2, narrow, 29631 + 2 * int(replicate) + int(narrow), "rows", replicate)
+    edges = owner_edges(N, 2)
+    diag = np.array([cell(i) + i for i in range(N)])
+    for r, z in enumerate(zs):
+        assert np.array_equal(z["full"], full)  # assembled block: bit-identical normalised kernel on every rank
+        if replicate:
+            assert np.array_equal(z["counts"], want)
+        else:
+            lo, hi = cell(edges[r]), cell(edges[r + 1])
+            assert np.array_equal(z["counts"][lo:hi], want[lo:hi])  # own rows complete
+            assert np.array_equal(z["counts"][diag], want[diag])    # diagonal exchanged
+            other = np.ones(len(want), bool)
+            other[lo:hi] = False
+            other[diag] = False
+            assert not z["counts"][other].any()                      # nothing else touched

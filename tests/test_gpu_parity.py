@@ -348,6 +348,39 @@ def test_two_ranks_sharing_the_gpu_banded_reduce(native, port, tmp_path, narrow)
     assert done == len(combos)
 
 
+@pytest.mark.parametrize("replicate", [0, 1])
+def test_two_ranks_sharing_the_gpu_row_sharded(native, port, tmp_path, replicate):
+    """shard_by="rows" with the REAL engine: two processes on cuda:0, each runs all combos over its
+    own band of rows; only the diagonal is exchanged (or finished bands are broadcast)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from fastsk_amd.distributed import owner_edges, cell
+    N, L, g, m = 1500, 120, 10, 6
+    tokens, offsets = synthetic_dna(N, L, seed=11)
+    combos = np.arange(0, 210, 7, dtype=np.int32)
+    fx = tmp_path / "in.npz"
+    np.savez(fx, tokens=tokens, offsets=offsets, n_train=N, n_test=0, g=g, m=m, combos=combos)
+    want, _, _ = port.raw_counts(tokens, offsets, g, m, combos, threads=8)
+    tri = port.normalise(want.astype(np.float64), N)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29711 + replicate), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(fx), str(tmp_path), "3",
+                               "1", "cuda:0", "rows", str(replicate)], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    edges = owner_edges(N, 2)
+    il = np.tril_indices(N)
+    for r in range(2):
+        z = np.load(tmp_path / ("rank%d.npz" % r))
+        assert np.array_equal(z["full"][il], tri)          # assembled from the owners: bit-identical
+        assert np.array_equal(z["full"], z["full"].T)
+        lo, hi = cell(edges[r]), cell(edges[r + 1])
+        assert np.array_equal(z["counts"][lo:hi], want[lo:hi])
+        if replicate:
+            assert np.array_equal(z["counts"], want)
+
+
 @pytest.mark.parametrize("global_pairs", ["0", "1"])
 def test_sparse_pair_accumulation_variants(native, port, monkeypatch, global_pairs):
     """Protein-like input through the sparse dataflow with owner-slice LDS accumulation and with
