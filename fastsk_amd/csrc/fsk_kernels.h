@@ -149,6 +149,21 @@ __device__ __forceinline__ void count_windows_k(const uint8_t* symT, uint32_t* h
     }
 }
 
+// Eight consecutive keys' counts of lane r's sequence -> one dword of lo nibbles and one of hi
+// nibbles; `seen` collects every count (a bit above bit 7 = some count exceeded 255).
+template <bool TAIL>
+__device__ __forceinline__ void pack_count_row(const uint16_t* hist16, uint32_t key0, uint32_t key_n, uint32_t r, uint32_t& plo,
+                                               uint32_t& phi, uint32_t& seen) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const uint32_t key = key0 + q;
+        const uint32_t c = (!TAIL || key < key_n) ? (uint32_t)hist16[key * 64u + r] : 0u;
+        seen |= c;
+        plo |= (c & 15u) << (4 * q);
+        phi |= ((c >> 4) & 15u) << (4 * q);
+    }
+}
+
 // Per-sequence counting sort of the k-mers selected by each combo ("segment counts").
 // grid = (n_panels, n_chunks), block = 256 (wave w takes windows j = w mod 4; lane = sequence).
 // dynamic LDS: symT[CH+g-1][64] u8 | hist[4*Vcq][32] u32 (two u16 counters per dword) | lut[V] u16.
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
     const uint32_t half = (uint32_t)(r & 1) * 16u;
     const uint32_t Vq8 = (Vq + 1u) >> 1;
     const uint32_t Vw = (V + 31u) >> 5;  // words of the key bitmap
-    bool ovf = false;
+    uint32_t seen = 0;  // OR of every count read out: a bit above bit 7 means some count exceeded 255
     for (int slot = slot0; slot < slot1; ++slot) {
         if (!MARK) {
             __syncthreads();  // previous combo's mask written out
@@ -240,17 +255,14 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
             }
             // read-out: 8 keys per dword row, lo and hi nibbles (Vcq is even, so a sweep starts on
             // an 8-key boundary); one 256-B row per wave and plane
+            // (lane r's 16-bit counter of `key` is halfword key*64 + r of the histogram; only the
+            // last row of an odd number of key quads has keys to mask out)
             const uint32_t n8 = ((key_n >> 2) + 1u) >> 1;
+            const uint16_t* hist16 = reinterpret_cast<const uint16_t*>(hist);
             for (uint32_t k8 = w; k8 < n8; k8 += 4) {
                 uint32_t plo = 0, phi = 0;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const uint32_t key = 8u * k8 + q;
-                    const uint32_t c = key < key_n ? (hist[key * 32u + (uint32_t)(r >> 1)] >> half) & 0xffffu : 0u;
-                    ovf |= c > 255u;
-                    plo |= (c & 15u) << (4 * q);
-                    phi |= ((c >> 4) & 15u) << (4 * q);
-                }
+                if (8u * k8 + 8u <= key_n) pack_count_row<false>(hist16, 8u * k8, key_n, (uint32_t)r, plo, phi, seen);
+                else pack_count_row<true>(hist16, 8u * k8, key_n, (uint32_t)r, plo, phi, seen);
                 const uint32_t row = (kc0 >> 1) + k8;
                 out4[(size_t)row * PANEL + panel_slot(r)] = plo;
                 out4h[(size_t)row * PANEL + panel_slot(r)] = phi;
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
             if ((uint32_t)tid < nst) rowmask[((size_t)panel * n_slots + slot) * nst + tid] = srowmask[tid];
         }
     }
-    if (!MARK && ovf) atomicOr(overflow_flag, 1u);
+    if (!MARK && seen > 255u) atomicOr(overflow_flag, 1u);
 }
 
 // Key compaction table of one combo: rank of every key that occurs, 0xFFFF otherwise; vc = how

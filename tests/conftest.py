@@ -72,3 +72,14 @@ def ref():
     if not loader.have_ref():
         pytest.skip("compiled reference (oracle/_ref) not present")
     return loader.ref()
+
+
+# degenerate shapes the reference accepts: (sequences, n_train, n_test, g, m)
+EDGE_CASES = [
+    ([[1, 2, 3, 4, 1, 2]], 1, 0, 6, 2),                                  # N = 1, one window
+    ([[1, 2, 3, 4, 1, 2], [2, 2, 3, 4, 1, 2], [1, 2, 3, 4, 1, 1]], 2, 1, 6, 2),   # every length == g
+    ([[3, 1, 4, 1, 5, 2, 2, 6]] * 5, 3, 2, 5, 2),                        # identical sequences -> all ones
+    ([[1, 2, 1, 2, 1, 2, 1], [2, 1, 2, 1, 2, 1, 2, 1, 2]], 1, 1, 4, 3),  # k = 1
+    ([[1, 1, 1, 1, 1], [2, 2, 2, 2, 2, 2]], 1, 1, 3, 1),                 # nothing shared: zero off-diagonal
+    ([list(range(1, 30)), list(range(5, 40)), list(range(1, 12))], 2, 1, 11, 0),  # m = 0: one combo, plain 11-mers
+]

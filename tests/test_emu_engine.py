@@ -146,6 +146,25 @@ def test_emu_error_convention(emu_lib):
     assert e.get_train()[0, 0] == 1.0
 
 
+def test_emu_edge_cases(emu_lib, port):
+    from fastsk_amd import _native
+    from conftest import EDGE_CASES
+    for X, ntr, nte, g, m in EDGE_CASES:
+        tokens, offsets = _native.flatten(X)
+        want, _, _ = port.compute(tokens, offsets, ntr, nte, g, m, t=1)
+        for path in (0, 1, 2):
+            if path == 1 and len(np.unique(tokens)) ** (g - m) > 16384:
+                continue
+            e = _native.Engine(g, m, path=path, lib=emu_lib)
+            e.compute(tokens, offsets, ntr, nte)
+            assert np.array_equal(e.get_triangle(), want), (X, g, m, path)
+            assert e.get_test().shape == (nte, ntr)
+            e.close()
+    with pytest.raises(_native.FskError) as ei:
+        _native.Engine(6, 2, lib=emu_lib).compute(np.zeros(0, np.int32), np.zeros(1, np.int64), 0, 0)
+    assert ei.value.code == -1
+
+
 def test_emu_relabelled_and_wide_alphabets(emu_lib, port):
     from fastsk_amd import _native
     d = load_golden("f3_ragged_sigma7_g6m3")

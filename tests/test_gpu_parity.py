@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import golden_names, load_golden, load_tokens, tri_to_square, synthetic_dna, GOLD
+from conftest import golden_names, load_golden, load_tokens, tri_to_square, synthetic_dna, GOLD, EDGE_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -274,6 +274,46 @@ def test_pybind_surface_on_gpu(native):
         FastSK(g=101, m=99).compute_train(X[:10])  # g > shortest (100): the reference exit(1)s
     with pytest.raises(NotImplementedError):
         f.fit()
+
+
+def test_edge_cases_and_error_convention(native, port):
+    """Degenerate shapes the reference accepts (one sequence, sequences of exactly g symbols, all
+    sequences equal, m = g - 1, a single combo) and the situations where it exits: status codes."""
+    for X, ntr, nte, g, m in EDGE_CASES:
+        tokens, offsets = native.flatten(X)
+        want, _, _ = port.compute(tokens, offsets, ntr, nte, g, m, t=1)
+        for path in (0, 1, 2):
+            sigma = len(np.unique(tokens))
+            if path == 1 and sigma ** (g - m) > 16384:
+                continue
+            e = native.Engine(g, m, path=path)
+            e.compute(tokens, offsets, ntr, nte)
+            assert np.array_equal(e.get_triangle(), want), (X, g, m, path)
+            assert e.get_test().shape == (nte, ntr)
+            e.close()
+    with pytest.raises(native.FskError) as ei:      # m must be < g
+        native.Engine(3, 3)
+    assert ei.value.code == -1
+    e = native.Engine(6, 2)
+    tok, off = native.flatten([[1, 2, 3, 4, 1, 2, 3], [1, 2, 3, 4, 1]])
+    with pytest.raises(native.FskError) as ei:      # reference: printf + exit(1), fastsk.cpp:53-58
+        e.compute(tok, off, 1, 1)
+    assert ei.value.code == -2 and "shortest test sequence has length 5" in str(ei.value)
+    with pytest.raises(native.FskError) as ei:      # nothing computed yet
+        e.get_train()
+    assert ei.value.code == -3
+    with pytest.raises(native.FskError) as ei:      # no sequences at all
+        e.compute(np.zeros(0, np.int32), np.zeros(1, np.int64), 0, 0)
+    assert ei.value.code == -1
+    tok, off = native.flatten([[1, 2, 3, 4, 1, 2, 3], [1, 2, 3, 4, 1, 4]])
+    e.load_sequences(tok, off, 2, 0)
+    with pytest.raises(native.FskError) as ei:      # combo id out of range (C(6,2) = 15)
+        e.accumulate([15])
+    assert ei.value.code == -1
+    e.accumulate(np.arange(15))
+    e.finalize()
+    assert e.get_test().shape == (0, 2) and e.get_train()[0, 0] == 1.0
+    e.close()
 
 
 def test_device_resident_block_getter(native):

@@ -149,6 +149,18 @@ def test_port_matches_compiled_reference_fresh_inputs(port, ref):
         assert np.array_equal(tri_r, tri_p) and np.array_equal(sd_r, sd_p)
 
 
+def test_port_matches_compiled_reference_edge_cases(port, ref):
+    """The degenerate shapes the engine tests use (conftest.EDGE_CASES): one sequence, lengths == g,
+    identical sequences, k = 1, nothing shared, m = 0."""
+    from conftest import EDGE_CASES
+    from fastsk_amd import _native
+    for X, ntr, nte, g, m in EDGE_CASES:
+        tokens, offsets = _native.flatten(X)
+        tri_r, _ = ref.full_triangle(tokens, offsets, ntr, nte, g, m, t=1)
+        tri_p, _, _ = port.compute(tokens, offsets, ntr, nte, g, m, t=1)
+        assert np.array_equal(tri_r, tri_p), (X, g, m)
+
+
 def test_fasta_reader_matches_reference_tokens(tmp_path):
     """fastsk_amd.utils.FastaUtility reproduces the reference reader's ids (shared vocab,
     lower-casing, first-seen order from 1) — checked on a file that exercises each rule."""
