@@ -90,6 +90,19 @@ __device__ __forceinline__ uint32_t panel_slot(uint32_t r) { return ((r & 15u) <
 // tile-local row/column (0..127) of register e (0..7) of lane group t (0..15): inverse of the above
 __device__ __forceinline__ uint32_t tile_index(uint32_t t, uint32_t e) { return (e >> 2) * 64u + t + 16u * (e & 3u); }
 
+// a * b + c with 24-bit operands: v_mad_u32_u24 issues at full rate, a 32-bit multiply-add does
+// not (the compiler turns __umul24 of small known ranges back into one, hence the asm).
+// b is wave-uniform.
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
+#ifdef FSK_EMU
+    return (a & 0xffffffu) * (b & 0xffffffu) + c;
+#else
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+    return d;
+#endif
+}
+
 // One wave's share of the windows [j0, hi) of a staging chunk: key from K kept positions held
 // in registers (K is a template parameter so the K LDS byte reads of a window are independent
 // and issue back to back; K = 0 is the generic loop for k > 8). MARK: only record which keys
@@ -104,7 +117,7 @@ __device__ __forceinline__ void count_windows(const uint8_t* symT, uint32_t* his
                                               int kmode) {
     for (uint32_t j = j0; j < hi; j += 4) {
         if (j < nwin) {
-            uint32_t key = 0;
+            uint32_t key = 0;  // keys stay below 2^24 on this path (V <= 16384): 24-bit multiplies issue at full rate
             if (!MARK && kmode == 2) {  // workgroup-uniform
                 key = kcache[j * PANEL + r];
                 key -= key_lo;
@@ -113,11 +126,11 @@ __device__ __forceinline__ void count_windows(const uint8_t* symT, uint32_t* his
             }
             if (K > 0) {
 #pragma unroll
-                for (int c = 0; c < K; ++c) key = key * sigma + symT[(j - cb + pr[c]) * PANEL + r];
+                for (int c = 0; c < K; ++c) key = mad24(key, sigma, symT[(j - cb + pr[c]) * PANEL + r]);
             } else {
 #pragma unroll
                 for (int c = 0; c < 16; ++c)
-                    if (c < k) key = key * sigma + symT[(j - cb + pr[c]) * PANEL + r];
+                    if (c < k) key = mad24(key, sigma, symT[(j - cb + pr[c]) * PANEL + r]);
             }
             if (MARK) {
                 atomicOr(&hist[key >> 5], 1u << (key & 31u));  // hist doubles as the key bitmap

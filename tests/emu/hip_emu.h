@@ -227,6 +227,7 @@ template <typename T> static inline T __shfl_xor(T v, int m) { return __shfl(v, 
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 static inline int __ffs(int x) { return __builtin_ffs(x); }
 static inline unsigned __builtin_amdgcn_readfirstlane(unsigned x) { return x; }
 static inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
