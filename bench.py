@@ -162,7 +162,10 @@ def main():
         torch.cuda.synchronize()
 
     def step(how=mode):
-        eng.reset_counts()
+        if use_dist and how == "rows" and not args.replicate:
+            eng.reset_counts_rows(*edges[rank:rank + 2])  # a rank only ever writes (and zeroes) the rows it owns
+        else:
+            eng.reset_counts()
         if use_dist and how == "rows":
             # every combo over this rank's rows; only the diagonal is exchanged
             distributed.accumulate_owned_rows(eng, K, every, replicate=args.replicate, n_sub=args.bands, edges=edges)
@@ -177,6 +180,7 @@ def main():
         eng.finalize()
 
     def timed(how, warmup, steps):
+        eng.reset_counts()  # whatever the other decomposition left in K (untimed)
         for _ in range(warmup):
             step(how)
         barrier()

@@ -50,7 +50,7 @@ class Stats(C.Structure):
 # every symbol include/fastsk_amd.h declares (checked by tests/test_abi.py)
 SYMBOLS = ["fsk_create", "fsk_destroy", "fsk_last_error", "fsk_abi_version", "fsk_device_count", "fsk_compute",
            "fsk_set_combo_order", "fsk_set_seed", "fsk_load_sequences", "fsk_bind_counts",
-           "fsk_counts_device_ptr", "fsk_reset_counts", "fsk_accumulate", "fsk_accumulate_rows", "fsk_synchronize", "fsk_finalize",
+           "fsk_counts_device_ptr", "fsk_reset_counts", "fsk_reset_counts_rows", "fsk_accumulate", "fsk_accumulate_rows", "fsk_synchronize", "fsk_finalize",
            "fsk_get_block", "fsk_get_block_device", "fsk_get_train", "fsk_get_test", "fsk_get_triangle", "fsk_get_counts",
            "fsk_get_counts_block", "fsk_get_stdevs", "fsk_save_kernel", "fsk_get_stats", "fsk_num_combos",
            "fsk_combo_positions"]
@@ -81,6 +81,7 @@ class Library:
             "fsk_bind_counts": ([vp, vp, i64], C.c_int),
             "fsk_counts_device_ptr": ([vp, C.POINTER(vp)], C.c_int),
             "fsk_reset_counts": ([vp], C.c_int),
+            "fsk_reset_counts_rows": ([vp, i64, i64], C.c_int),
             "fsk_accumulate": ([vp, vp, i32], C.c_int),
             "fsk_accumulate_rows": ([vp, vp, i32, i64, i64], C.c_int),
             "fsk_synchronize": ([vp], C.c_int),
@@ -210,6 +211,9 @@ class Engine:
 
     def reset_counts(self):
         self._ck(self.lib.L.fsk_reset_counts(self.h))
+
+    def reset_counts_rows(self, row_begin, row_end):
+        self._ck(self.lib.L.fsk_reset_counts_rows(self.h, row_begin, row_end))
 
     def accumulate(self, combos):
         combos = np.ascontiguousarray(combos, dtype=np.int32)

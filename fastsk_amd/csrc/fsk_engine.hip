@@ -990,6 +990,19 @@ int fsk_reset_counts(fsk_engine* e) {
     return FSK_OK;
 }
 
+int fsk_reset_counts_rows(fsk_engine* e, int64_t row_begin, int64_t row_end) {
+    if (!e) return FSK_EINVAL;
+    if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
+    if (row_begin < 0 || row_end > e->N || row_begin > row_end) return e->fail(FSK_EINVAL, "bad row range");
+    FSK_HIP(hipSetDevice(e->cfg.device));
+    const u64 c0 = (u64)row_begin * ((u64)row_begin + 1) / 2, c1 = (u64)row_end * ((u64)row_end + 1) / 2;
+    if (c1 > c0) FSK_HIP(hipMemsetAsync(e->d_K + c0, 0, (size_t)(c1 - c0) * sizeof(u64), e->stream));
+    e->finalized = false; e->result_f64 = false;
+    e->st.combos_done = 0;
+    e->prep_valid = false;
+    return FSK_OK;
+}
+
 int fsk_accumulate(fsk_engine* e, const int32_t* combos, int32_t n) {
     if (!e) return FSK_EINVAL;
     if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");

@@ -98,7 +98,9 @@ def accumulate_owned_rows(eng, K, combos, group=None, replicate=False, n_sub=Non
         eng.accumulate_rows(combos, lo, hi)
         eng.synchronize()
         idx = diag_index(N, K.device)
-        d = K[idx]  # zero outside [lo, hi): the sum over ranks is the full diagonal
+        d = K[idx]
+        d[:lo] = 0  # entries of other ranks' rows may still hold the previous pass's exchange
+        d[hi:] = 0
         dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)
         K[idx] = d
         if K.is_cuda:

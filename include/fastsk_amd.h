@@ -132,6 +132,8 @@ int fsk_bind_counts(fsk_engine* e, void* device_u64, int64_t n_cells);
 /* device address of the integer triangle (engine-owned or bound) */
 int fsk_counts_device_ptr(fsk_engine* e, void** out);
 int fsk_reset_counts(fsk_engine* e);
+/* zero only rows [row_begin, row_end) of the triangle (a rank that owns a band of rows) */
+int fsk_reset_counts_rows(fsk_engine* e, int64_t row_begin, int64_t row_end);
 /* THE HOT PATH. Adds the partial kernels of the listed combos into the integer triangle:
  * the loop body of kernel_build_parallel (fastsk_kernel.cpp:188-281) for each combo, and the
  * K += Ks reduce (fastsk_kernel.cpp:286-315). Asynchronous on the engine's stream. */

@@ -29,6 +29,13 @@ def main():
                                          shard_by=sys.argv[6] if len(sys.argv) > 6 else "combos",
                                          replicate=bool(int(sys.argv[7])) if len(sys.argv) > 7 else True)
     N = int(d["n_train"]) + int(d["n_test"])
+    if len(sys.argv) > 7 and sys.argv[6] == "rows" and not int(sys.argv[7]):
+        # a second pass on the same engine, zeroing only the owned rows: the diagonal entries of
+        # the other ranks' rows still hold the first pass's exchange and must not be summed again
+        lo, hi = distributed.owner_edges(N, world)[rank:rank + 2]
+        eng.reset_counts_rows(lo, hi)
+        distributed.accumulate_owned_rows(eng, K, d["combos"].astype(np.int32))
+        eng.finalize()
     full = distributed.get_block_distributed(eng, 0, N, 0, N, device=device).cpu().numpy()  # == local block when replicated
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), counts=K.cpu().numpy().view(np.uint64), tri=eng.get_triangle(),
              done=eng.stats()["combos_done"], world=world, full=full)
