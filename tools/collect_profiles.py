@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof/ (written by tools/refresh_profiles.sh on the GPU box) into the tracked
+files under profiles/: kernel stats CSV, the bench JSON lines, the per-dispatch HBM counters and
+traffic.json (what bench.py reports as roofline.traffic)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof")
+DST = os.path.join(ROOT, "profiles")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def json_line(path):
+    for line in open(path):
+        if line.startswith("{"):
+            return line
+    raise SystemExit("no JSON line in " + path)
+
+
+def main():
+    open(os.path.join(DST, TAG + "_bench100k.json"), "w").write(json_line(os.path.join(SRC, "bench.json")))
+    open(os.path.join(DST, TAG + "_bench100k_under_rocprof.json"), "w").write(json_line(os.path.join(SRC, "bench_under_rocprof.json")))
+    stats = glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv"))
+    shutil.copy(stats[0], os.path.join(DST, TAG + "_kernel_stats_bench100k.csv"))
+    rows = []
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(SRC, "pmc_" + counter)
+        cc = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
+        kt = glob.glob(os.path.join(d, "*", "*_kernel_trace.csv"))[0]
+        dur = {}
+        for r in csv.DictReader(open(kt)):
+            dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        for r in csv.DictReader(open(cc)):
+            if r["Counter_Name"] != counter or "fsk::" not in r["Kernel_Name"]:
+                continue
+            rows.append({"counter": counter, "kernel": r["Kernel_Name"].split("(")[0], "value_KiB": float(r["Counter_Value"]),
+                         "duration_ms": dur.get(r["Dispatch_Id"]), "grid": int(r["Grid_Size"]), "vgpr": int(r["VGPR_Count"]),
+                         "lds": int(r["LDS_Block_Size"])})
+    out = {"command": "cd /tmp; rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- python3 bench.py "
+                      "--steps 1 --warmup 0 --no-cpu-baseline --no-also (one pass per counter; tools/refresh_profiles.sh)",
+           "note": "values are KiB; on gfx950 FETCH_SIZE reads 1/2 of 16-B/lane streaming reads (MI355X_MICROARCH.md HBM "
+                   "section): double it before comparing with bytes", "rows": rows}
+    json.dump(out, open(os.path.join(DST, TAG + "_pmc_bench100k.json"), "w"), indent=1)
+    tile = lambda c: max(r["value_KiB"] for r in rows if r["counter"] == c and r["kernel"].endswith("k_dense_tile"))
+    bench = json.loads(json_line(os.path.join(SRC, "bench.json")))
+    fetch, write = tile("FETCH_SIZE") * 1024 * 2, tile("WRITE_SIZE") * 1024
+    json.dump({"n_seq": bench["config"]["n_seq"], "combos_per_launch": int(bench["roofline"]["combos_per_launch"]),
+               "kernel": "fsk::k_dense_tile", "fetch_bytes_corrected": fetch, "write_bytes": write,
+               "hbm_bytes_per_launch": fetch + write,
+               "source": "profiles/%s_pmc_bench100k.json (the 495-combo launch): FETCH_SIZE KiB x1024 x2 (gfx950 correction) + "
+                         "WRITE_SIZE KiB x1024" % TAG}, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
+    for src, dst in (("configs.jsonl", TAG + "_configs1-4_gpu_timings.jsonl"), ("large_g.jsonl", TAG + "_large_g_regime.jsonl")):
+        lines = [l for l in open(os.path.join(SRC, src)) if l.startswith("{")]
+        if lines:
+            open(os.path.join(DST, dst), "w").writelines(lines)
+    print("profiles/ refreshed from", SRC)
+
+
+if __name__ == "__main__":
+    main()
