@@ -25,10 +25,10 @@ def test_shard_partition():
     assert band_edges(300, 8) == [0, 128, 256, 300] or band_edges(300, 8)[-1] == 300
 
 
-def run_world(tmp_path, fixture, n_bands, narrow, port_no, shard_by="combos", replicate=True):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_no), WORLD_SIZE="2")
+def run_world(tmp_path, fixture, n_bands, narrow, port_no, shard_by="combos", replicate=True, world=2):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_no), WORLD_SIZE=str(world))
     procs = []
-    for rank in range(2):
+    for rank in range(world):
         e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), fixture,
                                        str(tmp_path), str(n_bands), str(int(narrow)), "cpu", shard_by,
@@ -36,7 +36,7 @@ def run_world(tmp_path, fixture, n_bands, narrow, port_no, shard_by="combos", re
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\\n".join(outs)
-    return [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(2)]
+    return [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
 
 
 def test_two_rank_gloo_all_reduce(tmp_path):
@@ -111,3 +111,27 @@ def test_two_rank_row_sharded(tmp_path, port, replicate, narrow):
             other[lo:hi] = False
             other[diag] = False
             assert not z["counts"][other].any()                      # nothing else touched
+
+
+@pytest.mark.parametrize("shard_by", ["rows", "combos"])
+def test_four_ranks(tmp_path, port, shard_by):
+    """World size 4 (nothing in the host path may be specific to two ranks): row ownership without
+    replication, and the banded all-reduce."""
+    from fastsk_amd.distributed import owner_edges
+    rng = np.random.default_rng(10)
+    N = 600
+    assert owner_edges(N, 4) == [0, 256, 384, 512, 600]
+    X = rng.integers(1, 5, size=(N, 30), dtype=np.int32)
+    tokens, offsets = X.reshape(-1), np.arange(N + 1, dtype=np.int64) * 30
+    combos = np.array([0, 17, 33, 50, 69], dtype=np.int32)
+    fx = tmp_path / "in.npz"
+    np.savez(fx, tokens=tokens, offsets=offsets, n_train=N, n_test=0, g=8, m=4, combos=combos)
+    want, _, _ = port.raw_counts(tokens, offsets, 8, 4, combos, threads=4)
+    tri = port.normalise(want.astype(np.float64), N)
+    il = np.tril_indices(N)
+    zs = run_world(tmp_path, str(fx), 2, True, 29641 + (shard_by == "rows"), shard_by, False, world=4)
+    for z in zs:
+        assert int(z["world"]) == 4
+        assert np.array_equal(z["full"][il], tri)
+        if shard_by == "combos":
+            assert np.array_equal(z["counts"], want)
