@@ -28,7 +28,7 @@ class Config(C.Structure):
     _fields_ = [("g", C.c_int32), ("m", C.c_int32), ("t", C.c_int32), ("approx", C.c_int32),
                 ("delta", C.c_double), ("max_iters", C.c_int32), ("skip_variance", C.c_int32),
                 ("device", C.c_int32), ("path", C.c_int32), ("profile", C.c_int32),
-                ("reserved", C.c_int32 * 5)]
+                ("skip_test_block", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class Stats(C.Structure):
@@ -148,10 +148,11 @@ class Engine:
     """One engine handle = one device, one HIP stream. Mirrors the C ABI one to one."""
 
     def __init__(self, g, m, t=-1, approx=False, delta=0.025, max_iters=-1, skip_variance=False, device=0,
-                 path=PATH_AUTO, profile=False, lib=None):
+                 path=PATH_AUTO, profile=False, lib=None, skip_test_block=False):
         self.lib = lib or library()
         cfg = Config(g=g, m=m, t=t, approx=int(bool(approx)), delta=delta, max_iters=max_iters,
-                     skip_variance=int(bool(skip_variance)), device=device, path=path, profile=int(bool(profile)))
+                     skip_variance=int(bool(skip_variance)), device=device, path=path, profile=int(bool(profile)),
+                     skip_test_block=int(bool(skip_test_block)))
         h = C.c_void_p()
         rc = self.lib.L.fsk_create(C.byref(cfg), C.byref(h))
         if rc:

@@ -83,8 +83,9 @@ class FastSK {
 
 public:
     FastSK(int g, int m, int t, bool approx, double delta, int max_iters, bool skip_variance, int device,
-           const std::string& path, py::object seed) {
+           const std::string& path, py::object seed, bool skip_test_block) {
         fsk_config c{};
+        c.skip_test_block = skip_test_block;
         c.g = g; c.m = m; c.t = t; c.approx = approx; c.delta = delta; c.max_iters = max_iters;
         c.skip_variance = skip_variance; c.device = device; c.path = parse_path(path);
         int rc = fsk_create(&c, &h_);
@@ -207,10 +208,10 @@ public:
 PYBIND11_MODULE(_fastsk, m) {
     m.doc() = "MI355X-native gapped-k-mer kernel engine behind the FastSK Python surface";
     py::class_<FastSK>(m, "FastSK")
-        .def(py::init<int, int, int, bool, double, int, bool, int, const std::string&, py::object>(),
+        .def(py::init<int, int, int, bool, double, int, bool, int, const std::string&, py::object, bool>(),
              py::arg("g"), py::arg("m"), py::arg("t") = -1, py::arg("approx") = false, py::arg("delta") = 0.025,
              py::arg("max_iters") = -1, py::arg("skip_variance") = false, py::arg("device") = 0,
-             py::arg("path") = "auto", py::arg("seed") = py::none())
+             py::arg("path") = "auto", py::arg("seed") = py::none(), py::arg("skip_test_block") = false)
         .def("compute_kernel", &FastSK::compute_kernel_np, py::arg("Xtrain").noconvert(), py::arg("Xtest").noconvert())
         .def("compute_kernel", &FastSK::compute_kernel, py::arg("Xtrain"), py::arg("Xtest"))
         .def("compute_kernel_flat", &FastSK::compute_kernel_flat, py::arg("tokens").noconvert(), py::arg("offsets").noconvert(),

@@ -370,7 +370,10 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
 // super-tiles are dealt to 8 queues (one per XCD, balanced by tile count); block b = 8q + x takes
 // the q-th tile of queue x, because the dispatcher is observed to place blocks b, b+8, ... on one
 // XCD (placement only changes speed, never results).
-void build_tile_table(uint32_t t0, uint32_t t1, std::vector<uint32_t>& tab) {
+// `first_test_tile` (skip_test_block): tiles whose columns are all test sequences and that are not
+// on the diagonal hold only test x test cells, which no getter of the reference exposes; they are
+// left out (tile granularity: a tile that straddles the train/test boundary is kept).
+void build_tile_table(uint32_t t0, uint32_t t1, uint32_t first_test_tile, std::vector<uint32_t>& tab) {
     constexpr uint32_t S = 8;
     std::vector<std::vector<uint32_t>> q(8);
     for (uint32_t si = t0 / S; si * S < t1; ++si)
@@ -379,7 +382,8 @@ void build_tile_table(uint32_t t0, uint32_t t1, std::vector<uint32_t>& tab) {
             for (size_t x = 1; x < 8; ++x)
                 if (q[x].size() < q[best].size()) best = x;
             for (uint32_t ti = std::max(si * S, t0); ti < std::min((si + 1) * S, t1); ++ti)
-                for (uint32_t tj = sj * S; tj < (sj + 1) * S && tj <= ti; ++tj) q[best].push_back(ti << 16 | tj);
+                for (uint32_t tj = sj * S; tj < (sj + 1) * S && tj <= ti; ++tj)
+                    if (tj < first_test_tile || tj == ti) q[best].push_back(ti << 16 | tj);
         }
     size_t total = 0, pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (auto& v : q) total += v.size();
@@ -400,8 +404,10 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
     const uint32_t panels_pad = (e->n_panels + 1u) & ~1u;  // tiles are 2x2 panels
     const uint32_t t0 = (uint32_t)(row0 / fsk::TILE), t1 = (uint32_t)((row1 + fsk::TILE - 1) / fsk::TILE);
     if (t1 > 0xffffu) return e->fail(FSK_EUNSUPPORTED, "more than 65535 tile rows");
-    const u64 n_tiles = (u64)t1 * (t1 + 1) / 2 - (u64)t0 * (t0 + 1) / 2;
-    if (n_tiles == 0) return FSK_OK;
+    if (t1 <= t0) return FSK_OK;
+    // skip_test_block: first tile column made of test sequences only (none when not asked for)
+    const uint32_t first_test_tile = e->cfg.skip_test_block && e->n_test > 0
+                                         ? (uint32_t)((e->n_train + fsk::TILE - 1) / fsk::TILE) : 0xffffffffu;
     const uint32_t Vq8 = (e->Vq + 1u) / 2u;                               // dword rows: 8 keys (nibbles) each
     const uint32_t nst = (Vq8 + fsk::STAGE_KQ - 1) / fsk::STAGE_KQ;      // 32-row stages per combo
     const size_t slot_dwords4 = (size_t)panels_pad * Vq8 * fsk::PANEL;    // dwords of one plane per combo
@@ -426,13 +432,15 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
     FSK_HIP(e->d_pos.reserve((size_t)chunk * e->k));
     if (e->tab_t0 != t0 || e->tab_t1 != t1 || e->tab_n == 0) {
         std::vector<uint32_t> tab;
-        build_tile_table(t0, t1, tab);
-        if (tab.size() != n_tiles) return e->fail(FSK_EDEVICE, "internal: tile table size mismatch");
+        build_tile_table(t0, t1, first_test_tile, tab);
+        if (first_test_tile == 0xffffffffu && tab.size() != (u64)t1 * (t1 + 1) / 2 - (u64)t0 * (t0 + 1) / 2)
+            return e->fail(FSK_EDEVICE, "internal: tile table size mismatch");
         FSK_HIP(e->d_tiletab.reserve(tab.size()));
         FSK_HIP(hipMemcpyAsync(e->d_tiletab.p, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
         FSK_HIP(hipStreamSynchronize(e->stream));
         e->tab_t0 = t0; e->tab_t1 = t1; e->tab_n = (uint32_t)tab.size();
     }
+    const u64 n_tiles = e->tab_n;
     const bool compact = e->compact;
     const uint32_t Vkeys = (uint32_t)e->V, Vw = (Vkeys + 31u) / 32u;
     DensePlan plan = dense_plan(e->maxW, e->cfg.g, e->Vq, compact ? (size_t)Vkeys * 2 : 0);  // may be re-planned below

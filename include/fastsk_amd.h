@@ -65,7 +65,11 @@ typedef struct fsk_config {
     int32_t device;        /* HIP device ordinal                                                */
     int32_t path;          /* FSK_PATH_*                                                        */
     int32_t profile;       /* 1: time every kernel family with HIP events (fsk_get_stats)       */
-    int32_t reserved[5];
+    int32_t skip_test_block; /* 1: cells with both sequences in the test set (other than the diagonal)
+                                may be left at zero — no getter of the reference exposes them
+                                (fastsk.cpp:190-217). Dense dataflow: whole tiles of such cells
+                                are not computed; the sparse dataflow computes everything.     */
+    int32_t reserved[4];
 } fsk_config;
 
 /* Measured and algorithmic quantities of the work done so far. */

@@ -165,6 +165,23 @@ def test_emu_edge_cases(emu_lib, port):
     assert ei.value.code == -1
 
 
+def test_emu_skip_test_block(emu_lib, port):
+    from fastsk_amd import _native
+    rng = np.random.default_rng(4)
+    N, ntr = 400, 100   # first all-test tile column = 1: cells with column >= 128 off the diagonal tiles
+    X = rng.integers(1, 5, size=(N, 24), dtype=np.int32)
+    tokens, offsets = X.reshape(-1), np.arange(N + 1, dtype=np.int64) * 24
+    want, _, _ = port.compute(tokens, offsets, ntr, N - ntr, 7, 4, t=1)
+    sq = tri_to_square(want, N)
+    e = _native.Engine(7, 4, path=1, lib=emu_lib, skip_test_block=True)
+    e.compute(tokens, offsets, ntr, N - ntr)
+    assert np.array_equal(e.get_train(), sq[:ntr, :ntr])
+    assert np.array_equal(e.get_test(), sq[ntr:, :ntr])
+    got = tri_to_square(e.get_counts(), N)
+    assert not got[300, 130] and not got[399, 255] and got[300, 290] and got[399, 399]
+    e.close()
+
+
 def test_emu_relabelled_and_wide_alphabets(emu_lib, port):
     from fastsk_amd import _native
     d = load_golden("f3_ragged_sigma7_g6m3")

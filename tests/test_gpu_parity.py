@@ -316,6 +316,35 @@ def test_edge_cases_and_error_convention(native, port):
     e.close()
 
 
+def test_skip_test_block(native, port):
+    """skip_test_block=1: everything a getter of the reference exposes (train x train, test x train,
+    hence every diagonal entry) is unchanged; tiles made of test x test cells only are not computed."""
+    N, ntr = 1500, 600   # first all-test tile column: ceil(600/128) = 5 -> cells with column >= 640 are skipped
+    tokens, offsets = synthetic_dna(N, 80, seed=3)
+    want, _, _ = port.compute(tokens, offsets, ntr, N - ntr, 9, 5, t=1)
+    sq = tri_to_square(want, N)
+    raw, _, _ = port.raw_counts(tokens, offsets, 9, 5, np.arange(port.num_combos(9, 5), dtype=np.int32), threads=8)
+    for bands in (False, True):
+        e = native.Engine(9, 5, path=1, skip_test_block=True)
+        if bands:
+            e.load_sequences(tokens, offsets, ntr, N - ntr)
+            for lo, hi in ((0, 512), (512, 1024), (1024, N)):
+                e.accumulate_rows(np.arange(126, dtype=np.int32), lo, hi)
+            e.finalize()
+        else:
+            e.compute(tokens, offsets, ntr, N - ntr)
+        assert np.array_equal(e.get_train(), sq[:ntr, :ntr])
+        assert np.array_equal(e.get_test(), sq[ntr:, :ntr])
+        got = tri_to_square(e.get_counts(), N).astype(np.int64)
+        ref = tri_to_square(raw, N).astype(np.int64)
+        assert np.array_equal(np.diag(got), np.diag(ref))
+        i, j = np.tril_indices(N, -1)
+        skipped = (j // 128 >= 5) & (i // 128 != j // 128)
+        assert not got[i[skipped], j[skipped]].any() and skipped.sum() > 200000
+        assert np.array_equal(got[i[~skipped], j[~skipped]], ref[i[~skipped], j[~skipped]])
+        e.close()
+
+
 def test_device_resident_block_getter(native):
     """fsk_get_block_device: the normalised block straight into a torch tensor on the GPU."""
     d = load_golden("f4_ep300_exact")
