@@ -9,12 +9,14 @@
 #include "fsk_kernels.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <cstdint>
@@ -62,7 +64,10 @@ struct fsk_engine {
     int k = 0;
     int64_t ncomb = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // variance mode: D2H of one iteration under the next one's kernels
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double* h_prod = nullptr;            // pinned staging of the per-cell variance terms (kept across calls)
+    size_t h_prod_cap = 0;
 
     // sequences
     bool loaded = false, finalized = false, result_f64 = false;
@@ -647,64 +652,141 @@ void default_order(fsk_engine* e) {
 int run_variance_mode(fsk_engine* e, int T) {
     const int64_t pairs = e->pairs;
     const int64_t train_pairs = (int64_t)((e->n_train / (double)2) * (e->n_train + 1));
+    const size_t tp = (size_t)std::max<int64_t>(1, train_pairs);
+    // The stop test of iteration i needs avg_variance, a SEQUENTIAL fp64 sum in triangle-index
+    // order (fastsk_kernel.cpp:116-131): it must keep that order for stdevs to match to the last
+    // bit, and one host core streams the freshly copied cells at ~15 GB/s. So the engine runs
+    // ahead of its stop test: iterations are issued in batches of AHEAD, two batches in flight.
+    // The cells of an iteration leave on a copy stream under the next iteration's kernels, the
+    // AHEAD sums of a batch are independent chains (one host thread each) and run under the GPU
+    // work of the next batch, the Welford state of every untested iteration is kept in a ring,
+    // and whatever lies beyond the stopping iteration is dropped.
+    constexpr int AHEAD = 4, RING = 2 * AHEAD + 1;
+    const bool trace = getenv("FSK_TRACE") != nullptr;  // stderr: where the wall time of this mode goes
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+    double t_wait = 0, t_sum = 0;
+    const auto t_begin = now();
     FSK_HIP(e->d_Kf64.reserve((size_t)pairs));
-    FSK_HIP(e->d_Khat.reserve((size_t)pairs));
-    FSK_HIP(e->d_prod.reserve((size_t)std::max<int64_t>(1, train_pairs)));
+    FSK_HIP(e->d_Khat.reserve((size_t)pairs * RING));
+    FSK_HIP(e->d_prod.reserve(tp * 2 * AHEAD));
     FSK_HIP(hipMemsetAsync(e->d_Kf64.p, 0, (size_t)pairs * sizeof(double), e->stream));
-    // pinned host buffer, copied in chunks so that the sequential host sum of chunk c overlaps
-    // the D2H copy of chunk c+1
-    const int64_t CHUNK = (int64_t)1 << 20;
-    const int n_chunks = (int)std::max<int64_t>(1, (train_pairs + CHUNK - 1) / CHUNK);
-    double* prod = nullptr;
-    FSK_HIP(hipHostMalloc((void**)&prod, (size_t)std::max<int64_t>(1, train_pairs) * sizeof(double)));
-    std::vector<hipEvent_t> evs((size_t)n_chunks);
-    for (auto& ev : evs) (void)hipEventCreate(&ev);
+    if (e->h_prod_cap < tp * 2 * AHEAD) {
+        if (e->h_prod) (void)hipHostFree(e->h_prod);
+        e->h_prod = nullptr; e->h_prod_cap = 0;
+        FSK_HIP(hipHostMalloc((void**)&e->h_prod, tp * 2 * AHEAD * sizeof(double)));
+        e->h_prod_cap = tp * 2 * AHEAD;
+    }
+    if (!e->copy_stream) FSK_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    hipEvent_t ev_cell[2 * AHEAD], ev_done[2];
+    for (auto& ev : ev_cell) FSK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (auto& ev : ev_done) FSK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     struct Cleanup {
-        double* p; std::vector<hipEvent_t>* e;
-        ~Cleanup() { for (auto& ev : *e) (void)hipEventDestroy(ev); (void)hipHostFree(p); }
-    } cleanup{prod, &evs};
+        hipEvent_t* a; hipEvent_t* b; fsk_engine* e;
+        ~Cleanup() {
+            (void)hipStreamSynchronize(e->stream);       // nothing of this call may still be in flight
+            (void)hipStreamSynchronize(e->copy_stream);
+            for (int i = 0; i < 2 * AHEAD; ++i) (void)hipEventDestroy(a[i]);
+            for (int i = 0; i < 2; ++i) (void)hipEventDestroy(b[i]);
+        }
+    } cleanup{ev_cell, ev_done, e};
+    const double t_alloc = ms_since(t_begin);
     const uint32_t blocks = (uint32_t)((pairs + 255) / 256);
     const int n_order = (int)e->order.size();
-    e->stdevs.clear();
-    for (int tid = 0; tid < T; ++tid) {
-        FSK_HIP(hipMemsetAsync(e->d_Khat.p, 0, (size_t)pairs * sizeof(double), e->stream));
-        int iter = 1, item = tid;
-        bool working = true;
-        while (working) {
+    auto khat = [&](int i) { return e->d_Khat.p + (size_t)(i % RING) * (size_t)pairs; };
+    struct Batch { int n = 0, first_iter = 0, first_item = 0, base = 0, half = 0; };
+    // how many iterations can still follow (end of the work list, max_iters)
+    auto plan = [&](int first_iter, int first_item) {
+        int n = AHEAD;
+        n = std::min(n, first_item < n_order ? (n_order - first_item + T - 1) / T : 0);
+        if (e->cfg.max_iters != -1) n = std::min(n, e->cfg.max_iters - first_iter + 1);
+        return std::max(n, 0);
+    };
+    auto issue = [&](const Batch& B) -> int {
+        for (int b = 0; b < B.n; ++b) {
+            const size_t slot = (size_t)(B.half * AHEAD + b);
             FSK_HIP(hipMemsetAsync(e->d_K, 0, (size_t)pairs * sizeof(u64), e->stream));
-            int32_t combo = e->order[item];
+            int32_t combo = e->order[B.first_item + b * T];
             int rc = do_accumulate(e, &combo, 1, e->d_K);
             if (rc) return rc;
-            FSK_LAUNCH(fsk::k_welford, dim3(blocks), dim3(256), 0, e->stream, e->d_K, e->d_Khat.p, e->d_prod.p, (u64)pairs,
-                       (u64)train_pairs, (double)iter);
-            for (int c = 0; c < n_chunks; ++c) {
-                const int64_t lo = (int64_t)c * CHUNK, cnt = std::min(CHUNK, train_pairs - lo);
-                if (cnt > 0)
-                    FSK_HIP(hipMemcpyAsync(prod + lo, e->d_prod.p + lo, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-                FSK_HIP(hipEventRecord(evs[(size_t)c], e->stream));
-            }
-            // the reference's avg_variance is a sequential fp64 sum in triangle-index order
-            // (fastsk_kernel.cpp:116-131); keep that order so stdevs match to the last bit
-            double avg = 0;
-            for (int c = 0; c < n_chunks; ++c) {
-                FSK_HIP(hipEventSynchronize(evs[(size_t)c]));
-                const int64_t lo = (int64_t)c * CHUNK, hi = std::min(lo + CHUNK, train_pairs);
-                for (int64_t i = lo; i < hi; ++i) avg += prod[i];
-            }
-            avg /= (double)train_pairs;
-            if (iter == 1) avg = 9999999;
-            else avg /= iter - 1;
-            double sd = std::sqrt(avg / iter);
-            if (tid == 0) e->stdevs.push_back(sd);
-            if (e->cfg.delta / sd > 1.96) working = false;
-            if (e->cfg.max_iters != -1 && iter >= e->cfg.max_iters) working = false;
-            item += T;
-            if (item >= n_order) working = false;
-            iter++;
+            FSK_LAUNCH(fsk::k_welford, dim3(blocks), dim3(256), 0, e->stream, e->d_K, (const double*)khat(B.base + b), khat(B.base + b + 1),
+                       e->d_prod.p + slot * tp, (u64)pairs, (u64)train_pairs, (double)(B.first_iter + b));
+            FSK_HIP(hipEventRecord(ev_cell[slot], e->stream));
+            FSK_HIP(hipStreamWaitEvent(e->copy_stream, ev_cell[slot], 0));
+            if (train_pairs > 0)
+                FSK_HIP(hipMemcpyAsync(e->h_prod + slot * tp, e->d_prod.p + slot * tp, (size_t)train_pairs * sizeof(double),
+                                       hipMemcpyDeviceToHost, e->copy_stream));
         }
-        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_add_nonzero<double>), dim3(blocks), dim3(256), 0, e->stream, e->d_Kf64.p, e->d_Khat.p, (u64)pairs);
+        FSK_HIP(hipEventRecord(ev_done[B.half], e->copy_stream));
+        return FSK_OK;
+    };
+    e->stdevs.clear();
+    for (int tid = 0; tid < T; ++tid) {
+        int cur = 0;  // ring position of the state after the last accepted iteration
+        FSK_HIP(hipMemsetAsync(khat(cur), 0, (size_t)pairs * sizeof(double), e->stream));
+        int iter = 1, item = tid;
+        Batch A;
+        A.first_iter = iter; A.first_item = item; A.base = cur; A.half = 0;
+        A.n = std::max(1, plan(iter, item));  // (the reference always runs the first iteration)
+        int rc = issue(A);
+        if (rc) return rc;
+        bool working = true;
+        while (working) {
+            Batch N;  // issued before A is tested: assumes all of A is accepted
+            N.first_iter = A.first_iter + A.n; N.first_item = A.first_item + A.n * T; N.base = A.base + A.n; N.half = A.half ^ 1;
+            N.n = plan(N.first_iter, N.first_item);
+            if (N.n > 0 && (rc = issue(N)) != FSK_OK) return rc;
+            auto t0 = now();
+            FSK_HIP(hipEventSynchronize(ev_done[A.half]));
+            t_wait += ms_since(t0);
+            t0 = now();
+            double avg[AHEAD] = {0, 0, 0, 0};
+            auto chain = [&](int b) {
+                const double* p = e->h_prod + (size_t)(A.half * AHEAD + b) * tp;
+                double a = 0;
+                for (int64_t i = 0; i < train_pairs; ++i) a += p[i];
+                avg[b] = a;
+            };
+            {
+                std::vector<std::thread> helpers;
+                for (int b = 1; b < A.n; ++b) helpers.emplace_back(chain, b);
+                chain(0);
+                for (auto& th : helpers) th.join();
+            }
+            t_sum += ms_since(t0);
+            int accepted = 0;
+            for (int b = 0; b < A.n && working; ++b) {
+                double v = avg[b] / (double)train_pairs;
+                if (iter == 1) v = 9999999;
+                else v /= iter - 1;
+                const double sd = std::sqrt(v / iter);
+                if (tid == 0) e->stdevs.push_back(sd);
+                if (e->cfg.delta / sd > 1.96) working = false;
+                if (e->cfg.max_iters != -1 && iter >= e->cfg.max_iters) working = false;
+                item += T;
+                if (item >= n_order) working = false;
+                iter++;
+                accepted = b + 1;
+            }
+            cur = A.base + accepted;
+            e->st.combos_done -= A.n - accepted;  // iterations run ahead of the stop are dropped
+            if (!working) {
+                e->st.combos_done -= N.n;
+                if (N.n > 0) {  // let the dropped batch drain before its buffers are reused
+                    FSK_HIP(hipStreamSynchronize(e->stream));
+                    FSK_HIP(hipStreamSynchronize(e->copy_stream));
+                }
+                break;
+            }
+            A = N;  // (working implies more items and iterations: N.n > 0)
+        }
+        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_add_nonzero<double>), dim3(blocks), dim3(256), 0, e->stream, e->d_Kf64.p, (const double*)khat(cur), (u64)pairs);
     }
     e->result_f64 = true;
+    FSK_HIP(hipStreamSynchronize(e->stream));
+    if (trace)
+        fprintf(stderr, "[fsk] variance mode: setup %.2f ms, waiting for the GPU %.2f ms, host sums %.2f ms, total %.2f ms (%lld cells/iteration)\n",
+                t_alloc, t_wait, t_sum, ms_since(t_begin), (long long)train_pairs);
     return FSK_OK;
 }
 
@@ -810,6 +892,8 @@ void fsk_destroy(fsk_engine* e) {
     e->d_blockhist.release(); e->d_totals.release(); e->d_estart.release(); e->d_eseq.release(); e->d_erun.release();
     e->d_rstart.release(); e->d_segtot.release(); e->d_blocksum.release(); e->d_U.release();
     e->d_bk_hist.release(); e->d_bk_tot.release(); e->d_slice_off.release(); e->d_list.release(); e->d_epair.release();
+    if (e->h_prod) (void)hipHostFree(e->h_prod);
+    if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
     (void)hipEventDestroy(e->ev0);
     (void)hipEventDestroy(e->ev1);
     (void)hipStreamDestroy(e->stream);

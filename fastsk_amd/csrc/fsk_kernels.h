@@ -804,16 +804,19 @@ __global__ __launch_bounds__(256) void k_triangle(const SrcT* K, const double* d
 // =============================================================================================
 // APPROX / VARIANCE MODE  (get_variance, fastsk_kernel.cpp:108-143)
 // =============================================================================================
-// K_hat += (Ks - K_hat)/iter; prod = delta * (Ks - K_hat') for the train x train prefix.
+// K_hat' = K_hat + (Ks - K_hat)/iter; prod = delta * (Ks - K_hat') for the train x train prefix.
 // The reference then sums prod sequentially in index order; that one reduction stays on the host.
-__global__ __launch_bounds__(256) void k_welford(const u64* Ks, double* K_hat, double* prod, u64 pairs, u64 train_pairs,
-                                                 double iter) {
+// K_hat is read from one buffer and written to another: the host runs a few iterations ahead of
+// its stop test and keeps the state of every iteration it has not yet accepted.
+__global__ __launch_bounds__(256) void k_welford(const u64* Ks, const double* K_hat_in, double* K_hat_out, double* prod, u64 pairs,
+                                                 u64 train_pairs, double iter) {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     if (i >= pairs) return;
     const double x = (double)Ks[i];
-    const double delta = __dsub_rn(x, K_hat[i]);
-    const double kh = __dadd_rn(K_hat[i], __ddiv_rn(delta, iter));
-    K_hat[i] = kh;
+    const double old = K_hat_in[i];
+    const double delta = __dsub_rn(x, old);
+    const double kh = __dadd_rn(old, __ddiv_rn(delta, iter));
+    K_hat_out[i] = kh;
     if (i < train_pairs) prod[i] = __dmul_rn(delta, __dsub_rn(x, kh));
 }
 

@@ -16,7 +16,7 @@ def build(force=False):
     deps += [os.path.join(ROOT, "fastsk_amd", "csrc", f) for f in ("fsk_kernels.h", "fsk_tile_kernel.inc", "fsk_platform.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
-    cmd = ["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-DFSK_EMU", "-ffp-contract=off",
+    cmd = ["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-pthread", "-DFSK_EMU", "-ffp-contract=off",
            "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-I", HERE, "-x", "c++", SRC, "-o", OUT]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -274,10 +274,14 @@ static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); 
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
 static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return 0; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline hipError_t hipDeviceSynchronize() { return 0; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emuEvent; return 0; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new emuEvent; return 0; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
