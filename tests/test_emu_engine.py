@@ -100,6 +100,31 @@ def test_emu_approx_modes(emu_lib, name):
         assert np.array_equal(e.get_counts(), d["counts"])
 
 
+def test_emu_variance_mode_stops_anywhere(emu_lib, port):
+    """Variance mode runs ahead of its stop test (batches of 4 iterations, two in flight): whatever
+    the chain count, max_iters and delta, the stop must land on the reference's iteration and the
+    state of the dropped iterations must not leak into the result."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(5)
+    X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(12, 40, size=30)]
+    tok, off = _native.flatten(X)
+    g, m = 7, 3
+    order = rng.permutation(port.num_combos(g, m)).astype(np.int32)
+    lengths = set()
+    for T in (1, 2, 3):
+        for max_iters in (-1, 1, 2, 4, 5, 6, 9):
+            for delta in (0.025, 0.2, 0.5, 1.0, 3.0):
+                want, sd, _ = port.compute(tok, off, 22, 8, g, m, t=T, approx=True, delta=delta, max_iters=max_iters, order=order)
+                e = _native.Engine(g, m, t=T, approx=True, delta=delta, max_iters=max_iters, lib=emu_lib)
+                e.set_combo_order(order)
+                e.compute(tok, off, 22, 8)
+                assert np.array_equal(e.get_stdevs(), sd), (T, max_iters, delta)
+                assert np.array_equal(e.get_triangle(), want), (T, max_iters, delta)
+                lengths.add(len(sd))
+                e.close()
+    assert len(lengths) >= 6  # stops landed at many different places inside the batches
+
+
 def test_emu_bound_counts_buffer_and_reset(emu_lib, port):
     """fsk_bind_counts: the integer triangle lives in caller-provided memory (on the GPU: a torch
     tensor that RCCL all-reduces). Under emulation device memory is host memory."""

@@ -316,6 +316,30 @@ def test_edge_cases_and_error_convention(native, port):
     e.close()
 
 
+def test_variance_mode_stops_anywhere(native, port):
+    """Variance mode runs ahead of its stop test (batches of 4 iterations, two in flight, copy
+    stream, host threads): whatever the chain count, max_iters and delta, stdevs and the kernel are
+    the oracle's, bit for bit."""
+    rng = np.random.default_rng(5)
+    X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(12, 40, size=30)]
+    tok, off = native.flatten(X)
+    g, m = 7, 3
+    order = rng.permutation(port.num_combos(g, m)).astype(np.int32)
+    lengths = set()
+    for T in (1, 2, 3):
+        for max_iters in (-1, 1, 2, 4, 5, 6, 9):
+            for delta in (0.025, 0.2, 0.5, 1.0, 3.0):
+                want, sd, _ = port.compute(tok, off, 22, 8, g, m, t=T, approx=True, delta=delta, max_iters=max_iters, order=order)
+                e = native.Engine(g, m, t=T, approx=True, delta=delta, max_iters=max_iters)
+                e.set_combo_order(order)
+                e.compute(tok, off, 22, 8)
+                assert np.array_equal(e.get_stdevs(), sd), (T, max_iters, delta)
+                assert np.array_equal(e.get_triangle(), want), (T, max_iters, delta)
+                lengths.add(len(sd))
+                e.close()
+    assert len(lengths) >= 6  # stops landed at many different places inside the batches
+
+
 def test_skip_test_block(native, port):
     """skip_test_block=1: everything a getter of the reference exposes (train x train, test x train,
     hence every diagonal entry) is unchanged; tiles made of test x test cells only are not computed."""
