@@ -316,6 +316,31 @@ def test_edge_cases_and_error_convention(native, port):
     e.close()
 
 
+def test_diag_exchange_on_a_triangle_beyond_2_31_cells():
+    """The row-sharded multi-GPU path gathers and scatters the N diagonal cells of the bound
+    triangle with torch indexing; at config 5 that tensor has 5e9 cells. Same indexing here on
+    2.45e9 cells (N = 70000): offsets above 2^31 must address the right cells."""
+    import torch
+    from fastsk_amd.distributed import diag_index, cell
+    N = 70000
+    K = torch.zeros(cell(N), dtype=torch.int64, device="cuda")
+    idx = diag_index(N, K.device)
+    assert int(idx[-1]) == cell(N) - 1 and int(idx[-1]) > 2 ** 31
+    vals = torch.arange(1, N + 1, dtype=torch.int64, device="cuda")
+    K[idx] = vals
+    assert torch.equal(K[idx], vals)
+    for i in (0, 1, 46340, 46341, 65535, 65536, N - 1):   # around the int32 / uint16 edges
+        assert int(K[cell(i) + i]) == i + 1
+        if i:
+            assert int(K[cell(i) + i - 1]) == 0
+    assert int(K.sum()) == N * (N + 1) // 2
+    d = K[idx]
+    d[:1000] = 0
+    d[N - 1000:] = 0
+    K[idx] = d
+    assert int(K.sum()) == N * (N + 1) // 2 - sum(range(1, 1001)) - sum(range(N - 999, N + 1))
+
+
 def test_variance_mode_stops_anywhere(native, port):
     """Variance mode runs ahead of its stop test (batches of 4 iterations, two in flight, copy
     stream, host threads): whatever the chain count, max_iters and delta, stdevs and the kernel are
