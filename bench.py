@@ -28,6 +28,9 @@ import time
 
 import numpy as np
 
+# the host driver only supports dmabuf IPC: RCCL between processes needs this before HIP starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -14,7 +14,9 @@ import sys
 import time
 
 import numpy as np
-import torch
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL between processes
+import torch  # noqa: E402
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
