@@ -126,14 +126,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    # Smoke tests of the multi-rank code on a 1-GPU box, not measurements: FSK_BENCH_FORCE_DIST=1 runs
+    # the RCCL leg with world size 1; FSK_BENCH_SHARE_GPU=1 puts every rank on cuda:0 over gloo (RCCL
+    # cannot run two ranks on one device).
+    share = os.environ.get("FSK_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    # FSK_BENCH_FORCE_DIST=1 exercises the RCCL leg on a single GPU (world size 1): a smoke test of
-    # the code the multi-GPU runs take, not a measurement
     use_dist = world > 1 or os.environ.get("FSK_BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     N, L, g, m = args.n_seq, args.seq_len, args.g, args.m
     tokens, offsets, X = synthetic(N, L)

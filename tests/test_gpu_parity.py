@@ -316,6 +316,31 @@ def test_edge_cases_and_error_convention(native, port):
     e.close()
 
 
+@pytest.mark.parametrize("shard", ["auto", "combos"])
+def test_bench_two_ranks_sharing_the_gpu(native, shard):
+    """bench.py's multi-rank flow end to end (launch as the driver does, both decompositions, the
+    `alt` leg, the JSON contract) with two ranks on cuda:0 over gloo — everything but RCCL."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, FSK_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29721" if shard == "auto" else "29722", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "1", "--warmup", "1", "--n-seq", "6000", "--shard", shard],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])   # the JSON line is the last thing printed
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d
+    assert d["n_gpus"] == 2 and d["unit"] == "combos/s" and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["config"]["combos"] == 495 and d["config"]["n_seq"] == 6000
+    assert ("row-band" in d["config"]["parallelism"]) == (shard == "auto")
+    assert d["alt"]["value"] > 0 and ("row-band" in d["alt"]["parallelism"]) == (shard == "combos")
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
 def test_diag_exchange_on_a_triangle_beyond_2_31_cells():
     """The row-sharded multi-GPU path gathers and scatters the N diagonal cells of the bound
     triangle with torch indexing; at config 5 that tensor has 5e9 cells. Same indexing here on
