@@ -15,6 +15,11 @@ DST = os.path.join(ROOT, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 
+def newest(pattern):
+    """gpurun merges each call's output into the local gpurun_out/: keep the latest run's file."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 def json_line(path):
     for line in open(path):
         if line.startswith("{"):
@@ -25,13 +30,12 @@ def json_line(path):
 def main():
     open(os.path.join(DST, TAG + "_bench100k.json"), "w").write(json_line(os.path.join(SRC, "bench.json")))
     open(os.path.join(DST, TAG + "_bench100k_under_rocprof.json"), "w").write(json_line(os.path.join(SRC, "bench_under_rocprof.json")))
-    stats = glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv"))
-    shutil.copy(stats[0], os.path.join(DST, TAG + "_kernel_stats_bench100k.csv"))
+    shutil.copy(newest(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv")), os.path.join(DST, TAG + "_kernel_stats_bench100k.csv"))
     rows = []
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = os.path.join(SRC, "pmc_" + counter)
-        cc = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
-        kt = glob.glob(os.path.join(d, "*", "*_kernel_trace.csv"))[0]
+        cc = newest(os.path.join(d, "*", "*_counter_collection.csv"))
+        kt = newest(os.path.join(d, "*", "*_kernel_trace.csv"))
         dur = {}
         for r in csv.DictReader(open(kt)):
             dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
