@@ -345,6 +345,7 @@ __global__ __launch_bounds__(64) void k_dense_distinct(const uint32_t* C4, const
 #include "fsk_tile_kernel.inc"
 #undef FSK_TILE_KERNEL
 #undef FSK_TILE_COMPACT
+#include "fsk_tile_kernel_dma.inc"
 
 // =============================================================================================
 // SPARSE PATH

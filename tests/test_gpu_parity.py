@@ -366,6 +366,27 @@ def test_diag_exchange_on_a_triangle_beyond_2_31_cells():
     assert int(K.sum()) == N * (N + 1) // 2 - sum(range(1, 1001)) - sum(range(N - 999, N + 1))
 
 
+def test_register_staged_tile_kernel_still_agrees(native, port, monkeypatch):
+    """FSK_TILE_DMA=0 selects k_dense_tile (register-staged panels) instead of the default
+    k_dense_tile_dma (direct-to-LDS loads): same counts, including rows with counts above 15 and a
+    key space that is not a multiple of a stage."""
+    rng = np.random.default_rng(77)
+    N = 700
+    X = rng.integers(1, 4, size=(N, 150), dtype=np.int32)   # 3 symbols, k = 5: 243 keys -> 31 dword rows
+    X[::9, 20:90] = 1                                        # long runs: counts above 15
+    tokens, offsets = native.flatten(X)
+    combos = np.arange(0, 126, 5, dtype=np.int32)
+    want, _, _ = port.raw_counts(tokens, offsets, 9, 4, combos, threads=8)
+    for dma in ("0", "1"):
+        monkeypatch.setenv("FSK_TILE_DMA", dma)
+        e = native.Engine(9, 4, path=1)
+        e.load_sequences(tokens, offsets, N, 0)
+        e.accumulate(combos)
+        e.finalize()
+        assert np.array_equal(e.get_counts(), want), "FSK_TILE_DMA=" + dma
+        e.close()
+
+
 def test_variance_mode_stops_anywhere(native, port):
     """Variance mode runs ahead of its stop test (batches of 4 iterations, two in flight, copy
     stream, host threads): whatever the chain count, max_iters and delta, stdevs and the kernel are
