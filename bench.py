@@ -14,7 +14,7 @@ The other of the two is timed for one step afterwards and reported as "alt".
 value = combos/s of the whole job = 495 * steps / max-over-ranks seconds.
 
 One JSON line on rank 0. Extra objects:
-  roofline      the dominant kernel (k_dense_tile) priced on SURVEY 8d's algorithmic bytes
+  roofline      the dominant kernel (k_dense_tile_dma) priced on SURVEY 8d's algorithmic bytes
                 (16*U + sort + input bytes per combo) against the 8 TB/s HBM peak, timed with HIP
                 events on the engine's own stream; plus the integer-VALU view of the same launch.
   cpu_baseline  the compiled reference (oracle/_ref, "reference") or our C restatement ("port")
@@ -250,7 +250,7 @@ def main():
                        "n_seq": N, "seq_len": L, "g": g, "m": m, "combos": int(ncomb),
                        "parallelism": describe(mode, world, args.replicate),
                        "path": "dense" if s1["path_used"] == 1 else "sparse"},
-            "roofline": {"bound": "hbm", "kernel": "k_dense_tile", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_dense_tile_dma" if os.environ.get("FSK_TILE_DMA", "1") != "0" else "k_dense_tile", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": tile_ms, "launches": int(launches), "combos_per_launch": combos_per_launch,
                          "cell_updates_per_launch": U, "algorithmic_bytes_per_launch": alg_bytes,
