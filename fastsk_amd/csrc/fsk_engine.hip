@@ -243,8 +243,12 @@ template <typename KeyT>
 int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t row0, int64_t row1) {
     const size_t nrec = (size_t)nb * (size_t)e->nfeat;
     if (nrec == 0) return FSK_OK;
+    // Only the k-mer bits are sorted. The records are generated combo-major and every LSD pass is
+    // stable, so after sorting on the k-mer alone the records of one (combo, k-mer) are still
+    // contiguous, in sequence order — groups are all the segment kernels need (they compare whole
+    // keys); the order of the groups is irrelevant to the sums. Saves the passes over the combo bits.
     int keybits = 1;
-    while (keybits < 64 && ((u64)1 << keybits) < (u64)nb * e->V) ++keybits;
+    while (keybits < 64 && ((u64)1 << keybits) < (u64)e->V) ++keybits;
     const int passes = (keybits + 7) / 8;
     const uint32_t rs_blocks = (uint32_t)((nrec + fsk::RS_TILE - 1) / fsk::RS_TILE);
     const uint32_t seg_blocks = (uint32_t)((nrec + fsk::SEG_TILE - 1) / fsk::SEG_TILE);
