@@ -571,15 +571,26 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
         // split are nearly free (the atomics drain under other workgroups' dot products).
         int n_splits = 1;
         if (n_tiles < 4096 && nb >= 2) {
-            const double t_combo = 16384.0 * (double)(Vq8 * 8) / (2.5e14 / 512.0);
-            double best = 1e300;
-            for (int sp = 1; sp <= std::min(nb, 4096); ++sp) {
-                const int per = (nb + sp - 1) / sp;
-                if ((nb + per - 1) / per != sp || per < 2) continue;
-                const double rounds = std::ceil((double)n_tiles * sp / 512.0);
-                const double cost = rounds * (per * t_combo + 3e-6) + (double)sp * (double)n_tiles * 3e-8;
-                if (cost < best) { best = cost; n_splits = sp; }
+            // Measured (tools/sweep_splits.py, both tile kernels, N = 256 .. 11000): the launch is
+            // fastest when a workgroup multiplies about 600 dword rows (20-odd combos of 256 keys)
+            // — short enough that the 1024 (compact: 768) resident slots turn over many times and
+            // the tail is short, long enough that prologue and flush stay small — with no more
+            // than ~16k workgroups in all and never fewer than slots when the combos allow it.
+            // The curve is flat around the optimum (+-2 %); one split costs 10-30 %.
+            double rows_per_combo = (double)Vq8;
+            if (compact && (int)e->h_vc_cache.size() == nb) {
+                double sum = 0;
+                for (uint16_t v : e->h_vc_cache) sum += (v + 7u) / 8u;
+                rows_per_combo = std::max(1.0, sum / nb);
             }
+            const int slots = compact ? 768 : 1024;
+            int per = std::max(2, (int)std::ceil(600.0 / rows_per_combo));
+            n_splits = std::max(1, (nb + per - 1) / per);
+            // ... and about 16k workgroups are enough: beyond that more splits only add flushes
+            n_splits = std::min(n_splits, (int)((16384 + n_tiles - 1) / n_tiles));
+            if ((double)n_tiles * n_splits < slots)
+                n_splits = std::max(n_splits, std::min(nb / 2, (int)((slots + n_tiles - 1) / n_tiles)));
+            n_splits = std::max(1, std::min({n_splits, nb, 4096}));
         }
         if (e->force_splits > 0) n_splits = std::min({nb, e->force_splits, 4096});
         const int slots_per_split = (nb + n_splits - 1) / n_splits;
