@@ -570,8 +570,8 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
         // 250 T MAC/s over 512 slots plus ~3 us of workgroup start-up; the extra flushes of a
         // split are nearly free (the atomics drain under other workgroups' dot products).
         int n_splits = 1;
-        if (n_tiles < 4096 && nb >= 2) {
-            // Measured (tools/sweep_splits.py, both tile kernels, N = 256 .. 11000): the launch is
+        if (n_tiles < 16384 && nb >= 2) {
+            // Measured (tools/sweep_splits.py, both tile kernels, N = 256 .. 22000): the launch is
             // fastest when a workgroup multiplies about 600 dword rows (20-odd combos of 256 keys)
             // — short enough that the 1024 (compact: 768) resident slots turn over many times and
             // the tail is short, long enough that prologue and flush stay small — with no more
