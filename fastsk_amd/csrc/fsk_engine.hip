@@ -215,7 +215,7 @@ DensePlan dense_plan(uint32_t maxW, int g, uint32_t Vq, size_t extra = 0) {
 bool dense_is_cheaper(const fsk_engine* e) {
     const double N = (double)e->N, V = (double)e->V;
     const double W = (double)e->nfeat / std::max(1.0, N);                 // windows per sequence
-    const double dense = 0.5 * N * N * (double)(((e->Vq + 1) / 2) * 8) / 2.4e14 + (double)e->nfeat * 4e-11;
+    const double dense = 0.5 * N * N * (double)(((e->Vq + 1) / 2) * 8) / 2.9e14 + (double)e->nfeat * 4e-11;
     const double d = N * (1.0 - std::exp(-W / V));                          // sequences holding a given key
     const double U = V * d * (d + 1.0) / 2.0;
     const double sparse = U / 1.6e10 + (double)e->nfeat * 3.0 / 2.0e10;
