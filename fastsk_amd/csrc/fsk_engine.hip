@@ -565,10 +565,8 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
             continue;
         }
         // ---- tiled accumulate. With few tiles (small N) the combo range is split over several
-        // workgroups per tile to fill 256 CUs x 2 resident workgroups in whole rounds. Model
-        // (fitted on MI355X, tools/sweep_splits.py): a round costs the combos of one split at
-        // 250 T MAC/s over 512 slots plus ~3 us of workgroup start-up; the extra flushes of a
-        // split are nearly free (the atomics drain under other workgroups' dot products).
+        // workgroups per tile (each flushes its partial sums with atomics, which drain under other
+        // workgroups' dot products).
         int n_splits = 1;
         if (n_tiles < 16384 && nb >= 2) {
             // Measured (tools/sweep_splits.py, both tile kernels, N = 256 .. 22000): the launch is
