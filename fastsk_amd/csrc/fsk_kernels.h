@@ -116,34 +116,41 @@ __device__ __forceinline__ void count_windows(const uint8_t* symT, uint32_t* his
                                               uint32_t r, uint32_t half, uint32_t key_lo, uint32_t key_n, uint16_t* kcache,
                                               int kmode) {
     if (K > 0 && !MARK && !LUT && kmode == 0) {
-        // The common case (every BASELINE config): two windows per trip. Window j+4 of a lane lies
+        // The common case (every BASELINE config): WPT windows per trip. Window j+4 of a lane lies
         // 4 rows = 256 bytes further in every symbol column, an immediate offset of the same
-        // address registers, so the loop bookkeeping is paid once per two windows. Rows past a
-        // sequence's end are zero padding inside symT (j + 4 < hi keeps them in range); their
-        // updates are predicated off.
+        // address registers, so the loop bookkeeping is paid once per WPT windows. Rows past a
+        // sequence's end are zero padding inside symT (the trip condition keeps them in range);
+        // their updates are predicated off.
+        constexpr int WPT = 4;
         const uint8_t* p[K > 0 ? K : 1];
 #pragma unroll
         for (int c = 0; c < K; ++c) p[c] = symT + (j0 - cb + pr[c]) * PANEL + r;
         uint32_t j = j0;
-        for (; j + 4u < hi; j += 8u) {
-            uint32_t k0 = 0, k1 = 0;
+        for (; j + 4u * (WPT - 1) < hi; j += 4u * WPT) {
+            uint32_t kk[WPT];
+#pragma unroll
+            for (int u = 0; u < WPT; ++u) kk[u] = 0;
+#pragma unroll
+            for (int c = 0; c < K; ++c) {
+#pragma unroll
+                for (int u = 0; u < WPT; ++u) kk[u] = mad24(kk[u], sigma, p[c][u * 4 * PANEL]);
+                p[c] += 4 * WPT * PANEL;
+            }
+#pragma unroll
+            for (int u = 0; u < WPT; ++u) {
+                const uint32_t key = kk[u] - key_lo;  // wraps for keys below the sweep: rejected by the compare
+                if (j + 4u * u < nwin && key < key_n) atomicAdd(&hist[key * 32u + (r >> 1)], 1u << half);
+            }
+        }
+        for (; j < hi; j += 4u) {  // the last few windows of the chunk
+            uint32_t k0 = 0;
 #pragma unroll
             for (int c = 0; c < K; ++c) {
                 k0 = mad24(k0, sigma, p[c][0]);
-                k1 = mad24(k1, sigma, p[c][4 * PANEL]);
-                p[c] += 8 * PANEL;
+                p[c] += 4 * PANEL;
             }
-            k0 -= key_lo;  // wraps for keys below the sweep: rejected by the compare
-            k1 -= key_lo;
-            if (j < nwin && k0 < key_n) atomicAdd(&hist[k0 * 32u + (r >> 1)], 1u << half);
-            if (j + 4u < nwin && k1 < key_n) atomicAdd(&hist[k1 * 32u + (r >> 1)], 1u << half);
-        }
-        if (j < hi && j < nwin) {
-            uint32_t k0 = 0;
-#pragma unroll
-            for (int c = 0; c < K; ++c) k0 = mad24(k0, sigma, p[c][0]);
             k0 -= key_lo;
-            if (k0 < key_n) atomicAdd(&hist[k0 * 32u + (r >> 1)], 1u << half);
+            if (j < nwin && k0 < key_n) atomicAdd(&hist[k0 * 32u + (r >> 1)], 1u << half);
         }
         return;
     }
