@@ -234,7 +234,7 @@ def main():
         macs = d("dense_macs") / launches
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if world == 1 and os.path.exists(tpath):  # (measured on the single-GPU launch: does not describe a rank's band)
             try:
                 tj = json.load(open(tpath))
                 if tj.get("n_seq") == N and tj.get("combos_per_launch") == int(combos_per_launch):
