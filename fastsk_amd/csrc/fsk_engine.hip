@@ -673,12 +673,15 @@ int run_variance_mode(fsk_engine* e, int T) {
     // The stop test of iteration i needs avg_variance, a SEQUENTIAL fp64 sum in triangle-index
     // order (fastsk_kernel.cpp:116-131): it must keep that order for stdevs to match to the last
     // bit, and one host core streams the freshly copied cells at ~15 GB/s. So the engine runs
-    // ahead of its stop test: iterations are issued in batches of AHEAD, two batches in flight.
-    // The cells of an iteration leave on a copy stream under the next iteration's kernels, the
-    // AHEAD sums of a batch are independent chains (one host thread each) and run under the GPU
-    // work of the next batch, the Welford state of every untested iteration is kept in a ring,
-    // and whatever lies beyond the stopping iteration is dropped.
-    constexpr int AHEAD = 4, RING = 2 * AHEAD + 1;
+    // ahead of its stop test: iterations are issued in batches of AHEAD, up to DEPTH batches in
+    // flight. The cells of an iteration leave on a copy stream under the next iteration's
+    // kernels; the AHEAD sums of a batch are independent chains, one host thread each, and while
+    // they run this thread already enqueues the batch after next; the Welford state of every
+    // untested iteration is kept in a ring; whatever lies beyond the stopping iteration is dropped.
+    constexpr int AHEAD = 4, MAX_DEPTH = 3;
+    // three batches in flight need 13 Welford buffers: only while that is small next to HBM
+    const int DEPTH = (size_t)pairs * sizeof(double) * (MAX_DEPTH * AHEAD + 1) <= ((size_t)8 << 30) ? MAX_DEPTH : 2;
+    const int RING = DEPTH * AHEAD + 1;
     const bool trace = getenv("FSK_TRACE") != nullptr;  // stderr: where the wall time of this mode goes
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
@@ -686,16 +689,16 @@ int run_variance_mode(fsk_engine* e, int T) {
     const auto t_begin = now();
     FSK_HIP(e->d_Kf64.reserve((size_t)pairs));
     FSK_HIP(e->d_Khat.reserve((size_t)pairs * RING));
-    FSK_HIP(e->d_prod.reserve(tp * 2 * AHEAD));
+    FSK_HIP(e->d_prod.reserve(tp * DEPTH * AHEAD));
     FSK_HIP(hipMemsetAsync(e->d_Kf64.p, 0, (size_t)pairs * sizeof(double), e->stream));
-    if (e->h_prod_cap < tp * 2 * AHEAD) {
+    if (e->h_prod_cap < tp * DEPTH * AHEAD) {
         if (e->h_prod) (void)hipHostFree(e->h_prod);
         e->h_prod = nullptr; e->h_prod_cap = 0;
-        FSK_HIP(hipHostMalloc((void**)&e->h_prod, tp * 2 * AHEAD * sizeof(double)));
-        e->h_prod_cap = tp * 2 * AHEAD;
+        FSK_HIP(hipHostMalloc((void**)&e->h_prod, tp * DEPTH * AHEAD * sizeof(double)));
+        e->h_prod_cap = tp * DEPTH * AHEAD;
     }
     if (!e->copy_stream) FSK_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-    hipEvent_t ev_cell[2 * AHEAD], ev_done[2];
+    hipEvent_t ev_cell[MAX_DEPTH * AHEAD], ev_done[MAX_DEPTH];
     for (auto& ev : ev_cell) FSK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     for (auto& ev : ev_done) FSK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     struct Cleanup {
@@ -703,15 +706,15 @@ int run_variance_mode(fsk_engine* e, int T) {
         ~Cleanup() {
             (void)hipStreamSynchronize(e->stream);       // nothing of this call may still be in flight
             (void)hipStreamSynchronize(e->copy_stream);
-            for (int i = 0; i < 2 * AHEAD; ++i) (void)hipEventDestroy(a[i]);
-            for (int i = 0; i < 2; ++i) (void)hipEventDestroy(b[i]);
+            for (int i = 0; i < MAX_DEPTH * AHEAD; ++i) (void)hipEventDestroy(a[i]);
+            for (int i = 0; i < MAX_DEPTH; ++i) (void)hipEventDestroy(b[i]);
         }
     } cleanup{ev_cell, ev_done, e};
     const double t_alloc = ms_since(t_begin);
     const uint32_t blocks = (uint32_t)((pairs + 255) / 256);
     const int n_order = (int)e->order.size();
     auto khat = [&](int i) { return e->d_Khat.p + (size_t)(i % RING) * (size_t)pairs; };
-    struct Batch { int n = 0, first_iter = 0, first_item = 0, base = 0, half = 0; };
+    struct Batch { int n = 0, first_iter = 0, first_item = 0, base = 0, part = 0; };
     // how many iterations can still follow (end of the work list, max_iters)
     auto plan = [&](int first_iter, int first_item) {
         int n = AHEAD;
@@ -719,9 +722,17 @@ int run_variance_mode(fsk_engine* e, int T) {
         if (e->cfg.max_iters != -1) n = std::min(n, e->cfg.max_iters - first_iter + 1);
         return std::max(n, 0);
     };
+    // the batch that would follow B if all of B is accepted
+    auto after = [&](const Batch& B) {
+        Batch N;
+        N.first_iter = B.first_iter + B.n; N.first_item = B.first_item + B.n * T; N.base = B.base + B.n;
+        N.part = (B.part + 1) % DEPTH;
+        N.n = plan(N.first_iter, N.first_item);
+        return N;
+    };
     auto issue = [&](const Batch& B) -> int {
         for (int b = 0; b < B.n; ++b) {
-            const size_t slot = (size_t)(B.half * AHEAD + b);
+            const size_t slot = (size_t)(B.part * AHEAD + b);
             FSK_HIP(hipMemsetAsync(e->d_K, 0, (size_t)pairs * sizeof(u64), e->stream));
             int32_t combo = e->order[B.first_item + b * T];
             int rc = do_accumulate(e, &combo, 1, e->d_K);
@@ -734,7 +745,7 @@ int run_variance_mode(fsk_engine* e, int T) {
                 FSK_HIP(hipMemcpyAsync(e->h_prod + slot * tp, e->d_prod.p + slot * tp, (size_t)train_pairs * sizeof(double),
                                        hipMemcpyDeviceToHost, e->copy_stream));
         }
-        FSK_HIP(hipEventRecord(ev_done[B.half], e->copy_stream));
+        FSK_HIP(hipEventRecord(ev_done[B.part], e->copy_stream));
         return FSK_OK;
     };
     e->stdevs.clear();
@@ -742,34 +753,52 @@ int run_variance_mode(fsk_engine* e, int T) {
         int cur = 0;  // ring position of the state after the last accepted iteration
         FSK_HIP(hipMemsetAsync(khat(cur), 0, (size_t)pairs * sizeof(double), e->stream));
         int iter = 1, item = tid;
-        Batch A;
-        A.first_iter = iter; A.first_item = item; A.base = cur; A.half = 0;
-        A.n = std::max(1, plan(iter, item));  // (the reference always runs the first iteration)
-        int rc = issue(A);
-        if (rc) return rc;
+        std::vector<Batch> q;  // issued, untested batches, oldest first (at most DEPTH)
+        {
+            Batch A;
+            A.first_iter = iter; A.first_item = item; A.base = cur; A.part = 0;
+            A.n = std::max(1, plan(iter, item));  // (the reference always runs the first iteration)
+            int rc = issue(A);
+            if (rc) return rc;
+            q.push_back(A);
+        }
         bool working = true;
         while (working) {
-            Batch N;  // issued before A is tested: assumes all of A is accepted
-            N.first_iter = A.first_iter + A.n; N.first_item = A.first_item + A.n * T; N.base = A.base + A.n; N.half = A.half ^ 1;
-            N.n = plan(N.first_iter, N.first_item);
-            if (N.n > 0 && (rc = issue(N)) != FSK_OK) return rc;
+            // keep DEPTH - 1 batches issued before the oldest one is summed ...
+            while ((int)q.size() < DEPTH - 1) {
+                Batch N = after(q.back());
+                if (N.n == 0) break;
+                int rc = issue(N);
+                if (rc) return rc;
+                q.push_back(N);
+            }
+            const Batch A = q.front();
             auto t0 = now();
-            FSK_HIP(hipEventSynchronize(ev_done[A.half]));
+            FSK_HIP(hipEventSynchronize(ev_done[A.part]));
             t_wait += ms_since(t0);
             t0 = now();
             double avg[AHEAD] = {0, 0, 0, 0};
             auto chain = [&](int b) {
-                const double* p = e->h_prod + (size_t)(A.half * AHEAD + b) * tp;
+                const double* p = e->h_prod + (size_t)(A.part * AHEAD + b) * tp;
                 double a = 0;
                 for (int64_t i = 0; i < train_pairs; ++i) a += p[i];
                 avg[b] = a;
             };
+            int rc_issue = FSK_OK;
             {
                 std::vector<std::thread> helpers;
-                for (int b = 1; b < A.n; ++b) helpers.emplace_back(chain, b);
-                chain(0);
+                for (int b = 0; b < A.n; ++b) helpers.emplace_back(chain, b);
+                // ... and enqueue one more while the chains run
+                if ((int)q.size() < DEPTH) {
+                    Batch N = after(q.back());
+                    if (N.n > 0) {
+                        rc_issue = issue(N);
+                        if (rc_issue == FSK_OK) q.push_back(N);
+                    }
+                }
                 for (auto& th : helpers) th.join();
             }
+            if (rc_issue) return rc_issue;
             t_sum += ms_since(t0);
             int accepted = 0;
             for (int b = 0; b < A.n && working; ++b) {
@@ -787,23 +816,24 @@ int run_variance_mode(fsk_engine* e, int T) {
             }
             cur = A.base + accepted;
             e->st.combos_done -= A.n - accepted;  // iterations run ahead of the stop are dropped
+            q.erase(q.begin());
             if (!working) {
-                e->st.combos_done -= N.n;
-                if (N.n > 0) {  // let the dropped batch drain before its buffers are reused
+                for (const Batch& B : q) e->st.combos_done -= B.n;
+                if (!q.empty()) {  // let the dropped batches drain before their buffers are reused
                     FSK_HIP(hipStreamSynchronize(e->stream));
                     FSK_HIP(hipStreamSynchronize(e->copy_stream));
                 }
                 break;
             }
-            A = N;  // (working implies more items and iterations: N.n > 0)
+            // (working implies more items and iterations: the queue is not empty)
         }
         FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_add_nonzero<double>), dim3(blocks), dim3(256), 0, e->stream, e->d_Kf64.p, (const double*)khat(cur), (u64)pairs);
     }
     e->result_f64 = true;
     FSK_HIP(hipStreamSynchronize(e->stream));
     if (trace)
-        fprintf(stderr, "[fsk] variance mode: setup %.2f ms, waiting for the GPU %.2f ms, host sums %.2f ms, total %.2f ms (%lld cells/iteration)\n",
-                t_alloc, t_wait, t_sum, ms_since(t_begin), (long long)train_pairs);
+        fprintf(stderr, "[fsk] variance mode: setup %.2f ms, waiting for the GPU %.2f ms, host sums %.2f ms, total %.2f ms (%lld cells/iteration, %d batches in flight)\n",
+                t_alloc, t_wait, t_sum, ms_since(t_begin), (long long)train_pairs, DEPTH);
     return FSK_OK;
 }
 
