@@ -66,6 +66,10 @@ struct fsk_engine {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // variance mode: D2H of one iteration under the next one's kernels
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // fsk_reset_counts does not fill K when the next accumulate can STORE its sums instead of adding
+    // them (dense dataflow, one workgroup per tile): rows [lazy_lo, lazy_hi) are zero by contract
+    // but not in memory until a tile launch stores them or materialise_zero() fills them.
+    int64_t lazy_lo = -1, lazy_hi = -1;
     double* h_prod = nullptr;            // pinned staging of the per-cell variance terms (kept across calls)
     size_t h_prod_cap = 0;
 
@@ -364,7 +368,10 @@ int ensure_featseq(fsk_engine* e) {
     return FSK_OK;
 }
 
+int materialise_zero(fsk_engine* e);
+
 int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0, int64_t row1) {
+    { int rcz = materialise_zero(e); if (rcz) return rcz; }
     int rc = ensure_featseq(e);
     if (rc) return rc;
     // batch so that the composite key stays below 2^62 and the record count below the cap
@@ -414,6 +421,19 @@ void build_tile_table(uint32_t t0, uint32_t t1, uint32_t first_test_tile, std::v
             }
             tab.push_back(q[src][pos[src]++]);
         }
+}
+
+// rows that fsk_reset_counts left for a storing tile launch get their zeros now (anything but such
+// a launch is about to look at K)
+int materialise_zero(fsk_engine* e) {
+    if (e->lazy_lo < 0) return FSK_OK;
+    const u64 c0 = (u64)e->lazy_lo * ((u64)e->lazy_lo + 1) / 2, c1 = (u64)e->lazy_hi * ((u64)e->lazy_hi + 1) / 2;
+    e->lazy_lo = e->lazy_hi = -1;
+    if (c1 > c0) FSK_HIP(hipMemsetAsync(e->d_K + c0, 0, (size_t)(c1 - c0) * sizeof(u64), e->stream));
+    return FSK_OK;
+}
+bool lazy_zero_possible(const fsk_engine* e) {
+    return e->path == FSK_PATH_DENSE && e->tile_dma && !e->compact && !(e->cfg.skip_test_block && e->n_test > 0);
 }
 
 // the U of the first launch of a combo list arrives here (profile mode only)
@@ -626,6 +646,20 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
         if (e->force_splits > 0) n_splits = std::min({nb, e->force_splits, 4096});
         const int slots_per_split = (nb + n_splits - 1) / n_splits;
         n_splits = (nb + slots_per_split - 1) / slots_per_split;
+        // Store instead of add? Only the first launch over rows that are still "zero by contract",
+        // starting at their lower edge, with one workgroup per tile and the engine's own triangle.
+        int store = 0;
+        if (e->lazy_lo >= 0) {
+            if (K == e->d_K && e->tile_dma && !compact && n_splits == 1 && first_test_tile == 0xffffffffu && row0 == e->lazy_lo &&
+                row1 <= e->lazy_hi) {
+                store = 1;
+                e->lazy_lo = row1 < e->lazy_hi ? row1 : -1;
+                if (e->lazy_lo < 0) e->lazy_hi = -1;
+            } else {
+                int rcz = materialise_zero(e);
+                if (rcz) return rcz;
+            }
+        }
         e->tic();
         if (compact)
             FSK_LAUNCH(fsk::k_dense_tile_compact, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C4.p,
@@ -633,7 +667,7 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
                        (const uint16_t*)e->d_vc.p);
         else if (e->tile_dma)
             FSK_LAUNCH(fsk::k_dense_tile_dma, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C4.p, e->d_C4H.p,
-                       e->d_rowmask.p, e->d_tiletab.p, nb, Vq8, nst, (uint32_t)e->N, K, slots_per_split);
+                       e->d_rowmask.p, e->d_tiletab.p, nb, Vq8, nst, (uint32_t)e->N, K, slots_per_split, store);
         else
             FSK_LAUNCH(fsk::k_dense_tile, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C4.p, e->d_C4H.p,
                        e->d_rowmask.p, e->d_tiletab.p, nb, Vq8, nst, (uint32_t)e->N, K, slots_per_split);
@@ -700,6 +734,7 @@ void default_order(fsk_engine* e) {
 
 // variance mode: T sequential Welford chains (fastsk_kernel.cpp:188-262, 286-315)
 int run_variance_mode(fsk_engine* e, int T) {
+    { int rcz = materialise_zero(e); if (rcz) return rcz; }
     const int64_t pairs = e->pairs;
     const int64_t train_pairs = (int64_t)((e->n_train / (double)2) * (e->n_train + 1));
     const size_t tp = (size_t)std::max<int64_t>(1, train_pairs);
@@ -871,6 +906,7 @@ int run_variance_mode(fsk_engine* e, int T) {
 }
 
 int fetch_block(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1, double* out) {
+    { int rcz = materialise_zero(e); if (rcz) return rcz; }
     if (!e->finalized) return e->fail(FSK_ESTATE, "no finalized kernel: call fsk_compute or fsk_finalize first");
     if (i0 < 0 || j0 < 0 || i1 > e->N || j1 > e->N || i0 > i1 || j0 > j1) return e->fail(FSK_EINVAL, "block out of range");
     const int64_t rows = i1 - i0, cols = j1 - j0;
@@ -1093,6 +1129,7 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
     e->n_panels = (uint32_t)((N + fsk::PANEL - 1) / fsk::PANEL);
     e->h_len = len32; e->h_fstart = fstart; e->featseq_ready = false;
     e->prep_valid = false; e->tab_n = 0; e->vc_sum = 0; e->vc_n = 0;
+    e->lazy_lo = e->lazy_hi = -1;  // (the triangle is filled with zeros below)
     e->u_known = false; e->u_pending = false; e->u_extra = 0; e->u_value = 0;
     if (e->V > DENSE_MAX_KEYS) e->Vq = 1;  // unused on the sparse path
     int rc = choose_path(e);
@@ -1138,6 +1175,12 @@ int fsk_bind_counts(fsk_engine* e, void* device_u64, int64_t n_cells) {
     if (!e) return FSK_EINVAL;
     if (!device_u64 || n_cells <= 0) return e->fail(FSK_EINVAL, "bad counts buffer");
     if (e->loaded && n_cells != e->pairs) return e->fail(FSK_EINVAL, "counts buffer holds %lld cells, need %lld", (long long)n_cells, (long long)e->pairs);
+    if (e->lazy_lo >= 0) {
+        FSK_HIP(hipSetDevice(e->cfg.device));
+        int rcz = materialise_zero(e);
+        if (rcz) return rcz;
+        FSK_HIP(hipStreamSynchronize(e->stream));
+    }
     if (e->K_owned) e->K_store.release();
     e->bound_cells = n_cells;
     e->d_K = (u64*)device_u64;
@@ -1157,7 +1200,12 @@ int fsk_reset_counts(fsk_engine* e) {
     if (!e) return FSK_EINVAL;
     if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
     FSK_HIP(hipSetDevice(e->cfg.device));
-    FSK_HIP(hipMemsetAsync(e->d_K, 0, (size_t)e->pairs * sizeof(u64), e->stream));
+    if (lazy_zero_possible(e)) {
+        e->lazy_lo = 0; e->lazy_hi = e->N;  // (whatever was pending is covered by this range)
+    } else {
+        e->lazy_lo = e->lazy_hi = -1;
+        FSK_HIP(hipMemsetAsync(e->d_K, 0, (size_t)e->pairs * sizeof(u64), e->stream));
+    }
     e->finalized = false; e->result_f64 = false;
     e->st.combos_done = 0;
     e->prep_valid = false;  // a new pass recounts its panels even when its first band starts at row > 0
@@ -1170,7 +1218,12 @@ int fsk_reset_counts_rows(fsk_engine* e, int64_t row_begin, int64_t row_end) {
     if (row_begin < 0 || row_end > e->N || row_begin > row_end) return e->fail(FSK_EINVAL, "bad row range");
     FSK_HIP(hipSetDevice(e->cfg.device));
     const u64 c0 = (u64)row_begin * ((u64)row_begin + 1) / 2, c1 = (u64)row_end * ((u64)row_end + 1) / 2;
-    if (c1 > c0) FSK_HIP(hipMemsetAsync(e->d_K + c0, 0, (size_t)(c1 - c0) * sizeof(u64), e->stream));
+    { int rcz = materialise_zero(e); if (rcz) return rcz; }  // an earlier, different reset
+    if (lazy_zero_possible(e) && row_begin % fsk::TILE == 0 && row_end > row_begin) {
+        e->lazy_lo = row_begin; e->lazy_hi = row_end;
+    } else if (c1 > c0) {
+        FSK_HIP(hipMemsetAsync(e->d_K + c0, 0, (size_t)(c1 - c0) * sizeof(u64), e->stream));
+    }
     e->finalized = false; e->result_f64 = false;
     e->st.combos_done = 0;
     e->prep_valid = false;
@@ -1203,6 +1256,7 @@ int fsk_accumulate_rows(fsk_engine* e, const int32_t* combos, int32_t n, int64_t
 int fsk_synchronize(fsk_engine* e) {
     if (!e) return FSK_EINVAL;
     FSK_HIP(hipSetDevice(e->cfg.device));
+    { int rcz = materialise_zero(e); if (rcz) return rcz; }
     FSK_HIP(hipStreamSynchronize(e->stream));
     FSK_HIP(hipGetLastError());
     return FSK_OK;
@@ -1212,6 +1266,7 @@ int fsk_finalize(fsk_engine* e) {
     if (!e) return FSK_EINVAL;
     if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
     FSK_HIP(hipSetDevice(e->cfg.device));
+    { int rcz = materialise_zero(e); if (rcz) return rcz; }
     return make_diag(e);
 }
 
@@ -1261,6 +1316,7 @@ int fsk_get_block_device(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int6
     if (rows == 0 || cols == 0) return FSK_OK;
     if (!device_out) return e->fail(FSK_EINVAL, "null output");
     FSK_HIP(hipSetDevice(e->cfg.device));
+    { int rcz = materialise_zero(e); if (rcz) return rcz; }
     const u64 max_cells = (u64)1 << 31;  // grid.x limit: launch in row chunks
     const u64 rows_per = std::max<u64>(1, std::min<u64>(rows, max_cells / cols));
     for (u64 r = 0; r < rows; r += rows_per) {
@@ -1293,6 +1349,7 @@ int fsk_get_triangle(fsk_engine* e, double* out) {
     if (!e->finalized) return e->fail(FSK_ESTATE, "no finalized kernel");
     if (!out) return e->fail(FSK_EINVAL, "null output");
     FSK_HIP(hipSetDevice(e->cfg.device));
+    { int rcz = materialise_zero(e); if (rcz) return rcz; }
     const u64 chunk = (u64)32 << 20;
     FSK_HIP(e->d_stage.reserve((size_t)std::min<u64>(chunk, (u64)e->pairs)));
     for (u64 c0 = 0; c0 < (u64)e->pairs; c0 += chunk) {
@@ -1314,6 +1371,7 @@ int fsk_get_counts(fsk_engine* e, uint64_t* out) {
     if (e->result_f64) return e->fail(FSK_ESTATE, "variance mode keeps a floating-point mean, not integer counts");
     if (!out) return e->fail(FSK_EINVAL, "null output");
     FSK_HIP(hipSetDevice(e->cfg.device));
+    { int rcz = materialise_zero(e); if (rcz) return rcz; }
     FSK_HIP(hipStreamSynchronize(e->stream));
     FSK_HIP(hipMemcpy(out, e->d_K, (size_t)e->pairs * sizeof(u64), hipMemcpyDeviceToHost));
     return FSK_OK;
@@ -1325,6 +1383,7 @@ int fsk_get_counts_block(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int6
     if (e->result_f64) return e->fail(FSK_ESTATE, "variance mode keeps a floating-point mean, not integer counts");
     if (i0 < 0 || j0 < 0 || i1 > e->N || j1 > e->N || i0 > i1 || j0 > j1) return e->fail(FSK_EINVAL, "block out of range");
     FSK_HIP(hipSetDevice(e->cfg.device));
+    { int rcz = materialise_zero(e); if (rcz) return rcz; }
     const int64_t rows = i1 - i0, cols = j1 - j0;
     if (rows == 0 || cols == 0) return FSK_OK;
     if (!out) return e->fail(FSK_EINVAL, "null output");

@@ -125,6 +125,56 @@ def test_emu_variance_mode_stops_anywhere(emu_lib, port):
     assert len(lengths) >= 6  # stops landed at many different places inside the batches
 
 
+def test_emu_reset_then_storing_launch(emu_lib, port, monkeypatch):
+    """fsk_reset_counts leaves the zeros to the next tile launch when that launch can STORE its
+    sums (dense dataflow, one workgroup per tile, rows starting at the reset range's lower edge);
+    every other consumer of K gets the zeros filled in first."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(123)
+    N = 520
+    X = rng.integers(1, 5, size=(N, 48), dtype=np.int32)
+    X[::11, 5:40] = 2   # rows with counts above 15
+    tokens, offsets = _native.flatten(X)
+    ca, cb = np.arange(0, 70, 3, dtype=np.int32), np.arange(1, 70, 4, dtype=np.int32)
+    wa, _, _ = port.raw_counts(tokens, offsets, 8, 4, ca, threads=4)
+    wb, _, _ = port.raw_counts(tokens, offsets, 8, 4, cb, threads=4)
+    cell = lambda r: r * (r + 1) // 2
+    for splits in ("1", "0"):   # "1": one workgroup per tile -> the storing launch; "0": automatic splits -> zero fill + atomics
+        monkeypatch.setenv("FSK_TILE_SPLITS", splits)
+        e = _native.Engine(8, 4, path=1, lib=emu_lib)
+        e.load_sequences(tokens, offsets, N, 0)
+        e.accumulate(ca)                        # K now holds data that every reset below must erase
+        e.reset_counts(); e.accumulate(cb); e.finalize()
+        assert np.array_equal(e.get_counts(), wb), splits
+        e.reset_counts()
+        assert not e.get_counts().any()         # a getter right after the reset sees zeros
+        e.accumulate(ca); e.accumulate(cb); e.finalize()
+        assert np.array_equal(e.get_counts(), wa + wb)
+        e.reset_counts()                        # ascending row bands: the first stores, the rest of the reset range follows
+        for lo, hi in ((0, 128), (128, 384), (384, N)):
+            e.accumulate_rows(cb, lo, hi)
+        e.finalize()
+        assert np.array_equal(e.get_counts(), wb)
+        e.reset_counts()                        # bands out of order: the fill must happen before the first of them
+        for lo, hi in ((256, N), (0, 256)):
+            e.accumulate_rows(ca, lo, hi)
+        e.finalize()
+        assert np.array_equal(e.get_counts(), wa)
+        e.reset_counts_rows(128, 384)           # only these rows are reset; the others keep `wa`
+        e.accumulate_rows(cb, 128, 384)
+        e.synchronize()
+        want = wa.copy()
+        want[cell(128):cell(384)] = wb[cell(128):cell(384)]
+        assert np.array_equal(e.get_counts(), want)
+        e.reset_counts_rows(128, 384)           # reset rows, then touch OTHER rows first
+        e.accumulate_rows(cb, 0, 128)
+        e.accumulate_rows(cb, 128, 384)
+        e.finalize()
+        want[cell(0):cell(128)] += wb[cell(0):cell(128)]
+        assert np.array_equal(e.get_counts(), want)
+        e.close()
+
+
 def test_emu_bound_counts_buffer_and_reset(emu_lib, port):
     """fsk_bind_counts: the integer triangle lives in caller-provided memory (on the GPU: a torch
     tensor that RCCL all-reduces). Under emulation device memory is host memory."""

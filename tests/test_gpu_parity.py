@@ -366,6 +366,55 @@ def test_diag_exchange_on_a_triangle_beyond_2_31_cells():
     assert int(K.sum()) == N * (N + 1) // 2 - sum(range(1, 1001)) - sum(range(N - 999, N + 1))
 
 
+def test_reset_then_storing_launch(native, port, monkeypatch):
+    """fsk_reset_counts leaves the zeros to the next tile launch when that launch can STORE its
+    sums (dense dataflow, one workgroup per tile, rows starting at the reset range's lower edge);
+    every other consumer of K gets the zeros filled in first."""
+    rng = np.random.default_rng(123)
+    N = 520
+    X = rng.integers(1, 5, size=(N, 48), dtype=np.int32)
+    X[::11, 5:40] = 2   # rows with counts above 15
+    tokens, offsets = native.flatten(X)
+    ca, cb = np.arange(0, 70, 3, dtype=np.int32), np.arange(1, 70, 4, dtype=np.int32)
+    wa, _, _ = port.raw_counts(tokens, offsets, 8, 4, ca, threads=4)
+    wb, _, _ = port.raw_counts(tokens, offsets, 8, 4, cb, threads=4)
+    cell = lambda r: r * (r + 1) // 2
+    for splits in ("1", "0"):   # "1": one workgroup per tile -> the storing launch; "0": automatic splits -> zero fill + atomics
+        monkeypatch.setenv("FSK_TILE_SPLITS", splits)
+        e = native.Engine(8, 4, path=1)
+        e.load_sequences(tokens, offsets, N, 0)
+        e.accumulate(ca)                        # K now holds data that every reset below must erase
+        e.reset_counts(); e.accumulate(cb); e.finalize()
+        assert np.array_equal(e.get_counts(), wb), splits
+        e.reset_counts()
+        assert not e.get_counts().any()         # a getter right after the reset sees zeros
+        e.accumulate(ca); e.accumulate(cb); e.finalize()
+        assert np.array_equal(e.get_counts(), wa + wb)
+        e.reset_counts()                        # ascending row bands: the first stores, the rest of the reset range follows
+        for lo, hi in ((0, 128), (128, 384), (384, N)):
+            e.accumulate_rows(cb, lo, hi)
+        e.finalize()
+        assert np.array_equal(e.get_counts(), wb)
+        e.reset_counts()                        # bands out of order: the fill must happen before the first of them
+        for lo, hi in ((256, N), (0, 256)):
+            e.accumulate_rows(ca, lo, hi)
+        e.finalize()
+        assert np.array_equal(e.get_counts(), wa)
+        e.reset_counts_rows(128, 384)           # only these rows are reset; the others keep `wa`
+        e.accumulate_rows(cb, 128, 384)
+        e.synchronize()
+        want = wa.copy()
+        want[cell(128):cell(384)] = wb[cell(128):cell(384)]
+        assert np.array_equal(e.get_counts(), want)
+        e.reset_counts_rows(128, 384)           # reset rows, then touch OTHER rows first
+        e.accumulate_rows(cb, 0, 128)
+        e.accumulate_rows(cb, 128, 384)
+        e.finalize()
+        want[cell(0):cell(128)] += wb[cell(0):cell(128)]
+        assert np.array_equal(e.get_counts(), want)
+        e.close()
+
+
 def test_register_staged_tile_kernel_still_agrees(native, port, monkeypatch):
     """FSK_TILE_DMA=0 selects k_dense_tile (register-staged panels) instead of the default
     k_dense_tile_dma (direct-to-LDS loads): same counts, including rows with counts above 15 and a
