@@ -135,6 +135,9 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
 int fsk_bind_counts(fsk_engine* e, void* device_u64, int64_t n_cells);
 /* device address of the integer triangle (engine-owned or bound) */
 int fsk_counts_device_ptr(fsk_engine* e, void** out);
+/* Zero the integer triangle before another pass. The zeros may be written by the next tile launch
+ * itself (it then stores its sums instead of adding them); every other reader of the triangle,
+ * including fsk_synchronize — after which a caller may read a bound buffer — sees them. */
 int fsk_reset_counts(fsk_engine* e);
 /* zero only rows [row_begin, row_end) of the triangle (a rank that owns a band of rows) */
 int fsk_reset_counts_rows(fsk_engine* e, int64_t row_begin, int64_t row_end);
