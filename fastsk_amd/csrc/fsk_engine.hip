@@ -225,10 +225,20 @@ DensePlan dense_plan(uint32_t maxW, int g, uint32_t Vq, size_t extra = 0) {
 bool dense_is_cheaper(const fsk_engine* e) {
     const double N = (double)e->N, V = (double)e->V;
     const double W = (double)e->nfeat / std::max(1.0, N);                 // windows per sequence
-    const double dense = 0.5 * N * N * (double)(((e->Vq + 1) / 2) * 8) / 2.9e14 + (double)e->nfeat * 4e-11;
-    const double d = N * (1.0 - std::exp(-W / V));                          // sequences holding a given key
+    // dense: every pair of sequences over the whole key space at the tile kernel's rate, plus the
+    // count kernel: one pass over the windows per histogram sweep (large key spaces need many)
+    const DensePlan plan = dense_plan(e->maxW, e->cfg.g, e->Vq);
+    const double sweeps = plan.Vcq ? std::ceil((double)e->Vq / plan.Vcq) : 1.0;
+    const double dense = 0.5 * N * N * (double)(((e->Vq + 1) / 2) * 8) / 3.0e14 + (double)e->nfeat * (4e-11 + (sweeps - 1.0) * 6e-12);
+    // sparse: sort + segments per g-mer, then one update per (run, pair). d = sequences holding a
+    // given key. Owner-slice LDS accumulation (N <= 8192) runs at 4e10 updates/s on short runs
+    // and up to 1.6e11 on long ones (partner ranges become contiguous reads); per-pair global
+    // atomics at 1.6e10.
+    const double d = N * (1.0 - std::exp(-W / V));
     const double U = V * d * (d + 1.0) / 2.0;
-    const double sparse = U / 1.6e10 + (double)e->nfeat * 3.0 / 2.0e10;
+    const bool owner_slices = N <= 8192.0;
+    const double rate = owner_slices ? 4.0e10 * std::min(4.0, std::max(1.0, d / 4.0)) : 1.6e10;
+    const double sparse = U / rate + (double)e->nfeat * 7e-11;
     return dense <= sparse;
 }
 
