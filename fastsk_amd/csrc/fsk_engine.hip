@@ -227,9 +227,16 @@ bool dense_is_cheaper(const fsk_engine* e) {
     const double W = (double)e->nfeat / std::max(1.0, N);                 // windows per sequence
     // dense: every pair of sequences over the whole key space at the tile kernel's rate, plus the
     // count kernel: one pass over the windows per histogram sweep (large key spaces need many)
-    const DensePlan plan = dense_plan(e->maxW, e->cfg.g, e->Vq);
+    // (a later sweep costs 6e-12 s per window when the window keys are cached in LDS, as
+    // accumulate_dense arranges when they fit, and 2e-11 s when they are recomputed)
+    DensePlan plan = dense_plan(e->maxW, e->cfg.g, e->Vq);
+    double sweep_cost = 2e-11;
+    if (plan.Vcq && plan.Vcq < e->Vq && plan.CH >= e->maxW) {
+        const DensePlan p2 = dense_plan(e->maxW, e->cfg.g, e->Vq, (size_t)e->maxW * fsk::PANEL * sizeof(uint16_t));
+        if (p2.CH >= e->maxW && p2.Vcq >= 64) { plan = p2; sweep_cost = 6e-12; }
+    }
     const double sweeps = plan.Vcq ? std::ceil((double)e->Vq / plan.Vcq) : 1.0;
-    const double dense = 0.5 * N * N * (double)(((e->Vq + 1) / 2) * 8) / 3.0e14 + (double)e->nfeat * (4e-11 + (sweeps - 1.0) * 6e-12);
+    const double dense = 0.5 * N * N * (double)(((e->Vq + 1) / 2) * 8) / 3.0e14 + (double)e->nfeat * (4e-11 + (sweeps - 1.0) * sweep_cost);
     // sparse: sort + segments per g-mer, then one update per (run, pair). d = sequences holding a
     // given key. Owner-slice LDS accumulation (N <= 8192) runs at 4e10 updates/s on short runs
     // and up to 1.6e11 on long ones (partner ranges become contiguous reads); per-pair global
@@ -550,7 +557,9 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
             FSK_HIP(hipMemsetAsync(e->d_flag.p, 0, sizeof(uint32_t), e->stream));
             FSK_HIP(hipStreamSynchronize(e->stream));  // `pos` is a pageable temporary
             // ---- segment counts
-            const int slots_per_chunk = std::max(1, std::min(nb, 16));
+            // up to 16 combos share one staging of a panel's symbols, fewer when that would leave the
+            // launch with less than ~1024 workgroups (few sequences)
+            const int slots_per_chunk = std::max(1, std::min({nb, 16, (int)((u64)nb * panels_pad / 1024)}));
             const int n_chunks = (nb + slots_per_chunk - 1) / slots_per_chunk;
             e->tic();
             const dim3 cgrid(panels_pad, n_chunks);
