@@ -227,25 +227,29 @@ bool dense_is_cheaper(const fsk_engine* e) {
     const double W = (double)e->nfeat / std::max(1.0, N);                 // windows per sequence
     // dense: every pair of sequences over the whole key space at the tile kernel's rate, plus the
     // count kernel: one pass over the windows per histogram sweep (large key spaces need many)
-    // (a later sweep costs 6e-12 s per window when the window keys are cached in LDS, as
-    // accumulate_dense arranges when they fit, and 2e-11 s when they are recomputed)
+    // (count kernel, fitted on MI355X: 1e-12 s per window for the first histogram sweep, 2.6e-12 s
+    // per window for every further sweep when the window keys are cached in LDS — as
+    // accumulate_dense arranges when they fit — and 8e-12 s when they are recomputed; 7e-13 s per
+    // (sequence, key) for zeroing and reading out the histograms)
     DensePlan plan = dense_plan(e->maxW, e->cfg.g, e->Vq);
-    double sweep_cost = 2e-11;
+    double sweep_cost = 8e-12;
     if (plan.Vcq && plan.Vcq < e->Vq && plan.CH >= e->maxW) {
         const DensePlan p2 = dense_plan(e->maxW, e->cfg.g, e->Vq, (size_t)e->maxW * fsk::PANEL * sizeof(uint16_t));
-        if (p2.CH >= e->maxW && p2.Vcq >= 64) { plan = p2; sweep_cost = 6e-12; }
+        if (p2.CH >= e->maxW && p2.Vcq >= 64) { plan = p2; sweep_cost = 2.6e-12; }
     }
     const double sweeps = plan.Vcq ? std::ceil((double)e->Vq / plan.Vcq) : 1.0;
-    const double dense = 0.5 * N * N * (double)(((e->Vq + 1) / 2) * 8) / 3.0e14 + (double)e->nfeat * (4e-11 + (sweeps - 1.0) * sweep_cost);
+    // (tile kernel: 3.0e14 count-MAC/s with thousands of tiles, ~2.4e14 with few)
+    const double dense = 0.5 * N * N * (double)(((e->Vq + 1) / 2) * 8) / (N < 8192.0 ? 2.4e14 : 3.0e14) +
+                         (double)e->nfeat * (1e-12 + (sweeps - 1.0) * sweep_cost) + N * V * 7e-13;
     // sparse: sort + segments per g-mer, then one update per (run, pair). d = sequences holding a
     // given key. Owner-slice LDS accumulation (N <= 8192) runs at 4e10 updates/s on short runs
-    // and up to 1.6e11 on long ones (partner ranges become contiguous reads); per-pair global
-    // atomics at 1.6e10.
+    // and up to 2.4e11 on long ones (partner ranges become contiguous reads); per-pair global
+    // atomics at 1.6e10. Sort + segments: 3.5e-11 s per g-mer.
     const double d = N * (1.0 - std::exp(-W / V));
     const double U = V * d * (d + 1.0) / 2.0;
     const bool owner_slices = N <= 8192.0;
-    const double rate = owner_slices ? 4.0e10 * std::min(4.0, std::max(1.0, d / 4.0)) : 1.6e10;
-    const double sparse = U / rate + (double)e->nfeat * 7e-11;
+    const double rate = owner_slices ? 4.0e10 * std::min(6.0, std::max(1.0, d / 4.0)) : 1.6e10;
+    const double sparse = U / rate + (double)e->nfeat * 3.5e-11;
     return dense <= sparse;
 }
 

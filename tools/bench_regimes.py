@@ -16,7 +16,7 @@ from fastsk_amd import _native  # noqa: E402
 def run(tokens, offsets, N, g, m, combos, path):
     e = _native.Engine(g, m, path=path, profile=False)
     e.load_sequences(tokens, offsets, N, 0)
-    e.accumulate(combos[:2])
+    e.accumulate(combos)  # warm-up with the same list: every buffer reaches its final size
     e.synchronize()
     e.reset_counts()
     t0 = time.perf_counter()
