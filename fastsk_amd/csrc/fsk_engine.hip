@@ -1086,17 +1086,31 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
     // dict_size = |{0} U tokens|, fastsk.cpp:70-85, only serves as its counting-sort radix)
     const int64_t total = offsets[N];
     std::vector<int32_t> distinct;
+    std::vector<int64_t> tok_hist;  // occurrences per token value when every token lies in [0, 65536): one pass
     {
-        int32_t lo = INT32_MAX, hi = INT32_MIN;
-        for (int64_t i = 0; i < total; ++i) { lo = std::min(lo, tokens[i]); hi = std::max(hi, tokens[i]); }
-        if (total > 0 && lo >= 0 && hi < (1 << 20)) {
-            std::vector<char> seen((size_t)hi + 1, 0);
-            for (int64_t i = 0; i < total; ++i) seen[tokens[i]] = 1;
-            for (int32_t v = 0; v <= hi; ++v) if (seen[v]) distinct.push_back(v);
+        tok_hist.assign(65536, 0);
+        bool small = true;
+        for (int64_t i = 0; i < total; ++i) {
+            const uint32_t t = (uint32_t)tokens[i];
+            if (t < 65536u) tok_hist[t]++;
+            else { small = false; break; }
+        }
+        if (small) {
+            for (int32_t v = 0; v < 65536; ++v)
+                if (tok_hist[v]) distinct.push_back(v);
         } else {
-            distinct.assign(tokens, tokens + total);
-            std::sort(distinct.begin(), distinct.end());
-            distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+            tok_hist.clear();
+            int32_t lo = INT32_MAX, hi = INT32_MIN;
+            for (int64_t i = 0; i < total; ++i) { lo = std::min(lo, tokens[i]); hi = std::max(hi, tokens[i]); }
+            if (total > 0 && lo >= 0 && hi < (1 << 20)) {
+                std::vector<char> seen((size_t)hi + 1, 0);
+                for (int64_t i = 0; i < total; ++i) seen[tokens[i]] = 1;
+                for (int32_t v = 0; v <= hi; ++v) if (seen[v]) distinct.push_back(v);
+            } else {
+                distinct.assign(tokens, tokens + total);
+                std::sort(distinct.begin(), distinct.end());
+                distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+            }
         }
     }
     if (distinct.size() > 256) return e->fail(FSK_EUNSUPPORTED, "alphabet of %zu symbols (> 256)", distinct.size());
@@ -1131,15 +1145,38 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
             lut.assign((size_t)(distinct.back() - base) + 1, 0);
             for (size_t r = 0; r < distinct.size(); ++r) lut[(size_t)(distinct[r] - base)] = (uint8_t)r;
         }
-        for (int64_t i = 0; i < N; ++i) {
-            const int32_t* s = tokens + offsets[i];
-            uint32_t* w = words.data() + wstart[i];
-            for (uint32_t p = 0; p < len32[i]; ++p) {
-                uint32_t r = direct ? lut[(size_t)(s[p] - base)]
-                                    : (uint32_t)(std::lower_bound(distinct.begin(), distinct.end(), s[p]) - distinct.begin());
-                const uint32_t bitpos = p * (uint32_t)bits;
-                w[bitpos >> 5] |= r << (bitpos & 31u);
-                sym_freq[r]++;
+        if (direct && !tok_hist.empty()) {
+            // frequencies are known from the histogram: the packing loop builds whole words
+            for (size_t r = 0; r < distinct.size(); ++r) sym_freq[r] = tok_hist[(size_t)distinct[r]];
+            const uint32_t per_word = 32u / (uint32_t)bits;
+            const uint8_t* lt = lut.data();
+            for (int64_t i = 0; i < N; ++i) {
+                const int32_t* sq = tokens + offsets[i];
+                uint32_t* w = words.data() + wstart[i];
+                const uint32_t len = len32[i];
+                uint32_t p = 0;
+                for (; p + per_word <= len; p += per_word) {
+                    uint32_t word = 0;
+                    for (uint32_t q = 0; q < per_word; ++q) word |= (uint32_t)lt[sq[p + q] - base] << (q * (uint32_t)bits);
+                    *w++ = word;
+                }
+                if (p < len) {
+                    uint32_t word = 0;
+                    for (uint32_t q = 0; p + q < len; ++q) word |= (uint32_t)lt[sq[p + q] - base] << (q * (uint32_t)bits);
+                    *w = word;
+                }
+            }
+        } else {
+            for (int64_t i = 0; i < N; ++i) {
+                const int32_t* sq = tokens + offsets[i];
+                uint32_t* w = words.data() + wstart[i];
+                for (uint32_t p = 0; p < len32[i]; ++p) {
+                    uint32_t r = direct ? lut[(size_t)(sq[p] - base)]
+                                        : (uint32_t)(std::lower_bound(distinct.begin(), distinct.end(), sq[p]) - distinct.begin());
+                    const uint32_t bitpos = p * (uint32_t)bits;
+                    w[bitpos >> 5] |= r << (bitpos & 31u);
+                    sym_freq[r]++;
+                }
             }
         }
     }
