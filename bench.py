@@ -271,8 +271,16 @@ def main():
             ns = min(args.cpu_sample, N)
             kind, cores, measured, nc, secs = cpu_baseline(X, g, m, ns, args.cpu_seconds)
             scale = (ns / N) ** 2
+            cpu_model = ""
+            try:
+                for line in open("/proc/cpuinfo"):
+                    if line.startswith("model name"):
+                        cpu_model = line.split(":", 1)[1].strip()
+                        break
+            except OSError:
+                pass
             out["cpu_baseline"] = {
-                "value": measured * scale, "unit": "combos/s", "cores": cores, "kind": kind,
+                "value": measured * scale, "unit": "combos/s", "cores": cores, "kind": kind, "cpu_model": cpu_model,
                 "measured_at_sample": measured,
                 "sample": "first %d of %d sequences, %d of %d combos, %.1f s on %d threads: %.3f combos/s at N=%d; "
                           "value = that x (%d/%d)^2 (count time scales as N^2; the reference itself cannot index N > 46340)"
