@@ -69,24 +69,50 @@ def cpu_baseline(X, g, m, n_sample, budget_s):
 
 
 def other_configs(_native):
-    """BASELINE configs[1] (EP300 DNA, 2000+2000 x 100 bp, g=10 m=6 exact) on the same GPU: the
-    whole fsk_compute call, host buffers in, result resident on the device (best of 3)."""
+    """The other BASELINE configs on the same GPU: the whole fsk_compute call, host buffers in, result
+    resident on the device (best of 4). Config 2 = BASELINE configs[1] (EP300 DNA, 2000+2000 x 100 bp,
+    g=10 m=6 exact); configs 1, 3, 4 from the golden descriptors (same modes and combo orders as the
+    parity tests)."""
+    out = {}
     path = os.path.join(ROOT, "tests", "golden", "tokens_EP300.npz")
-    if not os.path.exists(path):
-        return None
-    z = np.load(path)
-    tokens, offsets = z["tokens"].astype(np.int32), z["offsets"].astype(np.int64)
-    ntr, nte = int(z["n_train"]), int(z["n_test"])
-    e = _native.Engine(10, 6)
-    best = 1e9
-    for _ in range(4):
-        t0 = time.perf_counter()
-        e.compute(tokens, offsets, ntr, nte)
-        best = min(best, time.perf_counter() - t0)
-    e.close()
-    return {"config2_ep300_exact": {"n_seq": ntr + nte, "seq_len": 100, "g": 10, "m": 6, "combos": 210,
-                                    "seconds": best, "combos_per_s": 210 / best,
-                                    "reference_cpu_seconds_8_threads": 29.9}}
+    if os.path.exists(path):
+        z = np.load(path)
+        tokens, offsets = z["tokens"].astype(np.int32), z["offsets"].astype(np.int64)
+        ntr, nte = int(z["n_train"]), int(z["n_test"])
+        e = _native.Engine(10, 6)
+        best = 1e9
+        for _ in range(4):
+            t0 = time.perf_counter()
+            e.compute(tokens, offsets, ntr, nte)
+            best = min(best, time.perf_counter() - t0)
+        e.close()
+        out["config2_ep300_exact"] = {"n_seq": ntr + nte, "seq_len": 100, "g": 10, "m": 6, "combos": 210, "seconds": best,
+                                      "combos_per_s": 210 / best, "reference_cpu_seconds_8_threads": 29.9}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from conftest import load_golden, load_tokens, GOLD
+        for key, name in (("config1_prot11_approx_t1", "f7_cfg1_prot11_approx_t1"), ("config3_ep47848_100combos", "f7_cfg3_ep47848_100combos"),
+                          ("config4_prot219_exact", "f7_cfg4_prot219_exact")):
+            if not os.path.exists(os.path.join(GOLD, name + ".npz")):
+                continue
+            d = load_golden(name)
+            tokens, offsets, ntr, nte, _, _ = load_tokens(d["data"])
+            e = _native.Engine(d["g"], d["m"], t=d["t"], approx=bool(d["approx"]), delta=d["delta"], max_iters=d["max_iters"],
+                               skip_variance=bool(d["skip_variance"]))
+            if d["approx"]:
+                e.set_combo_order(d["order"])
+            best = 1e9
+            for _ in range(4):
+                t0 = time.perf_counter()
+                e.compute(tokens, offsets, ntr, nte)
+                best = min(best, time.perf_counter() - t0)
+            done = int(e.stats()["combos_done"])
+            e.close()
+            out[key] = {"n_seq": ntr + nte, "g": int(d["g"]), "m": int(d["m"]), "combos": done, "seconds": best,
+                        "combos_per_s": done / best, "reference_cpu_seconds": float(d["ref_seconds"])}
+    except Exception as exc:  # the headline line must not depend on the extras
+        out["error"] = repr(exc)
+    return out or None
 
 
 def describe(mode, world, replicate):
