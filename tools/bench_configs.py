@@ -39,7 +39,12 @@ def main():
             e.close()
             if not profile:
                 wall = dt
+        # algorithmic bytes of the direct-atomic dataflow, 16*U + 16*P*nfeat + packed input per combo
+        P = max(1, (d["g"] - d["m"]) * st["bits_per_symbol"] + 7) // 8
+        alg = 16.0 * st["cell_updates"] + st["combos_done"] * (16.0 * P * st["n_feat"] + st["n_feat"] * st["bits_per_symbol"] / 8.0)
         rows.append(dict(case=name, N=ntr + nte, combos=int(st["combos_done"]), gpu_seconds=wall,
+                         algorithmic_GB=round(alg / 1e9, 2), algorithmic_GB_per_s=round(alg / 1e9 / wall, 1),
+                         frac_of_8TBps=round(alg / 1e9 / wall / 8000.0, 3),
                          combos_per_s=st["combos_done"] / wall, ref_cpu_seconds=float(d["ref_seconds"]),
                          path="dense" if st["path_used"] == 1 else "sparse", U=int(st["cell_updates"]),
                          launches=st["launches"],
