@@ -6,6 +6,7 @@ the same library. There is no CPU fallback: if the HIP library is missing this m
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -56,10 +57,41 @@ SYMBOLS = ["fsk_create", "fsk_destroy", "fsk_last_error", "fsk_abi_version", "fs
            "fsk_combo_positions"]
 
 
+_hip_shared = False
+
+
+def share_hip_runtime_with_torch():
+    """One HIP runtime per process. A PyTorch-ROCm wheel carries its own libamdhip64 /
+    libhsa-runtime64; if this engine binds /opt/rocm's copy first and torch is imported later, the
+    process ends up with two HSA runtimes and the second one to initialise finds no GPU. So when
+    torch is installed but not imported yet, its copies (same SONAMEs) are loaded first and the
+    engine binds to them — exactly what happens anyway when torch is imported before this package.
+    No torch installed: nothing to do, /opt/rocm's runtime is used."""
+    global _hip_shared
+    if _hip_shared or "torch" in sys.modules:
+        _hip_shared = True
+        return
+    _hip_shared = True
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            path = os.path.join(libdir, name)
+            if os.path.exists(path):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass
+
+
 class Library:
     """The loaded shared library with typed entry points."""
 
     def __init__(self, path=None):
+        if path is None:
+            share_hip_runtime_with_torch()  # the product library; an explicit path is the CPU emulation of the tests
         path = path or LIB_PATH
         if not os.path.exists(path):
             raise ImportError(

@@ -341,6 +341,42 @@ def test_bench_two_ranks_sharing_the_gpu(native, shard):
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
 
 
+@pytest.mark.parametrize("surface", ["ctypes", "pybind"])
+def test_engine_before_torch_in_one_process(native, surface):
+    """A PyTorch-ROCm wheel carries its own HIP/HSA runtime; two runtimes in one process leave the
+    second without a GPU. Importing the engine FIRST and torch afterwards must still give both a
+    working device (fastsk_amd binds to torch's copies when torch is installed)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = """
+import sys
+sys.path.insert(0, %r)
+X = [[1, 2, 3, 1, 2, 3, 1], [2, 3, 1, 2, 3, 1, 2], [1, 1, 2, 2, 3, 3, 1]]
+if %r == "ctypes":
+    from fastsk_amd import _native
+    e = _native.Engine(3, 1)
+else:
+    from fastsk import FastSK
+    e = FastSK(3, 1)
+assert "torch" not in sys.modules
+import torch
+assert torch.cuda.is_available()
+assert float(torch.ones(8, device="cuda").sum()) == 8.0
+if %r == "ctypes":
+    tok, off = _native.flatten(X)
+    e.compute(tok, off, 3, 0)
+    K = e.get_train()
+else:
+    e.compute_train(X)
+    K = e.get_train_kernel()
+assert K[0][0] == 1.0 and K[1][1] == 1.0 and 0.0 < K[1][0] <= 1.0
+print("both fine")
+""" % (ROOT, surface, surface)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "both fine" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_diag_exchange_on_a_triangle_beyond_2_31_cells():
     """The row-sharded multi-GPU path gathers and scatters the N diagonal cells of the bound
     triangle with torch indexing; at config 5 that tensor has 5e9 cells. Same indexing here on
