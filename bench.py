@@ -1,28 +1,42 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the gapped-k-mer kernel build (BASELINE.json metric).
 
-A "step" is one pass of the hot path over the whole workload: BASELINE config 5, synthetic
-100,000 x 300 bp DNA, g=12, m=8, exact, all C(12,8)=495 mismatch combinations, with the packed
-sequences already resident in HBM when the timed region starts. With N GPUs the job is the same
-(STRONG scaling: total work fixed) and is sharded one of two ways (fastsk_amd/distributed.py):
-  rows    (default at this size) every rank owns an equal-area band of rows of the triangle and runs
-          all 495 combos over it; no cell is shared, the only exchange is the 0.8 MB diagonal, and
-          the kernel matrix stays distributed over the GPUs;
-  combos  the reference's decomposition: combos c = rank (mod N), every rank accumulates a private
-          triangle, RCCL all-reduces it over xGMI in row bands under the next band's kernels.
-The other of the two is timed for one step afterwards and reported as "alt".
-value = combos/s of the whole job = 495 * steps / max-over-ranks seconds.
+A "step" is one pass of the hot path over the whole workload with the packed sequences already
+resident in HBM when the timed region starts:
+  --config 5 (default)  BASELINE config 5: synthetic 100,000 x 300 bp DNA, g=12, m=8, exact, all
+                        C(12,8)=495 mismatch combinations (dense dataflow);
+  --config 4            BASELINE config 4: protein 2.19 (tests/golden/tokens_2.19.npz), g=14, m=10,
+                        exact, C(14,10)=1001 combinations (sparse dataflow: sort -> segments -> pairs).
+With N GPUs the job is the same (STRONG scaling: total work fixed). `python bench.py --gpus N` starts
+its own ranks (torch.distributed.run, one process per GPU, before this process touches the GPU);
+under an external torch.distributed.run (WORLD_SIZE set) it is one of the ranks. Two decompositions
+(fastsk_amd/distributed.py), both timed with the same --steps/--warmup:
+  combos  (`value`)  the reference's own decomposition (fastsk_kernel.cpp:148,275,286-315) and the
+          one BASELINE.json names: combos c = rank (mod N), every rank accumulates a private
+          triangle, ONE logical RCCL all-reduce sums them over xGMI — issued in row bands on RCCL's
+          stream under the next band's kernels;
+  rows    (`alt`; config 5 only) every rank owns an equal-area band of rows of the triangle and runs
+          all combos over it: no cell is shared, the only exchange is the 0.8 MB diagonal, and the
+          kernel matrix stays distributed.
+--shard rows swaps the two. value = combos/s of the whole job = C(g,m) * steps / max-over-ranks seconds.
 
 One JSON line on rank 0. Extra objects:
-  roofline      the dominant kernel (k_dense_tile_dma) priced on SURVEY 8d's algorithmic bytes
-                (16*U + sort + input bytes per combo) against the 8 TB/s HBM peak, timed with HIP
-                events on the engine's own stream; plus the integer-VALU view of the same launch.
-  cpu_baseline  the compiled reference (oracle/_ref, "reference") or our C restatement ("port")
-                on the host cores, on a bounded sample (smaller N, fewer combos), rank 0 / N=1 only.
+  roofline      the dominant kernel. Config 5: k_dense_tile_dma is bound by the integer-VALU issue
+                rate (v_dot8_u32_u4), so `frac` = count-MACs/s over that peak; the SURVEY 8(d)
+                algorithmic bytes (16*U + sort + input per combo), the measured HBM traffic and the
+                useful-update rate are given beside it. Config 4: the sparse pipeline against the
+                8 TB/s HBM peak on the same algorithmic bytes.
+  cpu_baseline  FastSK's own multithreaded engine (oracle/_ref, kind "reference"; our C restatement
+                as "port" when the compiled reference did not travel) on the host cores at
+                N = 4000 and 8000 of the same generator, T = physical cores and T = 20; rank 0, N=1 only.
+  end_to_end    load (pack + H2D) + one step + a normalised 4k x 4k block: SURVEY 8(d)'s metric boundary.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,6 +52,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 # v_dot8_u32_u4 / v_dot4_u32_u8 issue at HALF the v_fma_f32 rate on gfx950 (measured:
 # profiles/r01_ubench_valu_rates.txt): 64 lanes/clk/CU. Peak = CUs * 64 lanes * 8 MACs * 2.4 GHz.
 VALU_DOT8_PEAK_TMACS = 256 * 64 * 8 * 2.4e9 / 1e12  # = 314.6 T MAC/s
+KERNEL_FILES = ("fastsk_amd/csrc/fsk_kernels.h", "fastsk_amd/csrc/fsk_tile_kernel.inc", "fastsk_amd/csrc/fsk_tile_kernel_dma.inc")
 
 
 def synthetic(N, L, seed=20201214):
@@ -46,26 +61,97 @@ def synthetic(N, L, seed=20201214):
     return X.reshape(-1), np.arange(N + 1, dtype=np.int64) * L, X
 
 
-def cpu_baseline(X, g, m, n_sample, budget_s):
-    """Reference (or port) on the host cores over a bounded sample of the same workload."""
+def git_blob_hash(path):
+    """What `git hash-object` prints (needs no git on the GPU box)."""
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def kernel_hashes():
+    return {f: git_blob_hash(os.path.join(ROOT, f)) for f in KERNEL_FILES}
+
+
+def host_cpus():
+    """(physical cores, logical CPUs, model name) from /proc/cpuinfo."""
+    cores, model, phys, logical = set(), "", None, 0
+    try:
+        for line in open("/proc/cpuinfo"):
+            key, _, val = line.partition(":")
+            key, val = key.strip(), val.strip()
+            if key == "processor":
+                logical += 1
+            elif key == "model name" and not model:
+                model = val
+            elif key == "physical id":
+                phys = val
+            elif key == "core id":
+                cores.add((phys, val))
+    except OSError:
+        pass
+    logical = logical or (os.cpu_count() or 1)
+    return (len(cores) or logical), logical, model
+
+
+def mem_available_bytes():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 1 << 36
+
+
+def cpu_baseline(g, m, L, n_full, budget_s, sizes=(4000, 8000)):
+    """FastSK's own engine on the host cores: the config-5 generator at N = 4000 and 8000,
+    T = 20 (the reference's default, fastsk_kernel.cpp:55-60) and T = physical cores. Each row runs
+    KernelFunction::compute_kernel itself (thread pool, private uint32 triangles, locked reduce,
+    normalisation) on T combos — approx/skip_variance/max_iters=1 makes every thread take exactly one
+    combo, i.e. the budget is kept by trimming combos, never N. A row predicted (from the rows before
+    it: time ~ N^2 per combo, at least constant in T) not to fit the remaining budget is skipped and
+    says so."""
     from oracle import loader
-    cores = os.cpu_count() or 1
-    Xs = np.ascontiguousarray(X[:n_sample])
-    tokens = Xs.reshape(-1).astype(np.int32)
-    offsets = np.arange(n_sample + 1, dtype=np.int64) * X.shape[1]
+    phys, logical, model = host_cpus()
     kind = "reference" if loader.have_ref() else "port"
-    run = (lambda c: loader.ref().raw_counts(tokens, offsets, g, m, c, threads=cores, want_counts=False)[1]) \
-        if kind == "reference" else \
-        (lambda c: loader.port().raw_counts(tokens, offsets, g, m, c, threads=cores, want_counts=False)[1])
     ncomb = int(loader.port().num_combos(g, m))
-    probe = np.arange(min(cores, ncomb), dtype=np.int32)
-    t_probe = run(probe)
-    per_round = max(t_probe, 1e-3)  # `cores` combos in parallel
-    rounds = int(max(1, min((budget_s - t_probe) / per_round, (ncomb - len(probe)) // max(1, cores))))
-    combos = np.arange(len(probe), len(probe) + rounds * cores, dtype=np.int32) % ncomb
-    t_main = run(combos)
-    measured = len(combos) / t_main
-    return kind, cores, measured, len(combos), t_main
+    rows, spent, per_unit = [], 0.0, None  # per_unit: seconds per (N^2 * round) of the slowest row so far
+    plan = [(n, t) for n in sizes for t in (20, phys)]
+    for n, T in plan:
+        T = max(1, min(T, ncomb))
+        tokens, offsets, _ = synthetic(n, L)
+        pairs = n * (n + 1) // 2
+        need = T * pairs * 4 + pairs * 16 + n * L * 64
+        predicted = None if per_unit is None else per_unit * n * n
+        row = {"n": n, "threads": T, "combos": T}
+        if need > 0.6 * mem_available_bytes():
+            row["skipped"] = "needs %.0f GB of host memory for %d private triangles" % (need / 1e9, T)
+        elif predicted is not None and spent + predicted > budget_s:
+            row["skipped"] = "predicted %.0f s, %.0f s of the %.0f s budget left (rerun with --cpu-seconds)" % (
+                predicted, max(0.0, budget_s - spent), budget_s)
+        else:
+            t0 = time.perf_counter()
+            if kind == "reference":
+                loader.ref().full_triangle(tokens, offsets, n, 0, g, m, t=T, approx=True, skip_variance=True, max_iters=1, seed=1)
+            else:
+                loader.port().raw_counts(tokens, offsets, g, m, np.arange(T, dtype=np.int32), threads=T, want_counts=False)
+            dt = time.perf_counter() - t0
+            spent += dt
+            row.update(seconds=dt, combos_per_s=T / dt,
+                       extrapolated_combos_per_s_at_full_n=T / dt * (n / n_full) ** 2)
+            per_unit = max(per_unit or 0.0, dt / (n * n))
+        rows.append(row)
+    done = [r for r in rows if "combos_per_s" in r]
+    best = max(done, key=lambda r: (r["n"], r["combos_per_s"])) if done else None
+    return {
+        "value": best["extrapolated_combos_per_s_at_full_n"] if best else None, "unit": "combos/s",
+        "cores": best["threads"] if best else 0, "kind": kind, "cpu_model": model,
+        "physical_cores": phys, "logical_cpus": logical, "rows": rows, "seconds_spent": spent,
+        "sample": ("config-5 generator at N = %s, %d bp, g=%d m=%d; every row = one call of the %s engine on T combos "
+                   "(one per thread); value = the fastest row at the largest N, x (N/%d)^2 (count time scales as N^2; "
+                   "the reference itself cannot index N > 46340)" % (
+                       "/".join(str(s) for s in sizes), L, g, m,
+                       "reference's KernelFunction" if kind == "reference" else "restated", n_full)),
+    }
 
 
 def other_configs(_native):
@@ -122,27 +208,47 @@ def describe(mode, world, replicate):
         return ("row-band sharded x%d: every rank runs all combos over its own equal-area band of rows of the triangle; "
                 "exchange = the N-entry diagonal only%s" % (world, "; finished bands broadcast to every rank" if replicate
                                                             else "; the kernel matrix stays distributed"))
-    return "combo-sharded x%d + RCCL all-reduce of the triangle in row bands under the next band's kernels" % world
+    return ("combo-sharded x%d (combos c = rank mod %d, private triangles) + one RCCL all-reduce of the triangle, issued in "
+            "row bands under the next band's kernels" % (world, world))
 
 
-def main():
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, choices=[4, 5], default=5, help="BASELINE config: 5 = synthetic DNA (default), 4 = protein 2.19")
     ap.add_argument("--n-seq", type=int, default=100000)
     ap.add_argument("--seq-len", type=int, default=300)
-    ap.add_argument("-g", type=int, default=12)
-    ap.add_argument("-m", type=int, default=8)
-    ap.add_argument("--cpu-sample", type=int, default=2000, help="sequences in the CPU baseline sample")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("-g", type=int, default=None)
+    ap.add_argument("-m", type=int, default=None)
+    ap.add_argument("--cpu-seconds", type=float, default=60.0, help="budget of the CPU baseline (rows that do not fit are skipped)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the extra config-2 measurement (profiling runs)")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra measurements of configs 1-4 (profiling runs)")
     ap.add_argument("--bands", type=int, default=None, help="row bands of the overlapped all-reduce (default: auto)")
-    ap.add_argument("--shard", choices=["auto", "rows", "combos"], default="auto", help="multi-GPU decomposition")
+    ap.add_argument("--shard", choices=["combos", "rows"], default="combos",
+                    help="multi-GPU decomposition reported as `value` (the other one is `alt`)")
     ap.add_argument("--replicate", action="store_true", help="rows: broadcast finished bands so every rank holds all of K")
     ap.add_argument("--no-alt", action="store_true", help="multi-GPU: do not time the other decomposition")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # No launcher around us: start one fresh process per GPU and hand back their exit code. Nothing
+        # in THIS process has touched the GPU (torch is not even imported yet), and nothing is exec'd.
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
 
     import torch
     import torch.distributed as dist
@@ -151,7 +257,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     # Smoke tests of the multi-rank code on a 1-GPU box, not measurements: FSK_BENCH_FORCE_DIST=1 runs
     # the RCCL leg with world size 1; FSK_BENCH_SHARE_GPU=1 puts every rank on cuda:0 over gloo (RCCL
     # cannot run two ranks on one device).
@@ -160,34 +267,47 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("FSK_BENCH_FORCE_DIST") == "1"
+    backend = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        backend = "gloo" if share else "nccl"
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    N, L, g, m = args.n_seq, args.seq_len, args.g, args.m
-    tokens, offsets, X = synthetic(N, L)
+    # ---- workload
+    if args.config == 4:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "tokens_2.19.npz"))
+        tokens, offsets = z["tokens"].astype(np.int32), z["offsets"].astype(np.int64)
+        N, L, X = len(offsets) - 1, None, None
+        g, m = args.g or 14, args.m or 10
+        workload = "config4: protein 2.19, %d sequences (mean length %d), g=%d m=%d exact" % (N, int(offsets[-1] // N), g, m)
+        data = "real (data/2.19 FASTA tokens, tests/golden/tokens_2.19.npz)"
+    else:
+        N, L = args.n_seq, args.seq_len
+        g, m = args.g or 12, args.m or 8
+        tokens, offsets, X = synthetic(N, L)
+        workload = "config5: synthetic DNA %d x %d bp, g=%d m=%d exact" % (N, L, g, m)
+        data = "synthetic"
     eng = _native.Engine(g, m, device=local_rank, profile=True)
     ncomb = eng.lib.num_combos(g, m)
+    workload += ", %d combos" % ncomb
     pairs = N * (N + 1) // 2
     K = torch.zeros(pairs, dtype=torch.int64, device="cuda")  # the integer triangle RCCL reduces
     torch.cuda.synchronize()
     eng.bind_counts(K.data_ptr(), pairs, keepalive=K)
     t_load = time.perf_counter()
-    eng.load_sequences(tokens, offsets, N, 0)  # host packing + H2D: outside the timed region
+    eng.load_sequences(tokens, offsets, N, 0)  # host packing + H2D: outside the timed region (see end_to_end)
     eng.synchronize()
     t_load = time.perf_counter() - t_load
     every = np.arange(ncomb, dtype=np.int32)
-    edges = distributed.owner_edges(N, world)
     dense = eng.stats()["path_used"] == 1
+    edges = distributed.owner_edges(N, world) if dense else None
     mode = args.shard
-    if mode == "auto":
-        mode = "rows" if (world > 1 and dense and edges is not None) else "combos"
-    if mode == "rows" and edges is None:
-        raise SystemExit("--shard rows needs one 128-row band per rank")
+    if mode == "rows" and (edges is None or world == 1):
+        mode = "combos"  # rows needs the dense dataflow and one 128-row band per rank
     my_rows = (edges[rank], edges[rank + 1]) if mode == "rows" else (0, N)
     mine = every if mode == "rows" else np.arange(rank, ncomb, world, dtype=np.int32)
 
@@ -235,82 +355,157 @@ def main():
 
     elapsed, s0, s1 = timed(mode, args.warmup, args.steps)
     alt = None
-    if world > 1 and not args.no_alt and (mode == "combos" and dense and edges is not None or mode == "rows"):
+    if world > 1 and not args.no_alt and edges is not None:
         other = "combos" if mode == "rows" else "rows"
-        dt, _, _ = timed(other, 1, 1)
-        alt = {"parallelism": describe(other, world, args.replicate), "value": ncomb / dt, "unit": "combos/s",
-               "ms_per_step": 1e3 * dt, "steps": 1, "warmup": 1}
+        dt, _, _ = timed(other, args.warmup, args.steps)
+        alt = {"parallelism": describe(other, world, args.replicate), "value": ncomb * args.steps / dt, "unit": "combos/s",
+               "ms_per_step": 1e3 * dt / args.steps, "steps": args.steps, "warmup": args.warmup}
 
+    # ---- the exchange by itself: the same band-wise all-reduce, nothing overlapping it (untimed extras;
+    # K is garbage afterwards and is reset by whatever runs next)
+    comm = None
+    if use_dist:
+        narrow = ncomb * eng.stats()["max_windows"] ** 2 < 2 ** 31
+        nb = args.bands or (8 if (dense and N >= 8192) else 1)
+        be = distributed.band_edges(N, nb)
+        segs = [K[distributed.cell(lo):distributed.cell(hi)] for lo, hi in zip(be[:-1], be[1:])]
+        barrier()
+        t0 = time.perf_counter()
+        for seg in segs:
+            buf = seg.to(torch.int32) if narrow else seg
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            if narrow:
+                seg.copy_(buf)
+        barrier()
+        t_ar = time.perf_counter() - t0
+        payload = pairs * (4 if narrow else 8)
+        comm = {"backend": backend + (" (RCCL)" if backend == "nccl" else " (smoke test, not RCCL)"),
+                "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
+                "allreduce_ms_per_step_not_overlapped": 1e3 * t_ar, "allreduce_payload_bytes": payload,
+                "allreduce_dtype": "int32" if narrow else "int64", "bands": len(segs),
+                "algbw_GBs": payload / t_ar / 1e9,
+                "busbw_GBs": payload / t_ar / 1e9 * 2 * (world - 1) / max(1, world)}
+
+    # ---- SURVEY 8(d)'s metric boundary: load + one step + a normalised block (single GPU only)
+    end_to_end = None
+    if world == 1 and not use_dist:
+        nblk = min(4096, N)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.load_sequences(tokens, offsets, N, 0)
+        eng.accumulate(every)
+        eng.finalize()
+        blk = eng.get_block_torch(0, nblk, 0, nblk)
+        torch.cuda.synchronize()
+        t_e2e = time.perf_counter() - t0
+        assert bool((blk.diagonal() == 1.0).all())
+        end_to_end = {"seconds": t_e2e, "combos_per_s": ncomb / t_e2e,
+                      "includes": "fsk_load_sequences (alphabet scan, bit-packing, H2D of the packed sequences, zeroing K) + "
+                                  "all %d combos + fsk_finalize + normalised %d x %d train block on the device" % (ncomb, nblk, nblk)}
+
+    out = None
     if rank == 0:
         combos_rank = len(mine) * args.steps
         d = lambda k: s1[k] - s0[k]
         value = ncomb * args.steps / elapsed
-        # ---- roofline of the dominant kernel (tile accumulate), per launch
-        launches = max(1, d("n_tile_launches"))
-        tile_ms = d("ms_tile") / launches
-        # exact, from the count panels (whole triangle); a row-band launch owns its share of the cells
-        share = ((my_rows[1] * (my_rows[1] + 1) - my_rows[0] * (my_rows[0] + 1)) // 2) / pairs
-        U = d("cell_updates") / launches * share
         nfeat = s1["n_feat"]
-        combos_per_launch = combos_rank / launches
-        b_in = (N * L * s1["bits_per_symbol"] + 7) // 8
-        P = 1  # ceil(k*b/8) 8-bit passes for the packed k-mer (k=4, b=2)
-        alg_bytes = 16.0 * U + combos_per_launch * (b_in + 16.0 * P * nfeat)
-        achieved = alg_bytes / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
-        macs = d("dense_macs") / launches
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if world == 1 and os.path.exists(tpath):  # (measured on the single-GPU launch: does not describe a rank's band)
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("n_seq") == N and tj.get("combos_per_launch") == int(combos_per_launch):
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        b_in = (int(offsets[-1]) * s1["bits_per_symbol"] + 7) // 8
+        keybits = max(1, int(np.ceil(np.log2(max(2, s1["key_space"])))))
+        P = (keybits + 7) // 8  # 8-bit LSD passes SURVEY 8(d) prices the sort with
+        if dense:
+            # ---- roofline of the dominant kernel (tile accumulate), per launch
+            launches = max(1, d("n_tile_launches"))
+            tile_ms = d("ms_tile") / launches
+            # exact, from the count panels (whole triangle); a row-band launch owns its share of the cells
+            share_rows = ((my_rows[1] * (my_rows[1] + 1) - my_rows[0] * (my_rows[0] + 1)) // 2) / pairs
+            U = d("cell_updates") / launches * share_rows
+            combos_per_launch = combos_rank / launches
+            alg_bytes = 16.0 * U + combos_per_launch * (b_in + 16.0 * P * nfeat)
+            secs = tile_ms * 1e-3
+            alg_gbs = alg_bytes / secs / 1e9 if secs > 0 else 0.0
+            macs = d("dense_macs") / launches
+            tmacs = macs / secs / 1e12 if secs > 0 else 0.0
+            traffic, traffic_note = None, "no profiles/traffic.json for this launch shape"
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if world == 1 and os.path.exists(tpath):  # (measured on the single-GPU launch: does not describe a rank's band)
+                try:
+                    tj = json.load(open(tpath))
+                    if tj.get("n_seq") != N or tj.get("combos_per_launch") != int(combos_per_launch):
+                        traffic_note = "profiles/traffic.json describes another launch shape"
+                    elif tj.get("kernel_files") != kernel_hashes():
+                        traffic_note = "profiles/traffic.json was measured on other kernel sources (blob hashes differ): refused"
+                    else:
+                        traffic = tj.get("hbm_bytes_per_launch")
+                        traffic_note = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, NOT this run), commit %s" % tj.get("commit", "?")
+                except Exception as exc:
+                    traffic_note = "profiles/traffic.json unreadable: %r" % exc
+            roofline = {
+                "bound": "valu", "kernel": "k_dense_tile_dma" if os.environ.get("FSK_TILE_DMA", "1") != "0" else "k_dense_tile",
+                "achieved": tmacs, "peak": VALU_DOT8_PEAK_TMACS, "unit": "T count-MAC/s (v_dot8_u32_u4: 64 lanes/clk/CU x 8 MACs, 256 CUs, 2.4 GHz)",
+                "frac": tmacs / VALU_DOT8_PEAK_TMACS, "traffic": traffic, "traffic_source": traffic_note,
+                "hbm_measured_frac": (traffic / secs / 1e9 / HBM_PEAK_GBS) if (traffic and secs > 0) else None,
+                "hbm_peak_GBs": HBM_PEAK_GBS,
+                "useful_update_frac": (U / secs / 1e12) / VALU_DOT8_PEAK_TMACS if secs > 0 else 0.0,
+                "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_equiv_GBs": alg_gbs,
+                "algorithmic_x_hbm_peak": alg_gbs / HBM_PEAK_GBS,
+                "launch_ms": tile_ms, "launches": int(launches), "combos_per_launch": combos_per_launch,
+                "cell_updates_per_launch": U, "count_macs_per_launch": macs,
+                "note": "the tile kernel computes K += sum_v cnt_i(v) cnt_j(v) as on-chip integer dot products, so the binding ceiling is "
+                        "the v_dot8 issue rate (frac); useful_update_frac = the reference's `+=` count U per second over the same peak "
+                        "(the rest of the MACs multiply by a zero count); algorithmic_* = SURVEY 8(d) bytes of the direct-atomic dataflow "
+                        "(16*U + sort + input per combo), which this kernel does NOT move through HBM — not a fraction of anything",
+            }
+            phases = {"count": d("ms_count") / args.steps, "tile": d("ms_tile") / args.steps, "accumulate_total": d("ms_total") / args.steps}
+            dtype = "u4 count planes (v_dot8_u32_u4), u32 accumulate, u64 atomics"
+        else:
+            # ---- sparse pipeline: SURVEY 8(d) algorithmic bytes over the GPU time of the pipeline
+            U = d("cell_updates") / max(1, args.steps)
+            alg_bytes = 16.0 * U + len(mine) * (b_in + 16.0 * P * nfeat)
+            gpu_ms = (d("ms_extract") + d("ms_sort") + d("ms_segment") + d("ms_pairs")) / args.steps
+            alg_gbs = alg_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0
+            fam = {"extract": d("ms_extract"), "sort": d("ms_sort"), "segment": d("ms_segment"), "pairs": d("ms_pairs")}
+            roofline = {
+                "bound": "hbm", "kernel": "sparse pipeline (k_sparse_extract + k_rs_* + k_seg_* + pair accumulation); largest family: %s" % max(fam, key=fam.get),
+                "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS, "traffic": None,
+                "traffic_source": "not collected in this run (profiles/ holds the rocprofv3 --pmc passes of the sparse kernels)",
+                "algorithmic_bytes_per_step": alg_bytes, "cell_updates_per_step": U, "gpu_ms_per_step": gpu_ms,
+                "sort_passes_priced": P, "sort_passes_run": s1["sort_passes"],
+                "note": "algorithmic bytes = 16*U + 16*P*nfeat + input per combo (SURVEY 8d) over the HIP-event time of the pipeline's kernels",
+            }
+            phases = {k: v / args.steps for k, v in fam.items()}
+            phases["accumulate_total"] = d("ms_total") / args.steps
+            dtype = "u32/u64 packed k-mer keys, u32 LDS sums, u64 atomics"
         out = {
             "metric": "gkm kernel build: mismatch-combos/s", "value": value, "unit": "combos/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "u4 count planes (v_dot8_u32_u4), u32 accumulate, u64 atomics", "data": "synthetic",
-            "config": {"workload": "config5: synthetic DNA %d x %d bp, g=%d m=%d exact, %d combos" % (N, L, g, m, ncomb),
-                       "n_seq": N, "seq_len": L, "g": g, "m": m, "combos": int(ncomb),
+            "vs_baseline": None, "dtype": dtype, "data": data,
+            "config": {"workload": workload, "n_seq": N, "seq_len": L, "g": g, "m": m, "combos": int(ncomb),
                        "parallelism": describe(mode, world, args.replicate),
-                       "path": "dense" if s1["path_used"] == 1 else "sparse"},
-            "roofline": {"bound": "hbm", "kernel": "k_dense_tile_dma" if os.environ.get("FSK_TILE_DMA", "1") != "0" else "k_dense_tile", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "launch_ms": tile_ms, "launches": int(launches), "combos_per_launch": combos_per_launch,
-                         "cell_updates_per_launch": U, "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "algorithmic bytes = 16*U + sort + input (direct-atomic dataflow, SURVEY 8d); "
-                                 "frac > 1 means the tile kernel sums on chip what that dataflow would do in HBM",
-                         "valu": {"achieved": macs / (tile_ms * 1e-3) / 1e12 if tile_ms > 0 else 0.0,
-                                  "peak": VALU_DOT8_PEAK_TMACS, "unit": "T count-MAC/s (v_dot8_u32_u4 at 64 lanes/clk/CU, 2.4 GHz)",
-                                  "frac": (macs / (tile_ms * 1e-3) / 1e12) / VALU_DOT8_PEAK_TMACS if tile_ms > 0 else 0.0}},
+                       "path": "dense" if dense else "sparse"},
+            "roofline": roofline,
             "load_seconds_untimed": t_load,
-            "phases_ms_per_step": {"count": d("ms_count") / args.steps, "tile": d("ms_tile") / args.steps,
-                                   "accumulate_total": d("ms_total") / args.steps},
+            "phases_ms_per_step": phases,
         }
         if alt is not None:
             out["alt"] = alt
+        if comm is not None:
+            out["comm"] = comm
+        if end_to_end is not None:
+            out["end_to_end"] = end_to_end
+    if use_dist:
+        dist.barrier()
+    eng.close()
+    del K
+    if rank == 0:
         if world == 1 and not args.no_also:
             out["also"] = other_configs(_native)
         if world == 1 and not args.no_cpu_baseline:
-            ns = min(args.cpu_sample, N)
-            kind, cores, measured, nc, secs = cpu_baseline(X, g, m, ns, args.cpu_seconds)
-            scale = (ns / N) ** 2
-            cpu_model = ""
-            try:
-                for line in open("/proc/cpuinfo"):
-                    if line.startswith("model name"):
-                        cpu_model = line.split(":", 1)[1].strip()
-                        break
-            except OSError:
-                pass
-            out["cpu_baseline"] = {
-                "value": measured * scale, "unit": "combos/s", "cores": cores, "kind": kind, "cpu_model": cpu_model,
-                "measured_at_sample": measured,
-                "sample": "first %d of %d sequences, %d of %d combos, %.1f s on %d threads: %.3f combos/s at N=%d; "
-                          "value = that x (%d/%d)^2 (count time scales as N^2; the reference itself cannot index N > 46340)"
-                          % (ns, N, nc, ncomb, secs, cores, measured, ns, ns, N)}
+            full_n, full_L = (N, L) if args.config == 5 else (100000, 300)
+            bg, bm = (g, m) if args.config == 5 else (12, 8)
+            out["cpu_baseline"] = cpu_baseline(bg, bm, full_L, full_n, args.cpu_seconds)
+            if args.config != 5:
+                out["cpu_baseline"]["sample"] += " [config-5 generator: this run's own workload is --config %d]" % args.config
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

@@ -53,8 +53,8 @@ SYMBOLS = ["fsk_create", "fsk_destroy", "fsk_last_error", "fsk_abi_version", "fs
            "fsk_set_combo_order", "fsk_set_seed", "fsk_load_sequences", "fsk_bind_counts",
            "fsk_counts_device_ptr", "fsk_reset_counts", "fsk_reset_counts_rows", "fsk_accumulate", "fsk_accumulate_rows", "fsk_synchronize", "fsk_finalize",
            "fsk_get_block", "fsk_get_block_device", "fsk_get_train", "fsk_get_test", "fsk_get_triangle", "fsk_get_counts",
-           "fsk_get_counts_block", "fsk_get_stdevs", "fsk_save_kernel", "fsk_get_stats", "fsk_num_combos",
-           "fsk_combo_positions"]
+           "fsk_get_counts_block", "fsk_get_counts_cells", "fsk_get_stdevs", "fsk_save_kernel", "fsk_get_stats", "fsk_num_combos",
+           "fsk_combo_positions", "fsk_stream_wait_engine", "fsk_engine_wait_stream", "fsk_read_fasta"]
 
 
 _hip_shared = False
@@ -125,6 +125,10 @@ class Library:
             "fsk_get_triangle": ([vp, vp], C.c_int),
             "fsk_get_counts": ([vp, vp], C.c_int),
             "fsk_get_counts_block": ([vp, i64, i64, i64, i64, vp], C.c_int),
+            "fsk_get_counts_cells": ([vp, vp, vp, i64, vp], C.c_int),
+            "fsk_stream_wait_engine": ([vp, vp], C.c_int),
+            "fsk_engine_wait_stream": ([vp, vp], C.c_int),
+            "fsk_read_fasta": ([C.c_char_p, vp, C.POINTER(i32), vp, i64, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.c_char_p, i32], C.c_int),
             "fsk_get_stdevs": ([vp, vp, i32, C.POINTER(i32)], C.c_int),
             "fsk_save_kernel": ([vp, C.c_char_p], C.c_int),
             "fsk_get_stats": ([vp, C.POINTER(Stats)], C.c_int),
@@ -191,6 +195,7 @@ class Engine:
             raise FskError(rc, (self.lib.L.fsk_last_error(None) or b"").decode())
         self.h = h
         self.g, self.m = g, m
+        self.device = device
         self._keep = None
 
     def close(self):
@@ -259,6 +264,15 @@ class Engine:
     def synchronize(self):
         self._ck(self.lib.L.fsk_synchronize(self.h))
 
+    def stream_wait_engine(self, hip_stream):
+        """Work enqueued on ``hip_stream`` (a raw hipStream_t, e.g. ``torch.cuda.current_stream().cuda_stream``)
+        from now on waits for what the engine has enqueued so far; the host does not block."""
+        self._ck(self.lib.L.fsk_stream_wait_engine(self.h, C.c_void_p(hip_stream)))
+
+    def engine_wait_stream(self, hip_stream):
+        """The engine's later work waits for what ``hip_stream`` holds now."""
+        self._ck(self.lib.L.fsk_engine_wait_stream(self.h, C.c_void_p(hip_stream)))
+
     def finalize(self):
         self._ck(self.lib.L.fsk_finalize(self.h))
 
@@ -275,8 +289,9 @@ class Engine:
     def get_block_torch(self, i0, i1, j0, j1):
         """The normalised block as a float64 torch tensor ON THE GPU (no host round trip)."""
         import torch
-        out = torch.empty((i1 - i0, j1 - j0), dtype=torch.float64, device="cuda")
-        torch.cuda.synchronize()
+        dev = torch.device("cuda", self.device)  # the engine's device, whatever torch's current one is
+        out = torch.empty((i1 - i0, j1 - j0), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)
         self._ck(self.lib.L.fsk_get_block_device(self.h, i0, i1, j0, j1, C.c_void_p(out.data_ptr())))
         return out
 
@@ -303,6 +318,15 @@ class Engine:
     def get_counts_block(self, i0, i1, j0, j1):
         out = np.empty((i1 - i0, j1 - j0), dtype=np.uint64)
         self._ck(self.lib.L.fsk_get_counts_block(self.h, i0, i1, j0, j1, out.ctypes.data))
+        return out
+
+    def get_counts_cells(self, rows, cols):
+        """Raw integer cells (rows[q], cols[q]) of the symmetric matrix."""
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        cols = np.ascontiguousarray(cols, dtype=np.int64)
+        assert rows.shape == cols.shape and rows.ndim == 1
+        out = np.empty(len(rows), dtype=np.uint64)
+        self._ck(self.lib.L.fsk_get_counts_cells(self.h, rows.ctypes.data, cols.ctypes.data, len(rows), out.ctypes.data))
         return out
 
     def get_stdevs(self):

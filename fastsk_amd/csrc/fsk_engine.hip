@@ -54,7 +54,26 @@ struct DevBuf {
     }
 };
 
-struct PhaseTimer;
+// Every entry point runs on the engine's device and puts the calling thread's current device back
+// afterwards: the engine shares one HIP runtime with torch, whose current device must not move
+// under it (e.g. when an Engine on another GPU is garbage-collected).
+struct DeviceScope {
+    int prev = -1, dev;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev);
+    }
+    ~DeviceScope() {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+#define FSK_ON_DEVICE(e)                                                                      \
+    DeviceScope fsk_on_device_((e)->cfg.device);                                             \
+    if (fsk_on_device_.err != hipSuccess)                                                    \
+        return (e)->fail(FSK_EDEVICE, "hipSetDevice(%d) failed: %s", (e)->cfg.device, hipGetErrorString(fsk_on_device_.err))
 
 }  // namespace
 
@@ -66,6 +85,7 @@ struct fsk_engine {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // variance mode: D2H of one iteration under the next one's kernels
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_order = nullptr;       // fsk_stream_wait_engine / fsk_engine_wait_stream
     // fsk_reset_counts does not fill K when the next accumulate can STORE its sums instead of adding
     // them (dense dataflow, one workgroup per tile): rows [lazy_lo, lazy_hi) are zero by contract
     // but not in memory until a tile launch stores them or materialise_zero() fills them.
@@ -101,6 +121,7 @@ struct fsk_engine {
     DevBuf<u64> K_store;
     DevBuf<double> d_Kf64, d_Khat, d_prod, d_diag, d_stage;
     DevBuf<u64> d_stage_u64;
+    DevBuf<int64_t> d_cell_idx;
 
     // dense scratch
     DevBuf<uint32_t> d_C4, d_C4H, d_rowmask, d_flag;  // lo / hi nibble planes, per-row hi masks
@@ -998,7 +1019,8 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
         return FSK_EDEVICE;
     }
     if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "device ordinal out of range"; return FSK_EINVAL; }
-    if (hipSetDevice(cfg->device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return FSK_EDEVICE; }
+    DeviceScope on_device(cfg->device);  // the caller's current device is restored on return
+    if (on_device.err != hipSuccess) { g_create_error = "hipSetDevice failed"; return FSK_EDEVICE; }
     fsk_engine* e = new fsk_engine;
     e->cfg = *cfg;
     e->k = cfg->g - cfg->m;
@@ -1023,17 +1045,18 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
 
 void fsk_destroy(fsk_engine* e) {
     if (!e) return;
-    (void)hipSetDevice(e->cfg.device);
+    DeviceScope on_device(e->cfg.device);
     (void)hipStreamSynchronize(e->stream);
     e->d_words.release(); e->d_wstart.release(); e->d_len.release(); e->d_fstart.release(); e->d_featseq.release();
     e->d_pos.release(); e->K_store.release(); e->d_Kf64.release(); e->d_Khat.release(); e->d_prod.release();
-    e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_C4.release(); e->d_C4H.release(); e->d_rowmask.release(); e->d_flag.release(); e->d_tiletab.release(); e->d_keybits.release(); e->d_lut.release(); e->d_vc.release();
+    e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_cell_idx.release(); e->d_C4.release(); e->d_C4H.release(); e->d_rowmask.release(); e->d_flag.release(); e->d_tiletab.release(); e->d_keybits.release(); e->d_lut.release(); e->d_vc.release();
     for (int b = 0; b < 2; ++b) { e->d_keys[b].release(); e->d_vals[b].release(); }
     e->d_blockhist.release(); e->d_totals.release(); e->d_estart.release(); e->d_eseq.release(); e->d_erun.release();
     e->d_rstart.release(); e->d_segtot.release(); e->d_blocksum.release(); e->d_U.release(); e->d_U2.release();
     e->d_bk_hist.release(); e->d_bk_tot.release(); e->d_slice_off.release(); e->d_list.release(); e->d_epair.release();
     if (e->h_prod) (void)hipHostFree(e->h_prod);
     if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
+    if (e->ev_order) (void)hipEventDestroy(e->ev_order);
     (void)hipEventDestroy(e->ev0);
     (void)hipEventDestroy(e->ev1);
     (void)hipStreamDestroy(e->stream);
@@ -1062,11 +1085,15 @@ int fsk_set_seed(fsk_engine* e, uint64_t seed) {
 int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offsets, int64_t n_train, int64_t n_test) {
     if (!e) return FSK_EINVAL;
     if (!offsets || n_train <= 0 || n_test < 0) return e->fail(FSK_EINVAL, "need n_train >= 1, n_test >= 0 and offsets");
-    FSK_HIP(hipSetDevice(e->cfg.device));
+    FSK_ON_DEVICE(e);
     const int64_t N = n_train + n_test;
     const int g = e->cfg.g;
     if (N >= ((int64_t)1 << 31)) return e->fail(FSK_EUNSUPPORTED, "more than 2^31 sequences");
-    if (offsets[N] > 0 && !tokens) return e->fail(FSK_EINVAL, "null tokens");
+    if (offsets[0] < 0) return e->fail(FSK_EINVAL, "offsets[0] must be >= 0");
+    if (offsets[N] > offsets[0] && !tokens) return e->fail(FSK_EINVAL, "null tokens");
+    // only tokens[offsets[0] .. offsets[N]) belong to the call: everything below works on that window
+    tokens = tokens ? tokens + offsets[0] : tokens;
+    const int64_t off0 = offsets[0];
     // ---- lengths (fastsk.cpp:32-58)
     int64_t shortest_train = INT64_MAX, shortest_test = INT64_MAX, longest = 0, nfeat = 0;
     for (int64_t i = 0; i < N; ++i) {
@@ -1084,7 +1111,7 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
     if (nfeat >= ((int64_t)1 << 31) || longest >= ((int64_t)1 << 24)) return e->fail(FSK_EUNSUPPORTED, "input too large (g-mers >= 2^31 or a sequence >= 2^24)");
     // ---- alphabet: rank-remap the tokens that occur (equality preserving; the reference's
     // dict_size = |{0} U tokens|, fastsk.cpp:70-85, only serves as its counting-sort radix)
-    const int64_t total = offsets[N];
+    const int64_t total = offsets[N] - off0;
     std::vector<int32_t> distinct;
     std::vector<int64_t> tok_hist;  // occurrences per token value when every token lies in [0, 65536): one pass
     {
@@ -1151,7 +1178,7 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
             const uint32_t per_word = 32u / (uint32_t)bits;
             const uint8_t* lt = lut.data();
             for (int64_t i = 0; i < N; ++i) {
-                const int32_t* sq = tokens + offsets[i];
+                const int32_t* sq = tokens + (offsets[i] - off0);
                 uint32_t* w = words.data() + wstart[i];
                 const uint32_t len = len32[i];
                 uint32_t p = 0;
@@ -1168,7 +1195,7 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
             }
         } else {
             for (int64_t i = 0; i < N; ++i) {
-                const int32_t* sq = tokens + offsets[i];
+                const int32_t* sq = tokens + (offsets[i] - off0);
                 uint32_t* w = words.data() + wstart[i];
                 for (uint32_t p = 0; p < len32[i]; ++p) {
                     uint32_t r = direct ? lut[(size_t)(sq[p] - base)]
@@ -1236,7 +1263,7 @@ int fsk_bind_counts(fsk_engine* e, void* device_u64, int64_t n_cells) {
     if (!device_u64 || n_cells <= 0) return e->fail(FSK_EINVAL, "bad counts buffer");
     if (e->loaded && n_cells != e->pairs) return e->fail(FSK_EINVAL, "counts buffer holds %lld cells, need %lld", (long long)n_cells, (long long)e->pairs);
     if (e->lazy_lo >= 0) {
-        FSK_HIP(hipSetDevice(e->cfg.device));
+        FSK_ON_DEVICE(e);
         int rcz = materialise_zero(e);
         if (rcz) return rcz;
         FSK_HIP(hipStreamSynchronize(e->stream));
@@ -1259,7 +1286,7 @@ int fsk_counts_device_ptr(fsk_engine* e, void** out) {
 int fsk_reset_counts(fsk_engine* e) {
     if (!e) return FSK_EINVAL;
     if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
-    FSK_HIP(hipSetDevice(e->cfg.device));
+    FSK_ON_DEVICE(e);
     if (lazy_zero_possible(e)) {
         e->lazy_lo = 0; e->lazy_hi = e->N;  // (whatever was pending is covered by this range)
     } else {
@@ -1276,7 +1303,7 @@ int fsk_reset_counts_rows(fsk_engine* e, int64_t row_begin, int64_t row_end) {
     if (!e) return FSK_EINVAL;
     if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
     if (row_begin < 0 || row_end > e->N || row_begin > row_end) return e->fail(FSK_EINVAL, "bad row range");
-    FSK_HIP(hipSetDevice(e->cfg.device));
+    FSK_ON_DEVICE(e);
     const u64 c0 = (u64)row_begin * ((u64)row_begin + 1) / 2, c1 = (u64)row_end * ((u64)row_end + 1) / 2;
     { int rcz = materialise_zero(e); if (rcz) return rcz; }  // an earlier, different reset
     if (lazy_zero_possible(e) && row_begin % fsk::TILE == 0 && row_end > row_begin) {
@@ -1295,7 +1322,7 @@ int fsk_accumulate(fsk_engine* e, const int32_t* combos, int32_t n) {
     if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
     if (n < 0 || (n > 0 && !combos)) return e->fail(FSK_EINVAL, "bad combo list");
     if (n == 0) return FSK_OK;
-    FSK_HIP(hipSetDevice(e->cfg.device));
+    FSK_ON_DEVICE(e);
     e->finalized = false;
     return do_accumulate(e, combos, n, e->d_K);
 }
@@ -1308,30 +1335,51 @@ int fsk_accumulate_rows(fsk_engine* e, const int32_t* combos, int32_t n, int64_t
         (row_end % fsk::TILE != 0 && row_end != e->N))
         return e->fail(FSK_EINVAL, "row band must be [a,b) with a, b multiples of %d (b may be N)", fsk::TILE);
     if (n == 0 || row_begin == row_end) return FSK_OK;
-    FSK_HIP(hipSetDevice(e->cfg.device));
+    FSK_ON_DEVICE(e);
     e->finalized = false;
     return do_accumulate(e, combos, n, e->d_K, row_begin, row_end);
 }
 
 int fsk_synchronize(fsk_engine* e) {
     if (!e) return FSK_EINVAL;
-    FSK_HIP(hipSetDevice(e->cfg.device));
+    FSK_ON_DEVICE(e);
     { int rcz = materialise_zero(e); if (rcz) return rcz; }
     FSK_HIP(hipStreamSynchronize(e->stream));
     FSK_HIP(hipGetLastError());
     return FSK_OK;
 }
 
+// Ordering against a stream of the caller (torch's current stream, which RCCL collectives are
+// ordered after) without blocking the host: an event recorded on one stream, waited for by the other.
+int fsk_stream_wait_engine(fsk_engine* e, void* hip_stream) {
+    if (!e) return FSK_EINVAL;
+    FSK_ON_DEVICE(e);
+    if (!e->ev_order) FSK_HIP(hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming));
+    FSK_HIP(hipEventRecord(e->ev_order, e->stream));
+    FSK_HIP(hipStreamWaitEvent((hipStream_t)hip_stream, e->ev_order, 0));
+    return FSK_OK;
+}
+
+int fsk_engine_wait_stream(fsk_engine* e, void* hip_stream) {
+    if (!e) return FSK_EINVAL;
+    FSK_ON_DEVICE(e);
+    if (!e->ev_order) FSK_HIP(hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming));
+    FSK_HIP(hipEventRecord(e->ev_order, (hipStream_t)hip_stream));
+    FSK_HIP(hipStreamWaitEvent(e->stream, e->ev_order, 0));
+    return FSK_OK;
+}
+
 int fsk_finalize(fsk_engine* e) {
     if (!e) return FSK_EINVAL;
     if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
-    FSK_HIP(hipSetDevice(e->cfg.device));
+    FSK_ON_DEVICE(e);
     { int rcz = materialise_zero(e); if (rcz) return rcz; }
     return make_diag(e);
 }
 
 int fsk_compute(fsk_engine* e, const int32_t* tokens, const int64_t* offsets, int64_t n_train, int64_t n_test) {
     if (!e) return FSK_EINVAL;
+    FSK_ON_DEVICE(e);
     int rc = fsk_load_sequences(e, tokens, offsets, n_train, n_test);
     if (rc) return rc;
     const fsk_config& c = e->cfg;
@@ -1365,7 +1413,7 @@ int fsk_compute(fsk_engine* e, const int32_t* tokens, const int64_t* offsets, in
 
 int fsk_get_block(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1, double* out) {
     if (!e) return FSK_EINVAL;
-    FSK_HIP(hipSetDevice(e->cfg.device));
+    FSK_ON_DEVICE(e);
     return fetch_block(e, i0, i1, j0, j1, out);
 }
 int fsk_get_block_device(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1, double* device_out) {
@@ -1375,7 +1423,7 @@ int fsk_get_block_device(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int6
     const u64 rows = (u64)(i1 - i0), cols = (u64)(j1 - j0);
     if (rows == 0 || cols == 0) return FSK_OK;
     if (!device_out) return e->fail(FSK_EINVAL, "null output");
-    FSK_HIP(hipSetDevice(e->cfg.device));
+    FSK_ON_DEVICE(e);
     { int rcz = materialise_zero(e); if (rcz) return rcz; }
     const u64 max_cells = (u64)1 << 31;  // grid.x limit: launch in row chunks
     const u64 rows_per = std::max<u64>(1, std::min<u64>(rows, max_cells / cols));
@@ -1395,12 +1443,12 @@ int fsk_get_block_device(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int6
 
 int fsk_get_train(fsk_engine* e, double* out) {
     if (!e) return FSK_EINVAL;
-    FSK_HIP(hipSetDevice(e->cfg.device));
+    FSK_ON_DEVICE(e);
     return fetch_block(e, 0, e->n_train, 0, e->n_train, out);
 }
 int fsk_get_test(fsk_engine* e, double* out) {
     if (!e) return FSK_EINVAL;
-    FSK_HIP(hipSetDevice(e->cfg.device));
+    FSK_ON_DEVICE(e);
     return fetch_block(e, e->n_train, e->N, 0, e->n_train, out);
 }
 
@@ -1408,7 +1456,7 @@ int fsk_get_triangle(fsk_engine* e, double* out) {
     if (!e) return FSK_EINVAL;
     if (!e->finalized) return e->fail(FSK_ESTATE, "no finalized kernel");
     if (!out) return e->fail(FSK_EINVAL, "null output");
-    FSK_HIP(hipSetDevice(e->cfg.device));
+    FSK_ON_DEVICE(e);
     { int rcz = materialise_zero(e); if (rcz) return rcz; }
     const u64 chunk = (u64)32 << 20;
     FSK_HIP(e->d_stage.reserve((size_t)std::min<u64>(chunk, (u64)e->pairs)));
@@ -1430,7 +1478,7 @@ int fsk_get_counts(fsk_engine* e, uint64_t* out) {
     if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
     if (e->result_f64) return e->fail(FSK_ESTATE, "variance mode keeps a floating-point mean, not integer counts");
     if (!out) return e->fail(FSK_EINVAL, "null output");
-    FSK_HIP(hipSetDevice(e->cfg.device));
+    FSK_ON_DEVICE(e);
     { int rcz = materialise_zero(e); if (rcz) return rcz; }
     FSK_HIP(hipStreamSynchronize(e->stream));
     FSK_HIP(hipMemcpy(out, e->d_K, (size_t)e->pairs * sizeof(u64), hipMemcpyDeviceToHost));
@@ -1442,7 +1490,7 @@ int fsk_get_counts_block(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int6
     if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
     if (e->result_f64) return e->fail(FSK_ESTATE, "variance mode keeps a floating-point mean, not integer counts");
     if (i0 < 0 || j0 < 0 || i1 > e->N || j1 > e->N || i0 > i1 || j0 > j1) return e->fail(FSK_EINVAL, "block out of range");
-    FSK_HIP(hipSetDevice(e->cfg.device));
+    FSK_ON_DEVICE(e);
     { int rcz = materialise_zero(e); if (rcz) return rcz; }
     const int64_t rows = i1 - i0, cols = j1 - j0;
     if (rows == 0 || cols == 0) return FSK_OK;
@@ -1456,6 +1504,31 @@ int fsk_get_counts_block(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int6
         FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_block_raw<u64>), dim3((uint32_t)((cells + 255) / 256)), dim3(256), 0, e->stream, e->d_K,
                    (u64)(i0 + r), (u64)nr, (u64)j0, (u64)cols, e->d_stage_u64.p);
         FSK_HIP(hipMemcpyAsync(out + r * cols, e->d_stage_u64.p, cells * sizeof(u64), hipMemcpyDeviceToHost, e->stream));
+        FSK_HIP(hipStreamSynchronize(e->stream));
+    }
+    return FSK_OK;
+}
+
+int fsk_get_counts_cells(fsk_engine* e, const int64_t* rows, const int64_t* cols, int64_t n, uint64_t* out) {
+    if (!e) return FSK_EINVAL;
+    if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
+    if (e->result_f64) return e->fail(FSK_ESTATE, "variance mode keeps a floating-point mean, not integer counts");
+    if (n < 0 || (n > 0 && (!rows || !cols || !out))) return e->fail(FSK_EINVAL, "bad cell list");
+    for (int64_t q = 0; q < n; ++q)
+        if (rows[q] < 0 || rows[q] >= e->N || cols[q] < 0 || cols[q] >= e->N) return e->fail(FSK_EINVAL, "cell (%lld, %lld) out of range", (long long)rows[q], (long long)cols[q]);
+    if (n == 0) return FSK_OK;
+    FSK_ON_DEVICE(e);
+    { int rcz = materialise_zero(e); if (rcz) return rcz; }
+    const int64_t chunk = (int64_t)16 << 20;
+    FSK_HIP(e->d_cell_idx.reserve((size_t)std::min(n, chunk) * 2));
+    FSK_HIP(e->d_stage_u64.reserve((size_t)std::min(n, chunk)));
+    for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+        const int64_t cnt = std::min(chunk, n - c0);
+        FSK_HIP(hipMemcpyAsync(e->d_cell_idx.p, rows + c0, (size_t)cnt * sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
+        FSK_HIP(hipMemcpyAsync(e->d_cell_idx.p + cnt, cols + c0, (size_t)cnt * sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
+        FSK_LAUNCH(fsk::k_cells_raw, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, e->stream, e->d_K, (const int64_t*)e->d_cell_idx.p,
+                   (const int64_t*)(e->d_cell_idx.p + cnt), (u64)cnt, e->d_stage_u64.p);
+        FSK_HIP(hipMemcpyAsync(out + c0, e->d_stage_u64.p, (size_t)cnt * sizeof(u64), hipMemcpyDeviceToHost, e->stream));
         FSK_HIP(hipStreamSynchronize(e->stream));
     }
     return FSK_OK;
@@ -1488,7 +1561,7 @@ int fsk_save_kernel(fsk_engine* e, const char* path) {
 int fsk_get_stats(fsk_engine* e, fsk_stats* out) {
     if (!e || !out) return FSK_EINVAL;
     if (e->d_U.p && e->loaded) {
-        (void)hipSetDevice(e->cfg.device);
+        DeviceScope on_device(e->cfg.device);
         u64 U = 0;
         if (hipStreamSynchronize(e->stream) == hipSuccess && fetch_pending_u(e) == FSK_OK &&
             hipMemcpy(&U, e->d_U.p, sizeof U, hipMemcpyDeviceToHost) == hipSuccess)

@@ -827,6 +827,15 @@ __global__ __launch_bounds__(256) void k_block_raw(const SrcT* K, u64 i0, u64 ro
     out[c] = K[tri_index(a, b)];
 }
 
+// arbitrary cells (rows[q], cols[q]) of the symmetric matrix: scattered parity checks at sizes where
+// no block of the triangle can be compared whole
+__global__ __launch_bounds__(256) void k_cells_raw(const u64* K, const int64_t* rows, const int64_t* cols, u64 n, u64* out) {
+    const u64 q = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const u64 i = (u64)rows[q], j = (u64)cols[q];
+    out[q] = K[i > j ? tri_index(i, j) : tri_index(j, i)];
+}
+
 // whole triangle, cells [c0, c0+count) of the reference layout
 template <typename SrcT>
 __global__ __launch_bounds__(256) void k_triangle(const SrcT* K, const double* diag, u64 c0, u64 count, double* out) {

@@ -111,6 +111,7 @@ def accumulate_owned_rows(eng, K, combos, group=None, replicate=False, n_sub=Non
     if narrow is None:
         narrow = len(combos) * eng.stats()["max_windows"] ** 2 < 2 ** 31
     subs = [sub_edges(edges[r], edges[r + 1], n_sub) for r in range(world)]
+    stream = _torch_stream(K)
     pending = []
 
     def drain(keep):
@@ -123,7 +124,10 @@ def accumulate_owned_rows(eng, K, combos, group=None, replicate=False, n_sub=Non
     for k in range(max(len(s) for s in subs) - 1):
         if k < len(subs[rank]) - 1:
             eng.accumulate_rows(combos, subs[rank][k], subs[rank][k + 1])
-            eng.synchronize()
+            if stream is None:
+                eng.synchronize()
+            else:
+                eng.stream_wait_engine(stream)  # the sub-band is final before its broadcast reads it
         for r in range(world):  # same order on every rank
             if k >= len(subs[r]) - 1:
                 continue
@@ -136,8 +140,10 @@ def accumulate_owned_rows(eng, K, combos, group=None, replicate=False, n_sub=Non
             pending.append((work, seg, seg32, r == rank))
         drain(2 * world)
     drain(0)
-    if K.is_cuda:
+    if stream is not None:
+        eng.engine_wait_stream(stream)
         torch.cuda.synchronize(K.device)
+    eng.synchronize()
     return lo, hi
 
 
@@ -157,9 +163,18 @@ def get_block_distributed(eng, i0, i1, j0, j1, group=None, device=None):
     return blk
 
 
+def _torch_stream(K):
+    """Raw hipStream_t of torch's current stream on K's device (what RCCL collectives are ordered
+    after), or None for a host tensor."""
+    import torch
+    return torch.cuda.current_stream(K.device).cuda_stream if K.is_cuda else None
+
+
 def accumulate_and_reduce(eng, K, combos, group=None, n_bands=None, narrow=None, n_combos_total=None, force=False):
     """One pass: accumulate this rank's ``combos`` into the bound triangle ``K`` and sum it over
-    the ranks of ``group``, band by band, overlapping RCCL with the next band's kernels."""
+    the ranks of ``group``, band by band, overlapping RCCL with the next band's kernels. The host
+    never waits for a band: torch's stream (and RCCL behind it) waits for an event the engine
+    records after the band's last kernel. Returns when ``K`` holds the reduced triangle."""
     import torch
     import torch.distributed as dist
 
@@ -176,6 +191,7 @@ def accumulate_and_reduce(eng, K, combos, group=None, n_bands=None, narrow=None,
         total = n_combos_total if n_combos_total is not None else eng.lib.num_combos(eng.g, eng.m)
         narrow = total * eng.stats()["max_windows"] ** 2 < 2 ** 31
     edges = band_edges(N, n_bands)
+    stream = _torch_stream(K)
     pending = []
 
     def drain(keep):
@@ -187,15 +203,20 @@ def accumulate_and_reduce(eng, K, combos, group=None, n_bands=None, narrow=None,
 
     for lo, hi in zip(edges[:-1], edges[1:]):
         eng.accumulate_rows(combos, lo, hi)
-        eng.synchronize()  # the engine has its own HIP stream; RCCL is ordered after the band is final
+        if stream is None:
+            eng.synchronize()
+        else:
+            eng.stream_wait_engine(stream)  # the band is final before anything torch / RCCL does to it
         seg = K[cell(lo):cell(hi)]
         seg32 = seg.to(torch.int32) if narrow else None
         work = dist.all_reduce(seg32 if narrow else seg, op=dist.ReduceOp.SUM, group=group, async_op=True)
         pending.append((work, seg, seg32))
         drain(2)
     drain(0)
-    if K.is_cuda:
+    if stream is not None:
+        eng.engine_wait_stream(stream)  # the engine's next pass starts after the reduced cells are in place
         torch.cuda.synchronize(K.device)
+    eng.synchronize()  # (fills rows a reset left for a storing launch that never came: none on this path)
 
 
 def compute_sharded(tokens, offsets, n_train, n_test, g, m, combos=None, group=None, device=None, lib=None,

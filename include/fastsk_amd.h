@@ -152,6 +152,15 @@ int fsk_accumulate(fsk_engine* e, const int32_t* combos, int32_t n);
 int fsk_accumulate_rows(fsk_engine* e, const int32_t* combos, int32_t n, int64_t row_begin, int64_t row_end);
 /* wait for the engine's stream */
 int fsk_synchronize(fsk_engine* e);
+/* Order the engine's stream against a HIP stream of the caller (hipStream_t passed as void*; NULL =
+ * the default stream) without blocking the host. fsk_stream_wait_engine: work enqueued on
+ * `hip_stream` after the call waits for everything the engine has enqueued so far (e.g. RCCL's
+ * all-reduce of a finished row band, issued on torch's stream, while the engine accumulates the next
+ * band). Rows that an fsk_reset_counts left for a later storing launch are NOT filled by this call:
+ * the other stream may read only rows already accumulated (fsk_synchronize fills the rest).
+ * fsk_engine_wait_stream: the engine's later work waits for what `hip_stream` holds now. */
+int fsk_stream_wait_engine(fsk_engine* e, void* hip_stream);
+int fsk_engine_wait_stream(fsk_engine* e, void* hip_stream);
 /* extract the raw diagonal for normalisation (fastsk_kernel.cpp:96-103); call after the last
  * accumulate (and after any cross-GPU all-reduce of the triangle) */
 int fsk_finalize(fsk_engine* e);
@@ -167,6 +176,9 @@ int fsk_get_test(fsk_engine* e, double* out);       /* n_test  x n_train, get_te
 int fsk_get_triangle(fsk_engine* e, double* out);   /* double[N(N+1)/2], the reference's K     */
 int fsk_get_counts(fsk_engine* e, uint64_t* out);   /* raw integer triangle (exact/skip-var)   */
 int fsk_get_counts_block(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint64_t* out);
+/* raw integer cells (rows[q], cols[q]), q < n, of the symmetric matrix: scattered spot checks of a
+ * triangle too large to copy out (tri_access of arbitrary pairs, shared.cpp:97-117) */
+int fsk_get_counts_cells(fsk_engine* e, const int64_t* rows, const int64_t* cols, int64_t n, uint64_t* out);
 /* approx/variance mode: thread 0's convergence trace, get_stdevs() (fastsk.cpp:219-221) */
 int fsk_get_stdevs(fsk_engine* e, double* out, int32_t cap, int32_t* n);
 /* "%d:%e " text dump, one row per line, 1-based column ids: save_kernel (fastsk.cpp:223-237) */
@@ -176,6 +188,21 @@ int fsk_get_stats(fsk_engine* e, fsk_stats* out);
 /* ---- helpers shared with the host side --------------------------------------------------- */
 int64_t fsk_num_combos(int32_t g, int32_t m);                              /* nchoosek */
 int fsk_combo_positions(int32_t g, int32_t k, int64_t combo, int32_t* out); /* getCombinations */
+
+
+/* ---- input: native counterpart of FastaUtility.read_data + Vocabulary (src/fastsk/utils.py:5-96)
+ * Alternating ">label" / sequence lines; every line stripped and lower-cased; labels in {-1,0,1};
+ * token ids in first-seen order from *next_id (1 for a fresh vocabulary; id 0 stays reserved),
+ * kept in vocab256[byte] (0 = not seen yet) so that successive files share ids as the files read
+ * through one FastaUtility do. Host only, no device needed. Call once with tokens = offsets =
+ * labels = NULL to learn *n_seq and *n_tokens (the vocabulary is already updated; the second call
+ * finds every symbol assigned), then with buffers tokens[n_tokens], offsets[n_seq + 1],
+ * labels[n_seq]. Returns FSK_EINVAL on a malformed file (where the reference's asserts fire) and
+ * FSK_EUNSUPPORTED on non-ASCII bytes (the caller's text-mode fallback handles those); the message
+ * goes to err[err_cap]. */
+int fsk_read_fasta(const char* path, int32_t* vocab256, int32_t* next_id, int32_t* tokens, int64_t tokens_cap,
+                   int64_t* offsets, int32_t* labels, int64_t seq_cap, int64_t* n_seq, int64_t* n_tokens, char* err,
+                   int32_t err_cap);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ OUT = os.path.join(HERE, "libfastsk_emu.so")
 def _current():
     deps = [SRC, os.path.join(HERE, "hip_emu.h"), os.path.join(ROOT, "include", "fastsk_amd.h")]
     deps += [os.path.join(ROOT, "fastsk_amd", "csrc", f)
-             for f in ("fsk_kernels.h", "fsk_tile_kernel.inc", "fsk_tile_kernel_dma.inc", "fsk_platform.h")]
+             for f in ("fsk_kernels.h", "fsk_tile_kernel.inc", "fsk_tile_kernel_dma.inc", "fsk_platform.h", "fsk_fasta.cpp")]
     return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps)
 
 
@@ -30,7 +30,8 @@ def build(force=False):
             return OUT
         tmp = OUT + ".tmp%d" % os.getpid()
         cmd = ["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-pthread", "-DFSK_EMU", "-ffp-contract=off",
-               "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-I", HERE, "-x", "c++", SRC, "-o", tmp]
+               "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-I", HERE, "-x", "c++", SRC,
+               os.path.join(ROOT, "fastsk_amd", "csrc", "fsk_fasta.cpp"), "-o", tmp]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             if os.path.exists(tmp):

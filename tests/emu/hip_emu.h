@@ -262,6 +262,7 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDevi
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipSetDevice(int) { return 0; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
 template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }

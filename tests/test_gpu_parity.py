@@ -316,29 +316,56 @@ def test_edge_cases_and_error_convention(native, port):
     e.close()
 
 
-@pytest.mark.parametrize("shard", ["auto", "combos"])
+@pytest.mark.parametrize("shard", ["combos", "rows"])
 def test_bench_two_ranks_sharing_the_gpu(native, shard):
-    """bench.py's multi-rank flow end to end (launch as the driver does, both decompositions, the
-    `alt` leg, the JSON contract) with two ranks on cuda:0 over gloo — everything but RCCL."""
+    """bench.py's multi-rank flow end to end, started the way a user would — `python bench.py --gpus 2`,
+    no external launcher: bench.py spawns its own ranks before touching the GPU — both decompositions
+    with full steps, the JSON contract, two ranks on cuda:0 over gloo: everything but RCCL."""
     import json
     import subprocess
     import sys
     from conftest import ROOT
     env = dict(os.environ, FSK_BENCH_SHARE_GPU="1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29721" if shard == "auto" else "29722", os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--steps", "1", "--warmup", "1", "--n-seq", "6000", "--shard", shard],
-                       env=env, capture_output=True, text=True, timeout=900)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--n-seq", "6000", "--shard", shard], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])   # the JSON line is the last thing printed
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "comm"):
         assert key in d
     assert d["n_gpus"] == 2 and d["unit"] == "combos/s" and d["value"] > 0 and d["scaling"] == "strong"
     assert d["config"]["combos"] == 495 and d["config"]["n_seq"] == 6000
-    assert ("row-band" in d["config"]["parallelism"]) == (shard == "auto")
+    assert ("row-band" in d["config"]["parallelism"]) == (shard == "rows")
+    assert ("combo-sharded" in d["config"]["parallelism"]) == (shard == "combos")
     assert d["alt"]["value"] > 0 and ("row-band" in d["alt"]["parallelism"]) == (shard == "combos")
+    assert d["alt"]["steps"] == 2 and d["alt"]["warmup"] == 1          # both decompositions at equal weight
+    assert d["comm"]["rccl_ranks"] == 0 and "gloo" in d["comm"]["backend"]  # (a shared GPU cannot run RCCL)
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert d["roofline"]["bound"] == "valu" and 0 < d["roofline"]["frac"] <= 1.0
+
+
+def test_bench_rccl_leg_on_one_rank(native):
+    """The RCCL leg itself (backend nccl, device_id, band-wise int32 all-reduce ordered by stream events)
+    with a world of one — the most this single-GPU box can run of it — and config 4 through the
+    sparse dataflow."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, FSK_BENCH_FORCE_DIST="1", MASTER_PORT="29741")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    for extra, path in ((["--n-seq", "9000"], "dense"), (["--config", "4"], "sparse")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+                            "--no-cpu-baseline", "--no-also"] + extra, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["comm"]["rccl_ranks"] == 1 and "RCCL" in d["comm"]["backend"] and d["comm"]["allreduce_dtype"] == "int32"
+        assert d["config"]["path"] == path and d["value"] > 0
+        if path == "sparse":
+            assert d["config"]["combos"] == 1001 and d["roofline"]["bound"] == "hbm" and d["roofline"]["cell_updates_per_step"] > 1e9
 
 
 @pytest.mark.parametrize("surface", ["ctypes", "pybind"])

@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def newest(pattern):
@@ -53,9 +53,16 @@ def main():
     tile = lambda c: max(r["value_KiB"] for r in rows if r["counter"] == c and "k_dense_tile" in r["kernel"])
     bench = json.loads(json_line(os.path.join(SRC, "bench.json")))
     fetch, write = tile("FETCH_SIZE") * 1024 * 2, tile("WRITE_SIZE") * 1024
+    sys.path.insert(0, ROOT)
+    import subprocess
+    from bench import kernel_hashes
+    commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "fastsk_amd/csrc"], capture_output=True, text=True).stdout.strip()
     json.dump({"n_seq": bench["config"]["n_seq"], "combos_per_launch": int(bench["roofline"]["combos_per_launch"]),
                "kernel": "fsk::k_dense_tile_dma", "fetch_bytes_corrected": fetch, "write_bytes": write,
                "hbm_bytes_per_launch": fetch + write,
+               # bench.py refuses these numbers once the kernel sources they were measured on change
+               "kernel_files": kernel_hashes(), "commit": commit + ("+uncommitted csrc changes" if dirty else ""),
                "source": "profiles/%s_pmc_bench100k.json (the 495-combo launch): FETCH_SIZE KiB x1024 x2 (gfx950 correction) + "
                          "WRITE_SIZE KiB x1024" % TAG}, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
     for src, dst in (("configs.jsonl", TAG + "_configs1-4_gpu_timings.jsonl"), ("large_g.jsonl", TAG + "_large_g_regime.jsonl")):
