@@ -136,18 +136,22 @@ struct fsk_engine {
     std::vector<int32_t> prep_combos;              // combos whose count panels are resident
     bool prep_valid = false, prep_overflow = false;
     // sparse scratch
-    DevBuf<unsigned char> d_keys[2];
-    DevBuf<uint32_t> d_vals[2], d_blockhist, d_totals, d_estart, d_eseq, d_erun, d_rstart, d_segtot;
-    DevBuf<u64> d_blocksum, d_U;
+    DevBuf<unsigned char> d_keys[2];      // packed sort records (u32 or u64), double-buffered
+    DevBuf<uint32_t> d_blockhist, d_totals, d_tile_ent, d_ebase, d_Pk, d_owner_r0, d_ucount, d_uchunk, d_utot, d_list_off, d_ulist, d_part_base;
+    DevBuf<u64> d_tile_stat;
+    DevBuf<int> d_tile_lrh, d_tile_rs;
+    DevBuf<uint2> d_E;                    // entries: {sequence, multiplicity}
+    DevBuf<u64> d_sxstat, d_U;
+    std::vector<uint32_t> h_owner_r0;     // owner bands of K: rows [r0[o], r0[o+1])
+    uint32_t n_owners = 0, sx_rounds = 1, sx_cap = 0;
+    int sx_pb = 16, sx_sb = 1, sx_keybits = 1, sx_own_shift = 13;
+    bool sx_lists = false, owner_ready = false;
     // profile mode, dense dataflow: U of the last single-chunk combo list is kept, so that repeating
     // the same pass (bench steps, row bands of later passes) does not re-read every count panel
     DevBuf<u64> d_U2;
     std::vector<int32_t> u_combos;
     bool u_known = false, u_pending = false;
     u64 u_value = 0, u_extra = 0;
-    DevBuf<uint32_t> d_bk_hist, d_bk_tot, d_slice_off;  // owner-slice pair accumulation
-    DevBuf<uint4> d_list;
-    DevBuf<uint2> d_epair;
     int force_global_pairs = 0;  // FSK_SPARSE_GLOBAL=1: per-pair global atomics (testing)
     int tile_dma = 1;            // FSK_TILE_DMA=0: register-staged tile kernel instead of the direct-to-LDS one (testing)
 
@@ -290,59 +294,108 @@ int choose_path(fsk_engine* e) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// sparse dataflow for a batch of combos (composite key = slot * V + k-mer)
-template <typename KeyT>
-int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t row0, int64_t row1) {
-    const size_t nrec = (size_t)nb * (size_t)e->nfeat;
-    if (nrec == 0) return FSK_OK;
-    // Only the k-mer bits are sorted. The records are generated combo-major and every LSD pass is
-    // stable, so after sorting on the k-mer alone the records of one (combo, k-mer) are still
-    // contiguous, in sequence order — groups are all the segment kernels need (they compare whole
-    // keys); the order of the groups is irrelevant to the sums. Saves the passes over the combo bits.
-    int keybits = 1;
-    while (keybits < 64 && ((u64)1 << keybits) < (u64)e->V) ++keybits;
-    const int passes = (keybits + 7) / 8;
-    const uint32_t rs_blocks = (uint32_t)((nrec + fsk::RS_TILE - 1) / fsk::RS_TILE);
-    const uint32_t seg_blocks = (uint32_t)((nrec + fsk::SEG_TILE - 1) / fsk::SEG_TILE);
-    for (int b = 0; b < 2; ++b) {
-        FSK_HIP(e->d_keys[b].reserve(nrec * sizeof(KeyT)));
-        FSK_HIP(e->d_vals[b].reserve(nrec));
+// sparse dataflow: owner bands of K. The update stream of a band is summed in LDS by one workgroup,
+// so a band is a range of whole rows with about 8192 cells (the LDS budget of k_sx_consume bounds
+// it: SX_CAP cells per round, at most SX_MAX_ROUNDS rounds over the band's stream).
+constexpr uint32_t SX_CAP = 16384;        // u32 cells of K one k_sx_consume workgroup holds in LDS (64 KiB)
+constexpr uint32_t SX_MAX_ROUNDS = 16;
+constexpr u64 SX_MAX_LIST_WORDS = (u64)1 << 31;
+
+void plan_owner_bands(fsk_engine* e) {
+    // band o = the rows whose first cell index lies in [o << t, (o + 1) << t): a row's band is a shift
+    // of its triangular index, bands hold about 2^t cells (2^t + N at most: the last row of a band is
+    // kept whole) and can be empty when a single row is longer than 2^t cells.
+    const u64 N = (u64)e->N, cells = N * (N + 1) / 2;
+    int t = 13;
+    while ((((cells + (((u64)1) << t) - 1) >> t)) > (u64)fsk::SX_MAX_OWNERS) ++t;
+    e->sx_own_shift = t;
+    e->n_owners = (uint32_t)((cells + (((u64)1) << t) - 1) >> t);
+    e->h_owner_r0.assign((size_t)e->n_owners + 1, (uint32_t)N);
+    u64 largest = 0;
+    {
+        uint32_t o = 0;  // r0[o] = first row whose triangular index reaches o << t
+        for (u64 i = 0; i < N && o <= e->n_owners; ++i)
+            while (o <= e->n_owners && (i * (i + 1) / 2) >= ((u64)o << t)) e->h_owner_r0[o++] = (uint32_t)i;
+        for (uint32_t q = 0; q < e->n_owners; ++q) {
+            const u64 a = e->h_owner_r0[q], b = e->h_owner_r0[q + 1];
+            largest = std::max(largest, b * (b + 1) / 2 - a * (a + 1) / 2);
+        }
     }
-    FSK_HIP(e->d_blockhist.reserve((size_t)256 * rs_blocks));
-    FSK_HIP(e->d_totals.reserve(256));
-    FSK_HIP(e->d_blocksum.reserve(seg_blocks));
-    FSK_HIP(e->d_estart.reserve(nrec + 1));
-    FSK_HIP(e->d_eseq.reserve(nrec));
-    FSK_HIP(e->d_erun.reserve(nrec));
-    FSK_HIP(e->d_rstart.reserve(nrec));
-    FSK_HIP(e->d_segtot.reserve(2));
-    FSK_HIP(e->d_U.reserve(1));
+    int L = 1;
+    while (((u64)1 << L) < largest) ++L;
+    e->sx_pb = 32 - L;
+    e->sx_rounds = (uint32_t)std::max<u64>(1, (largest + SX_CAP - 1) / SX_CAP);
+    e->sx_cap = (uint32_t)std::max<u64>(1, std::min<u64>(SX_CAP, largest));
+    e->sx_lists = e->n_owners <= (uint32_t)fsk::SX_MAX_OWNERS && e->sx_rounds <= SX_MAX_ROUNDS && e->sx_pb >= 8;
+    e->owner_ready = false;
+}
+
+template <typename RecT>
+int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t row0, int64_t row1) {
+    const uint32_t nfeat = (uint32_t)e->nfeat;
+    const size_t nrec = (size_t)nb * nfeat;
+    if (nrec == 0) return FSK_OK;
+    // Only the k-mer bits are sorted: the records of a slot are generated in sequence order and every
+    // LSD pass is stable, so equal k-mers end up contiguous with their sequence ids ascending.
+    int keybits = 1;
+    while (keybits < 62 && ((u64)1 << keybits) < (u64)e->V) ++keybits;
+    const int sb = e->sx_sb;
+    const int passes = (keybits + 7) / 8;
+    const uint32_t tps = (nfeat + fsk::SX_TILE - 1) / fsk::SX_TILE;   // sort tiles per slot
+    const uint32_t tpg = (nfeat + fsk::SG_TILE - 1) / fsk::SG_TILE;   // segment tiles per slot
+    const uint32_t ntiles = tpg * (uint32_t)nb;
+    const bool lists = e->sx_lists && !e->force_global_pairs;
+    const uint32_t O = e->n_owners;
+    for (int b = 0; b < 2; ++b) FSK_HIP(e->d_keys[b].reserve(nrec * sizeof(RecT)));
+    FSK_HIP(e->d_blockhist.reserve((size_t)256 * tps * nb));
+    FSK_HIP(e->d_totals.reserve((size_t)256 * nb));
+    FSK_HIP(e->d_tile_ent.reserve(ntiles));
+    FSK_HIP(e->d_tile_lrh.reserve(ntiles));
+    FSK_HIP(e->d_tile_rs.reserve(ntiles));
+    FSK_HIP(e->d_ebase.reserve((size_t)ntiles + 1));
+    FSK_HIP(e->d_E.reserve(nrec));
+    FSK_HIP(e->d_Pk.reserve(nrec));
+    FSK_HIP(e->d_sxstat.reserve(2));
+    FSK_HIP(e->d_tile_stat.reserve((size_t)2 * ntiles));
     FSK_HIP(e->d_pos.reserve((size_t)nb * e->k));
+    if (!e->owner_ready) {
+        FSK_HIP(e->d_owner_r0.reserve(e->h_owner_r0.size()));
+        FSK_HIP(hipMemcpyAsync(e->d_owner_r0.p, e->h_owner_r0.data(), e->h_owner_r0.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        e->owner_ready = true;  // (h_owner_r0 lives as long as the engine: no wait needed)
+    }
+    const uint32_t nchunks = (ntiles + fsk::UC_CHUNK - 1) / fsk::UC_CHUNK;
+    if (lists) {
+        FSK_HIP(e->d_ucount.reserve((size_t)O * ntiles));
+        FSK_HIP(e->d_uchunk.reserve((size_t)O * nchunks));
+        FSK_HIP(e->d_utot.reserve(O));
+        FSK_HIP(e->d_list_off.reserve((size_t)O + 1));
+        FSK_HIP(e->d_part_base.reserve((size_t)O + 1));
+    }
     std::vector<uint8_t> pos((size_t)nb * e->k);
     for (int s = 0; s < nb; ++s)
         memcpy(&pos[(size_t)s * e->k], &e->all_pos[(size_t)combos[s] * e->k], e->k);
     FSK_HIP(hipMemcpyAsync(e->d_pos.p, pos.data(), pos.size(), hipMemcpyHostToDevice, e->stream));
+    FSK_HIP(hipMemsetAsync(e->d_sxstat.p, 0, 2 * sizeof(u64), e->stream));
     FSK_HIP(hipStreamSynchronize(e->stream));  // `pos` is a pageable temporary
 
-    KeyT* keys[2] = {(KeyT*)e->d_keys[0].p, (KeyT*)e->d_keys[1].p};
-    uint32_t* vals[2] = {e->d_vals[0].p, e->d_vals[1].p};
-    const uint32_t fblocks = (uint32_t)((e->nfeat + 255) / 256);
+    RecT* rec[2] = {(RecT*)e->d_keys[0].p, (RecT*)e->d_keys[1].p};
+    const uint32_t fblocks = (nfeat + 255) / 256;
 
     e->tic();
-    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sparse_extract<KeyT>), dim3(fblocks, nb), dim3(256), 0, e->stream, e->view(),
-               e->d_featseq.p, e->d_fstart.p, (uint32_t)e->nfeat, e->k, e->sigma, e->V, e->d_pos.p, keys[0], vals[0]);
+    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_extract<RecT>), dim3(fblocks, nb), dim3(256), 0, e->stream, e->view(), e->d_featseq.p,
+               e->d_fstart.p, nfeat, e->k, e->sigma, sb, e->d_pos.p, rec[0]);
     e->toc(&e->st.ms_extract);
     e->st.launches += 1;
 
     e->tic();
     int cur = 0;
     for (int p = 0; p < passes; ++p) {
-        const int shift = 8 * p;
-        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_rs_hist<KeyT>), dim3(rs_blocks), dim3(256), 0, e->stream, keys[cur], (u64)nrec,
-                   shift, e->d_blockhist.p, rs_blocks);
-        FSK_LAUNCH(fsk::k_rs_scan_rows, dim3(256), dim3(256), 0, e->stream, e->d_blockhist.p, rs_blocks, e->d_totals.p);
-        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_rs_scatter<KeyT>), dim3(rs_blocks), dim3(256), 0, e->stream, keys[cur],
-                   vals[cur], keys[cur ^ 1], vals[cur ^ 1], (u64)nrec, shift, e->d_blockhist.p, e->d_totals.p, rs_blocks);
+        const int shift = sb + 8 * p;
+        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_hist<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tps, shift,
+                   e->d_blockhist.p);
+        FSK_LAUNCH(fsk::k_sx_scan_slot, dim3(nb), dim3(256), 0, e->stream, e->d_blockhist.p, tps, e->d_totals.p);
+        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_scatter<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, rec[cur], rec[cur ^ 1], nfeat,
+                   tps, shift, e->d_blockhist.p, e->d_totals.p);
         cur ^= 1;
         e->st.launches += 3;
     }
@@ -351,50 +404,62 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     e->st.sort_passes = passes;
 
     e->tic();
-    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_seg_reduce<KeyT>), dim3(seg_blocks), dim3(256), 0, e->stream, keys[cur], vals[cur],
-               (u64)nrec, e->d_blocksum.p);
-    FSK_LAUNCH(fsk::k_seg_scan_blocks, dim3(1), dim3(256), 0, e->stream, e->d_blocksum.p, seg_blocks, (u64)nrec,
-               e->d_segtot.p, e->d_estart.p);
-    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_seg_write<KeyT>), dim3(seg_blocks), dim3(256), 0, e->stream, keys[cur], vals[cur],
-               (u64)nrec, e->d_blocksum.p, e->d_estart.p, e->d_eseq.p, e->d_erun.p, e->d_rstart.p);
+    const uint32_t maxprod = (1u << e->sx_pb) - 1u;
+    const uint32_t cmax = maxprod / std::max<uint32_t>(1u, e->maxW);  // multiplicities up to here: one word per pair
+    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_seg_count<RecT>), dim3(tpg, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tpg, sb,
+               e->d_tile_ent.p, e->d_tile_lrh.p);
+    FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(1), dim3(256), 0, e->stream, e->d_tile_ent.p, e->d_tile_lrh.p, ntiles, e->d_ebase.p,
+               e->d_tile_rs.p);
+    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_seg_write<RecT>), dim3(tpg, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tpg, sb,
+               e->d_ebase.p, e->d_tile_rs.p, e->d_E.p, e->d_Pk.p, e->sx_own_shift, O,
+               lists ? e->d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->d_tile_stat.p);
+    FSK_LAUNCH(fsk::k_sx_stat_sum, dim3(32), dim3(256), 0, e->stream, (const u64*)e->d_tile_stat.p, ntiles, e->d_sxstat.p);
+    e->st.launches += 4;
+    u64 words = 0;
+    if (lists) {  // where every (tile, owner) share of the update streams starts
+        FSK_LAUNCH(fsk::k_sx_ucol_sum, dim3(nchunks), dim3(256), 0, e->stream, (const uint32_t*)e->d_ucount.p, ntiles, O, e->d_uchunk.p);
+        FSK_LAUNCH(fsk::k_sx_ucol_scan, dim3((O + 255) / 256), dim3(256), 0, e->stream, e->d_uchunk.p, nchunks, O, e->d_utot.p);
+        FSK_LAUNCH(fsk::k_scan_totals, dim3(1), dim3(256), 0, e->stream, (const uint32_t*)e->d_utot.p, O, e->d_list_off.p);
+        FSK_LAUNCH(fsk::k_sx_ucol_apply, dim3(nchunks), dim3(256), 0, e->stream, e->d_ucount.p, ntiles, O, (const uint32_t*)e->d_uchunk.p);
+        e->st.launches += 4;
+    }
+    u64 stat[2] = {0, 0};
+    FSK_HIP(hipMemcpyAsync(stat, e->d_sxstat.p, sizeof stat, hipMemcpyDeviceToHost, e->stream));
+    FSK_HIP(hipStreamSynchronize(e->stream));  // the update streams are sized exactly
     e->toc(&e->st.ms_segment);
+    e->u_extra += stat[0];
+    words = stat[1];
 
     e->tic();
-    // rows of K per owner slice: as many as fit 32 KiB of u32 cells (four workgroups per CU hide
-    // the latency of the partner fetches)
-    const size_t row_bytes = (size_t)e->N * sizeof(uint32_t);
-    const uint32_t rps = (uint32_t)std::min<size_t>((size_t)e->N, std::max<size_t>(1, ((size_t)32 << 10) / row_bytes));
-    const uint32_t n_slices = (uint32_t)((e->N + rps - 1) / rps);
-    const bool lds_ok = row_bytes <= LDS_BUDGET && n_slices <= (uint32_t)fsk::BK_MAX_SLICES && !e->force_global_pairs;
-    if (lds_ok) {
-        const uint32_t bk_blocks = (uint32_t)((nrec + fsk::BK_TILE - 1) / fsk::BK_TILE);
-        FSK_HIP(e->d_bk_hist.reserve((size_t)n_slices * bk_blocks));
-        FSK_HIP(e->d_bk_tot.reserve(n_slices));
-        FSK_HIP(e->d_slice_off.reserve((size_t)n_slices + 1));
-        FSK_HIP(e->d_list.reserve(nrec * (size_t)4));  // up to BK_SPLIT work records per entry
-        FSK_HIP(e->d_epair.reserve(nrec));
-        FSK_LAUNCH(fsk::k_bucket_hist, dim3(bk_blocks), dim3(256), 0, e->stream, e->d_segtot.p, e->d_estart.p, e->d_eseq.p,
-                   e->d_erun.p, e->d_rstart.p, rps,
-                   n_slices, bk_blocks, e->d_bk_hist.p, e->d_epair.p);
-        FSK_LAUNCH(fsk::k_rs_scan_rows, dim3(n_slices), dim3(256), 0, e->stream, e->d_bk_hist.p, bk_blocks, e->d_bk_tot.p);
-        FSK_LAUNCH(fsk::k_bucket_scan_totals, dim3(1), dim3(256), 0, e->stream, e->d_bk_tot.p, n_slices, e->d_slice_off.p);
-        FSK_LAUNCH(fsk::k_bucket_scatter, dim3(bk_blocks), dim3(256), 0, e->stream, e->d_segtot.p, e->d_epair.p, e->d_erun.p,
-                   e->d_rstart.p, rps, n_slices, bk_blocks, e->d_bk_hist.p, e->d_slice_off.p, e->d_list.p);
-        const uint32_t s_lo = (uint32_t)(row0 / rps), s_hi = (uint32_t)((row1 + rps - 1) / rps);
-        const size_t lds = (size_t)rps * row_bytes;
+    const bool use_lists = lists && words < SX_MAX_LIST_WORDS;
+    if (use_lists) {
+        if (words > 0) {
+            FSK_HIP(e->d_ulist.reserve((size_t)words));
+            FSK_LAUNCH(fsk::k_sx_emit<false>, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
+                       (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)e->d_list_off.p,
+                       (const uint32_t*)e->d_ucount.p, e->d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K);
+            const size_t lds = (size_t)e->sx_cap * sizeof(uint32_t);
 #ifndef FSK_EMU
-        FSK_HIP(hipFuncSetAttribute((const void*)fsk::k_slice_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            FSK_HIP(hipFuncSetAttribute((const void*)fsk::k_sx_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #endif
-        if (s_hi > s_lo)
-            FSK_LAUNCH(fsk::k_slice_pairs, dim3(s_hi - s_lo), dim3(256), lds, e->stream, e->d_slice_off.p, e->d_list.p, e->d_epair.p,
-                       rps, (uint32_t)e->N, s_lo, (u64)row0, (u64)row1, K, e->d_U.p);
-        e->st.launches += 4;
+            // parts of about `target` words: ~1024 workgroups, and never so short that the flush of a
+            // part (up to sx_cap cells) outweighs the words it summed
+            const uint32_t target = (uint32_t)std::max<u64>((u64)4 * e->sx_cap, (words + 1023) / 1024);
+            const uint32_t max_parts = O + (uint32_t)((words + target - 1) / target);
+            FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, e->stream, (const uint32_t*)e->d_list_off.p, O, target, e->d_part_base.p);
+            FSK_LAUNCH(fsk::k_sx_consume, dim3(max_parts, e->sx_rounds), dim3(fsk::CS_THREADS), lds, e->stream, (const uint32_t*)e->d_ulist.p,
+                       (const uint32_t*)e->d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)e->d_part_base.p, O, target,
+                       e->sx_cap, e->sx_pb, K);
+            e->st.launches += 1;
+            e->st.launches += 2;
+        }
     } else {
-        FSK_LAUNCH(fsk::k_sparse_pairs, dim3((uint32_t)((nrec + 255) / 256)), dim3(256), 0, e->stream, e->d_segtot.p,
-                   e->d_estart.p, e->d_eseq.p, e->d_erun.p, e->d_rstart.p, (u64)row0, (u64)row1, K, e->d_U.p);
+        FSK_LAUNCH(fsk::k_sx_emit<true>, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
+                   (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)nullptr,
+                   (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K);
+        e->st.launches += 1;
     }
     e->toc(&e->st.ms_pairs);
-    e->st.launches += 4;
     FSK_HIP(hipGetLastError());
     return FSK_OK;
 }
@@ -416,15 +481,18 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     { int rcz = materialise_zero(e); if (rcz) return rcz; }
     int rc = ensure_featseq(e);
     if (rc) return rc;
-    // batch so that the composite key stays below 2^62 and the record count below the cap
+    if (e->sx_keybits + e->sx_sb > 64)
+        return e->fail(FSK_EUNSUPPORTED, "sparse dataflow: k-mer (%d bits) + sequence id (%d bits) exceed a 64-bit sort record",
+                       e->sx_keybits, e->sx_sb);
+    // batch so that the record count stays below the cap ...
     size_t per = SPARSE_MAX_RECORDS / (size_t)std::max<int64_t>(1, e->nfeat);
     int B = (int)std::max<size_t>(1, std::min<size_t>(per, (size_t)n));
-    while (B > 1 && (u64)B * e->V >= ((u64)1 << 62)) B /= 2;
-    // the owner-slice accumulation sums a batch in u32 LDS cells: per cell and combo <= maxW^2
+    // ... and the owner bands can sum a batch in u32 LDS cells: per cell and combo <= maxW^2
     B = (int)std::max<u64>(1, std::min<u64>((u64)B, 0xffffffffull / std::max<u64>(1, (u64)e->maxW * e->maxW)));
+    B = std::min(B, 65535);  // grid.y
+    const bool wide = e->sx_keybits + e->sx_sb > 32;
     for (int s = 0; s < n; s += B) {
         const int nb = std::min(B, n - s);
-        const bool wide = (u64)nb * e->V > 0xffffffffull;
         rc = wide ? sparse_batch<u64>(e, combos + s, nb, K, row0, row1) : sparse_batch<uint32_t>(e, combos + s, nb, K, row0, row1);
         if (rc) return rc;
     }
@@ -1050,10 +1118,10 @@ void fsk_destroy(fsk_engine* e) {
     e->d_words.release(); e->d_wstart.release(); e->d_len.release(); e->d_fstart.release(); e->d_featseq.release();
     e->d_pos.release(); e->K_store.release(); e->d_Kf64.release(); e->d_Khat.release(); e->d_prod.release();
     e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_cell_idx.release(); e->d_C4.release(); e->d_C4H.release(); e->d_rowmask.release(); e->d_flag.release(); e->d_tiletab.release(); e->d_keybits.release(); e->d_lut.release(); e->d_vc.release();
-    for (int b = 0; b < 2; ++b) { e->d_keys[b].release(); e->d_vals[b].release(); }
-    e->d_blockhist.release(); e->d_totals.release(); e->d_estart.release(); e->d_eseq.release(); e->d_erun.release();
-    e->d_rstart.release(); e->d_segtot.release(); e->d_blocksum.release(); e->d_U.release(); e->d_U2.release();
-    e->d_bk_hist.release(); e->d_bk_tot.release(); e->d_slice_off.release(); e->d_list.release(); e->d_epair.release();
+    for (int b = 0; b < 2; ++b) e->d_keys[b].release();
+    e->d_blockhist.release(); e->d_totals.release(); e->d_tile_ent.release(); e->d_ebase.release(); e->d_Pk.release();
+    e->d_owner_r0.release(); e->d_ucount.release(); e->d_uchunk.release(); e->d_part_base.release(); e->d_tile_stat.release(); e->d_utot.release(); e->d_list_off.release(); e->d_ulist.release();
+    e->d_tile_lrh.release(); e->d_tile_rs.release(); e->d_E.release(); e->d_sxstat.release(); e->d_U.release(); e->d_U2.release();
     if (e->h_prod) (void)hipHostFree(e->h_prod);
     if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
     if (e->ev_order) (void)hipEventDestroy(e->ev_order);
@@ -1219,6 +1287,13 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
     e->lazy_lo = e->lazy_hi = -1;  // (the triangle is filled with zeros below)
     e->u_known = false; e->u_pending = false; e->u_extra = 0; e->u_value = 0;
     if (e->V > DENSE_MAX_KEYS) e->Vq = 1;  // unused on the sparse path
+    {   // sparse dataflow: sort record = (k-mer << sx_sb) | sequence id; owner bands of K
+        e->sx_sb = 1;
+        while (((int64_t)1 << e->sx_sb) < N) ++e->sx_sb;
+        e->sx_keybits = 1;
+        while (e->sx_keybits < 62 && ((u64)1 << e->sx_keybits) < V) ++e->sx_keybits;
+        plan_owner_bands(e);
+    }
     int rc = choose_path(e);
     if (rc) return rc;
     {   // key compaction pays when a symbol is rare (DNA with a few 'n'): most of the sigma^k key

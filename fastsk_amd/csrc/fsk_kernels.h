@@ -18,13 +18,14 @@
 //                    registers over ALL combos of the launch, then ONE 64-bit atomicAdd per cell.
 //
 //   SPARSE (large key space, e.g. protein: 24^4 keys, runs of 3-5) — the reference's dataflow
-//     k_sparse_extract  packed (combo,k-mer) key + sequence id per g-mer, straight from packed HBM
-//     k_rs_*            LDS-staged 8-bit LSD radix sort (wave64 ballot match ranking, stable)
-//     k_seg_*           run heads by neighbour compare, wave prefix sums -> distinct (k-mer,seq)
-//                       entries with multiplicities and run starts
-//     k_bucket_* + k_slice_pairs  (run, pair) updates summed in LDS by the workgroup that owns the
-//                       rows, non-zero cells flushed with 64-bit atomicAdd (k_sparse_pairs: direct
-//                       per-pair atomics, used when a row band of K does not fit in LDS)
+//     k_sx_extract      packed record (k-mer << sb | sequence id) per g-mer, straight from packed HBM
+//     k_sx_hist/scatter LDS-staged 8-bit LSD radix sort, one independent sort per combo of the batch
+//                       (wave64 ballot match ranking, stable)
+//     k_sx_seg_*        run heads by neighbour compare, block prefix sums -> distinct (k-mer,seq)
+//                       entries with multiplicities and ranks inside their run
+//     k_sx_emit + k_sx_consume  every (run, pair) update becomes a 32-bit word in the stream of the
+//                       workgroup that owns the rows; the owner sums its stream in LDS and adds the
+//                       non-zero cells into the 64-bit triangle (DIRECT: 64-bit atomicAdd per pair)
 //
 // Everything is written for 64-wide wavefronts; lane = threadIdx.x & 63.
 #pragma once
@@ -67,6 +68,30 @@ __device__ __forceinline__ T block_excl_scan_256(T v, T* tmp, T* total) {
     T base = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
+        T t = tmp[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    if (total) *total = tot;
+    return base + x - v;
+}
+
+// the same for a block of NW waves (NW * 64 threads). tmp: >= NW entries.
+template <typename T, int NW>
+__device__ __forceinline__ T block_excl_scan(T v, T* tmp, T* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) tmp[wave] = x;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
         T t = tmp[w];
         if (w < wave) base += t;
         tot += t;
@@ -387,13 +412,67 @@ __global__ __launch_bounds__(64) void k_dense_distinct(const uint32_t* C4, const
 #include "fsk_tile_kernel_dma.inc"
 
 // =============================================================================================
-// SPARSE PATH
+// SPARSE PATH — the reference's dataflow (gather -> sort -> run-length -> K +=), as streams
 // =============================================================================================
-// key = slot * V + sum_c sym[j+pos_c] * sigma^(k-1-c): one record per (slot, g-mer).
-template <typename KeyT>
-__global__ __launch_bounds__(256) void k_sparse_extract(SeqView S, const uint32_t* feat_seq, const uint32_t* fstart,
-                                                        uint32_t nfeat, int k, uint32_t sigma, u64 V,
-                                                        const uint8_t* combo_pos, KeyT* keys, uint32_t* vals) {
+// Per batch of B combos ("slots"):
+//   k_sx_extract   one packed record per (slot, g-mer): rec = (k-mer << sb) | sequence id, u32 when
+//                  that fits 32 bits (every BASELINE config) else u64; slot s owns rec[s*nfeat ..):
+//                  the slot is implicit in the position, so B independent sorts run in one launch.
+//   k_sx_hist / k_rs_scan_rows / k_sx_scatter   stable LSD radix sort over the k-mer bits only
+//                  (records are generated in sequence order and every pass is stable), 8-bit digits,
+//                  4096-record tiles ranked with wave64 ballot matching, permuted in LDS and written
+//                  out in digit runs.
+//   k_sx_seg_count / k_sx_seg_scan / k_sx_seg_write   sorted records -> compact entries
+//                  E[e] = {sequence, multiplicity} (distinct (k-mer, sequence) pairs, compacted through
+//                  LDS so the write is coalesced) and Pk[e] = rank of the entry inside its run of
+//                  equal k-mers, counted from 1: entry e pairs with entries e-Pk[e]+1 .. e — exactly
+//                  the `+=` of countAndUpdateTri (shared.cpp:316-327).
+//   k_sx_emit      every (entry, partner) pair becomes one 32-bit update word {cell inside its owner's
+//                  band of rows of K, product of the two multiplicities}; the words of a tile are
+//                  binned by owner in LDS and leave as contiguous runs (long entries write their
+//                  partner range directly, one wave per entry).
+//   k_sx_consume   one workgroup per owner band sums its update stream in LDS (u32 cells) and adds
+//                  the non-zero cells into the 64-bit triangle, row-contiguous, no atomics needed
+//                  (a cell has one owner; launches are ordered on the stream).
+// When a band of K does not fit the LDS budget (very large N) or FSK_SPARSE_GLOBAL=1, k_sx_emit adds
+// every product into K with a 64-bit atomicAdd instead (DIRECT).
+constexpr int SX_TILE = 4096;           // records per sort tile
+constexpr int SX_ITEMS = SX_TILE / 256;
+constexpr int SG_TILE = 2048;           // records per segment tile = most entries one emit workgroup holds
+constexpr int SG_ITEMS = SG_TILE / 256;
+constexpr int SX_MAX_OWNERS = 512;      // owner bands of K (bins of the update streams)
+constexpr uint32_t SX_SHORT = 8;        // entries with up to this many partners are staged in LDS
+
+// block-wide exclusive running maximum of one int per thread (256 threads); identity = -1 (all
+// values are >= -1). Every thread of the block must call it.
+__device__ __forceinline__ int block_excl_maxscan_256(int v, int* tmp, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d && y > x) x = y;
+    }
+    int prev = __shfl_up(x, 1);
+    if (lane == 0) prev = -1;
+    __syncthreads();  // tmp may still be read from a previous call
+    if (lane == 63) tmp[wave] = x;
+    __syncthreads();
+    int base = -1, tot = -1;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int t = tmp[w];
+        if (w < wave && t > base) base = t;
+        if (t > tot) tot = t;
+    }
+    if (total) *total = tot;
+    return base > prev ? base : prev;
+}
+
+// rec = (k-mer << sb) | sequence id, one per (slot, g-mer); grid = (ceil(nfeat/256), slots)
+template <typename RecT>
+__global__ __launch_bounds__(256) void k_sx_extract(SeqView S, const uint32_t* feat_seq, const uint32_t* fstart, uint32_t nfeat, int k,
+                                                    uint32_t sigma, int sb, const uint8_t* combo_pos, RecT* rec) {
     const uint32_t f = blockIdx.x * 256u + threadIdx.x;
     const uint32_t slot = blockIdx.y;
     if (f >= nfeat) return;
@@ -403,35 +482,55 @@ __global__ __launch_bounds__(256) void k_sparse_extract(SeqView S, const uint32_
     const uint8_t* pos = combo_pos + (size_t)slot * k;
     u64 key = 0;
     for (int c = 0; c < k; ++c) key = key * sigma + fetch_sym(S.words, wbase, j + pos[c], S.bits);
-    const size_t o = (size_t)slot * nfeat + f;
-    keys[o] = (KeyT)((u64)slot * V + key);
-    vals[o] = seq;
+    rec[(size_t)slot * nfeat + f] = (RecT)((key << sb) | (u64)seq);
 }
 
-constexpr int RS_ITEMS = 8;
-constexpr int RS_TILE = 256 * RS_ITEMS;
-
-// pass 1: per-workgroup digit histogram, stored digit-major so each digit row scans linearly
-template <typename KeyT>
-__global__ __launch_bounds__(256) void k_rs_hist(const KeyT* keys, u64 n, int shift, uint32_t* blockhist, uint32_t nblocks) {
+// digit histogram of one tile of one slot -> blockhist[slot][tile][digit]; grid = (tiles per slot, slots)
+template <typename RecT>
+__global__ __launch_bounds__(256) void k_sx_hist(const RecT* rec, uint32_t nfeat, uint32_t tps, int shift, uint32_t* blockhist) {
     __shared__ uint32_t h[256];
-    const int tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, tile = blockIdx.x, slot = blockIdx.y;
     h[tid] = 0u;
     __syncthreads();
-    const u64 base = (u64)blockIdx.x * RS_TILE;
+    const RecT* r = rec + (size_t)slot * nfeat;
+    const uint32_t base = tile * (uint32_t)SX_TILE;
 #pragma unroll
-    for (int it = 0; it < RS_ITEMS; ++it) {
-        const u64 i = base + (u64)it * 256 + tid;
-        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    for (int it = 0; it < SX_ITEMS; ++it) {
+        const uint32_t i = base + (uint32_t)it * 256u + tid;
+        if (i < nfeat) atomicAdd(&h[(uint32_t)(r[i] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    blockhist[(size_t)tid * nblocks + blockIdx.x] = h[tid];
+    blockhist[((size_t)slot * tps + tile) * 256u + tid] = h[tid];
 }
 
-// pass 2: one workgroup per digit: exclusive scan of its row in place, row total to totals[digit]
+// one workgroup per slot, thread = digit: the digit's tile counts become exclusive offsets inside the
+// digit's block (in place), and dbase[slot][digit] = where that block starts inside the slot
+__global__ __launch_bounds__(256) void k_sx_scan_slot(uint32_t* blockhist, uint32_t tps, uint32_t* dbase) {
+    __shared__ uint32_t tmp[4];
+    const uint32_t tid = threadIdx.x, slot = blockIdx.x;
+    uint32_t* h = blockhist + (size_t)slot * tps * 256u + tid;
+    uint32_t run = 0;
+    uint32_t t = 0;
+    for (; t + 4 <= tps; t += 4) {  // the four loads do not depend on the running sum
+        const uint32_t v0 = h[(size_t)t * 256u], v1 = h[(size_t)(t + 1) * 256u], v2 = h[(size_t)(t + 2) * 256u],
+                       v3 = h[(size_t)(t + 3) * 256u];
+        h[(size_t)t * 256u] = run;
+        h[(size_t)(t + 1) * 256u] = run + v0;
+        h[(size_t)(t + 2) * 256u] = run + v0 + v1;
+        h[(size_t)(t + 3) * 256u] = run + v0 + v1 + v2;
+        run += v0 + v1 + v2 + v3;
+    }
+    for (; t < tps; ++t) {
+        const uint32_t v = h[(size_t)t * 256u];
+        h[(size_t)t * 256u] = run;
+        run += v;
+    }
+    dbase[(size_t)slot * 256u + tid] = block_excl_scan_256<uint32_t>(run, tmp, nullptr);
+}
+
+// one workgroup per row: exclusive scan of the row in place, row total to totals[row]
 __global__ __launch_bounds__(256) void k_rs_scan_rows(uint32_t* blockhist, uint32_t nblocks, uint32_t* totals) {
     __shared__ uint32_t tmp[4];
-    __shared__ uint32_t carry_s;
     uint32_t* row = blockhist + (size_t)blockIdx.x * nblocks;
     const int tid = threadIdx.x;
     uint32_t carry = 0;
@@ -453,40 +552,60 @@ __global__ __launch_bounds__(256) void k_rs_scan_rows(uint32_t* blockhist, uint3
         }
         carry += tot;
     }
-    if (tid == 0) { totals[blockIdx.x] = carry; carry_s = carry; }
-    (void)carry_s;
+    if (tid == 0) totals[blockIdx.x] = carry;
 }
 
-// pass 3: stable scatter. Ranking inside the workgroup uses wave64 ballot matching (8 ballots
-// give the set of lanes holding the same digit); elements are first permuted into digit order
-// in LDS, then written out so that equal digits go to consecutive addresses.
-template <typename KeyT>
-__global__ __launch_bounds__(256) void k_rs_scatter(const KeyT* keys_in, const uint32_t* vals_in, KeyT* keys_out,
-                                                    uint32_t* vals_out, u64 n, int shift, const uint32_t* blockhist,
-                                                    const uint32_t* totals, uint32_t nblocks) {
-    __shared__ uint32_t goff[256];         // global destination of this workgroup's first `digit`
-    __shared__ uint32_t wave_cnt[4][256];  // per round: count, then offset, of digit in wave
-    __shared__ uint32_t running[256];      // digit count in earlier rounds
-    __shared__ uint32_t blk_start[256];    // exclusive scan of this workgroup's digit totals
+// exclusive scan of n totals (single workgroup), off[n] = grand total
+__global__ __launch_bounds__(256) void k_scan_totals(const uint32_t* totals_in, uint32_t n, uint32_t* off) {
     __shared__ uint32_t tmp[4];
-    __shared__ KeyT s_keys[RS_TILE];
-    __shared__ uint32_t s_vals[RS_TILE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u64 base = (u64)blockIdx.x * RS_TILE;
-    {
-        const uint32_t tot = totals[tid];
-        const uint32_t dbase = block_excl_scan_256<uint32_t>(tot, tmp, nullptr);
-        goff[tid] = dbase + blockhist[(size_t)tid * nblocks + blockIdx.x];
-        running[tid] = 0u;
+    const int tid = threadIdx.x;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 256) {
+        const uint32_t i = base + (uint32_t)tid;
+        const uint32_t v = i < n ? totals_in[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_256<uint32_t>(v, tmp, &tot) + carry;
+        if (i < n) off[i] = ex;
+        carry += tot;
     }
-    KeyT key[RS_ITEMS];
-    uint32_t val[RS_ITEMS], rank[RS_ITEMS];
+    if (tid == 0) off[n] = carry;
+}
+
+// Stable scatter of one tile of one slot. Wave w owns the contiguous quarter w of the tile, so the
+// four waves rank their records independently (wave64 ballot matching: 8 ballots give the lanes
+// holding the same digit; a per-wave LDS counter carries the digit's count from round to round)
+// and meet at ONE barrier; the records are then permuted into digit order in LDS and written out
+// so that equal digits go to consecutive addresses. grid = (tiles per slot, slots)
+template <typename RecT>
+__global__ __launch_bounds__(256) void k_sx_scatter(const RecT* in, RecT* out, uint32_t nfeat, uint32_t tps, int shift,
+                                                    const uint32_t* blockhist, const uint32_t* dbase) {
+    __shared__ uint32_t goff[256];         // destination, inside the slot, of this tile's first record of each digit
+    __shared__ uint32_t wave_run[4][256];  // per wave: records of the digit so far; later: where the wave's share starts in LDS
+    __shared__ uint32_t blk_start[256];    // exclusive scan of the tile's digit totals
+    __shared__ uint32_t tmp[4];
+    __shared__ RecT s_rec[SX_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tile = blockIdx.x, slot = blockIdx.y;
+    const RecT* r = in + (size_t)slot * nfeat;
+    RecT* o = out + (size_t)slot * nfeat;
+    goff[tid] = dbase[(size_t)slot * 256u + tid] + blockhist[((size_t)slot * tps + tile) * 256u + tid];
 #pragma unroll
-    for (int it = 0; it < RS_ITEMS; ++it) {
-        const u64 i = base + (u64)it * 256 + tid;
-        const bool valid = i < n;
-        key[it] = valid ? keys_in[i] : (KeyT)0;
-        val[it] = valid ? vals_in[i] : 0u;
+    for (int q = 0; q < 4; ++q) wave_run[q][tid] = 0u;
+    __syncthreads();
+    RecT key[SX_ITEMS];
+    uint32_t rank[SX_ITEMS];
+    const uint32_t base = tile * (uint32_t)SX_TILE + (uint32_t)wave * (SX_TILE / 4);
+    volatile uint32_t* my_run = wave_run[wave];
+#pragma unroll
+    for (int it = 0; it < SX_ITEMS; ++it) {
+        if (base + (uint32_t)it * 64u >= nfeat) {  // (wave-uniform) nothing of the slot left for this wave
+            key[it] = (RecT)0;
+            rank[it] = 0xffffffffu;
+            continue;
+        }
+        const uint32_t i = base + (uint32_t)it * 64u + (uint32_t)lane;
+        const bool valid = i < nfeat;
+        key[it] = valid ? r[i] : (RecT)0;
         const uint32_t digit = (uint32_t)(key[it] >> shift) & 255u;
         u64 peers = __ballot(valid);
 #pragma unroll
@@ -496,299 +615,499 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const KeyT* keys_in, const u
             peers &= bit ? m : ~m;
         }
         const uint32_t rank_in_wave = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
-        const uint32_t cnt = (uint32_t)__popcll(peers);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) wave_cnt[q][tid] = 0u;
-        __syncthreads();
-        if (valid && rank_in_wave == 0) wave_cnt[wave][digit] = cnt;
-        __syncthreads();
-        {
-            uint32_t off = running[tid];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t c = wave_cnt[q][tid];
-                wave_cnt[q][tid] = off;
-                off += c;
-            }
-            running[tid] = off;
-        }
-        __syncthreads();
-        rank[it] = valid ? wave_cnt[wave][digit] + rank_in_wave : 0xffffffffu;
-        __syncthreads();  // wave_cnt is cleared at the top of the next round
+        const uint32_t prior = valid ? my_run[digit] : 0u;
+        (void)__ballot(true);  // every lane has read the counter before the group's first lane adds to it
+        if (valid && rank_in_wave == 0) atomicAdd(&wave_run[wave][digit], (uint32_t)__popcll(peers));
+        rank[it] = valid ? prior + rank_in_wave : 0xffffffffu;
     }
+    __syncthreads();
     {
-        const uint32_t mine = running[tid];
-        const uint32_t ex = block_excl_scan_256<uint32_t>(mine, tmp, nullptr);
+        uint32_t c[4], tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { c[q] = wave_run[q][tid]; tot += c[q]; }
+        uint32_t ex = block_excl_scan_256<uint32_t>(tot, tmp, nullptr);
         blk_start[tid] = ex;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { wave_run[q][tid] = ex; ex += c[q]; }
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < RS_ITEMS; ++it) {
+    for (int it = 0; it < SX_ITEMS; ++it) {
         if (rank[it] != 0xffffffffu) {
             const uint32_t digit = (uint32_t)(key[it] >> shift) & 255u;
-            const uint32_t p = blk_start[digit] + rank[it];
-            s_keys[p] = key[it];
-            s_vals[p] = val[it];
+            s_rec[wave_run[wave][digit] + rank[it]] = key[it];
         }
     }
     __syncthreads();
-    const u64 remain = n - base;
-    const uint32_t nvalid = remain < (u64)RS_TILE ? (uint32_t)remain : (uint32_t)RS_TILE;
+    const uint32_t first = tile * (uint32_t)SX_TILE;
+    const uint32_t nvalid = nfeat - first < (uint32_t)SX_TILE ? nfeat - first : (uint32_t)SX_TILE;
 #pragma unroll
-    for (int it = 0; it < RS_ITEMS; ++it) {
+    for (int it = 0; it < SX_ITEMS; ++it) {
         const uint32_t p = (uint32_t)it * 256u + (uint32_t)tid;
         if (p < nvalid) {
-            const KeyT kx = s_keys[p];
+            const RecT kx = s_rec[p];
             const uint32_t digit = (uint32_t)(kx >> shift) & 255u;
-            const size_t dst = (size_t)goff[digit] + (p - blk_start[digit]);
-            keys_out[dst] = kx;
-            vals_out[dst] = s_vals[p];
+            o[goff[digit] + (p - blk_start[digit])] = kx;
         }
     }
 }
 
-// ---- segments: distinct (key, seq) entries and runs of equal keys ---------------------------
-// flag word: low 32 bits count entry heads, high 32 bits count run heads.
-constexpr int SEG_ITEMS = 8;
-constexpr int SEG_TILE = 256 * SEG_ITEMS;
-
-template <typename KeyT>
-__device__ __forceinline__ u64 seg_flag(const KeyT* keys, const uint32_t* vals, u64 i) {
-    if (i == 0) return (1ull << 32) | 1ull;
-    const bool hk = keys[i] != keys[i - 1];
-    const bool hkv = hk || vals[i] != vals[i - 1];
-    return ((u64)hk << 32) | (u64)hkv;
-}
-
-template <typename KeyT>
-__global__ __launch_bounds__(256) void k_seg_reduce(const KeyT* keys, const uint32_t* vals, u64 n, u64* blocksum) {
-    __shared__ u64 tmp[4];
-    const int tid = threadIdx.x;
-    const u64 base = (u64)blockIdx.x * SEG_TILE + (u64)tid * SEG_ITEMS;
-    u64 s = 0;
-#pragma unroll
-    for (int q = 0; q < SEG_ITEMS; ++q)
-        if (base + q < n) s += seg_flag(keys, vals, base + q);
-    u64 tot;
-    block_excl_scan_256<u64>(s, tmp, &tot);
-    if (tid == 0) blocksum[blockIdx.x] = tot;
-}
-
-// single workgroup: exclusive scan of blocksum in place; totals[0]=entries D, totals[1]=runs R;
-// plants the sentinel estart[D] = n.
-__global__ __launch_bounds__(256) void k_seg_scan_blocks(u64* blocksum, uint32_t nblocks, u64 n, uint32_t* totals,
-                                                         uint32_t* estart) {
-    __shared__ u64 tmp[4];
-    const int tid = threadIdx.x;
-    u64 carry = 0;
-    for (uint32_t base = 0; base < nblocks; base += 256) {
-        const uint32_t i = base + (uint32_t)tid;
-        const u64 v = i < nblocks ? blocksum[i] : 0ull;
-        u64 tot;
-        const u64 ex = block_excl_scan_256<u64>(v, tmp, &tot) + carry;
-        if (i < nblocks) blocksum[i] = ex;
-        carry += tot;
-    }
-    if (tid == 0) {
-        const uint32_t D = (uint32_t)(carry & 0xffffffffull);
-        totals[0] = D;
-        totals[1] = (uint32_t)(carry >> 32);
-        estart[D] = (uint32_t)n;
-    }
-}
-
-template <typename KeyT>
-__global__ __launch_bounds__(256) void k_seg_write(const KeyT* keys, const uint32_t* vals, u64 n, const u64* blocksum,
-                                                   uint32_t* estart, uint32_t* eseq, uint32_t* erun, uint32_t* rstart) {
-    __shared__ u64 tmp[4];
-    const int tid = threadIdx.x;
-    const u64 base = (u64)blockIdx.x * SEG_TILE + (u64)tid * SEG_ITEMS;
-    u64 fl[SEG_ITEMS], s = 0;
-#pragma unroll
-    for (int q = 0; q < SEG_ITEMS; ++q) {
-        fl[q] = base + q < n ? seg_flag(keys, vals, base + q) : 0ull;
-        s += fl[q];
-    }
-    u64 ex = block_excl_scan_256<u64>(s, tmp, nullptr) + blocksum[blockIdx.x];
-#pragma unroll
-    for (int q = 0; q < SEG_ITEMS; ++q) {
-        if (fl[q] & 1ull) {  // entry head
-            const uint32_t e = (uint32_t)(ex & 0xffffffffull);
-            const uint32_t hk = (uint32_t)(fl[q] >> 32);
-            const uint32_t run = (uint32_t)(ex >> 32) + hk - 1u;  // runs started up to here, minus 1
-            estart[e] = (uint32_t)(base + q);
-            eseq[e] = vals[base + q];
-            erun[e] = run;
-            if (hk) rstart[run] = e;
-        }
-        ex += fl[q];
-    }
-}
-
-// per (run, pair) atomics: entry e pairs with every earlier entry of its run and itself —
-// exactly the += the reference issues (shared.cpp:316-327). U counts them.
-__global__ __launch_bounds__(256) void k_sparse_pairs(const uint32_t* totals, const uint32_t* estart, const uint32_t* eseq,
-                                                      const uint32_t* erun, const uint32_t* rstart, u64 row0, u64 row1,
-                                                      u64* K, u64* U) {
-    const uint32_t D = totals[0];
-    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
-    const bool active = e < D;
-    u64 work = 0;
-    if (active) {
-        const u64 sa = eseq[e];
-        const u64 ca = estart[e + 1] - estart[e];
-        const uint32_t rs = rstart[erun[e]];
-        for (uint32_t b = rs; b <= e; ++b) {
-            const u64 sb = eseq[b];
-            const u64 cb = estart[b + 1] - estart[b];
-            const u64 i = sa > sb ? sa : sb, j = sa > sb ? sb : sa;
-            if (i >= row0 && i < row1) {  // only the requested band of rows
-                atomicAdd(&K[tri_index(i, j)], ca * cb);
-                ++work;
-            }
-        }
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) work += __shfl_xor(work, d);
-    if ((threadIdx.x & 63) == 0 && work) atomicAdd(U, work);
-}
-
-// ---- owner-slice pair accumulation -----------------------------------------------------------
-// Scattered 64-bit atomics run at the chip's per-request rate (~16 G/s) and the protein configs
-// issue ~450 of them per cell of K over a full run. When a band of `rps` rows of K fits in LDS
-// (rps * N u32 cells), the entries are bucketed by the slice that owns their row (an LDS-
-// privatised counting sort, any order inside a bucket), every slice is owned by ONE workgroup,
-// the (run, pair) updates of a whole batch of combos are summed with LDS atomics, and only the
-// non-zero cells are flushed, row-contiguous, with one 64-bit atomicAdd each.
-constexpr int BK_TILE = 2048;       // entries per bucketing workgroup
-constexpr uint32_t BK_SPLIT = 4;    // an entry with many partners becomes up to this many work records
-constexpr uint32_t BK_CHUNK = 8;    // partners per record (at least)
-// partners per record for an entry with P partners, and the number of records that makes
-__device__ __forceinline__ uint32_t bk_chunk(uint32_t P) {
-    const uint32_t c = (P + BK_SPLIT - 1u) / BK_SPLIT;
-    return c > BK_CHUNK ? c : BK_CHUNK;
-}
-__device__ __forceinline__ uint32_t bk_records(uint32_t P) { return (P + bk_chunk(P) - 1u) / bk_chunk(P); }
-constexpr int BK_MAX_SLICES = 8192; // LDS histogram / cursor size
-
-// pass A: per-workgroup slice histogram -> blockhist[slice][block]; also packs (seq, multiplicity)
-// per entry so that the pair loop fetches a partner with one 8-byte load
-__global__ __launch_bounds__(256) void k_bucket_hist(const uint32_t* totals, const uint32_t* estart, const uint32_t* eseq,
-                                                     const uint32_t* erun, const uint32_t* rstart, uint32_t rps,
-                                                     uint32_t n_slices, uint32_t nblocks, uint32_t* blockhist, uint2* epair) {
-    __shared__ uint32_t h[BK_MAX_SLICES];
-    const uint32_t D = totals[0];
-    const int tid = threadIdx.x;
-    for (uint32_t i = tid; i < n_slices; i += 256) h[i] = 0u;
-    __syncthreads();
-    const uint32_t base = blockIdx.x * BK_TILE;
-    for (int it = 0; it < BK_TILE / 256; ++it) {
-        const uint32_t e = base + (uint32_t)it * 256u + (uint32_t)tid;
-        if (e < D) {
-            const uint32_t sq = eseq[e];
-            const uint32_t P = e - rstart[erun[e]] + 1u;  // partners: earlier entries of the run + itself
-            atomicAdd(&h[sq / rps], bk_records(P));
-            epair[e] = make_uint2(sq, estart[e + 1] - estart[e]);
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < n_slices; i += 256) blockhist[(size_t)i * nblocks + blockIdx.x] = h[i];
-}
-
-// pass C: exclusive scan of the slice totals (single workgroup), slice_off[n_slices] = D
-__global__ __launch_bounds__(256) void k_bucket_scan_totals(const uint32_t* totals_in, uint32_t n_slices, uint32_t* slice_off) {
+// ---- segments --------------------------------------------------------------------------------
+// Inside a slot, record j starts an ENTRY when it differs from record j-1 (new k-mer or new sequence)
+// and a RUN when its k-mer differs; j = 0 starts both. Thread t of a tile looks at SG_ITEMS
+// consecutive records.
+template <typename RecT>
+__global__ __launch_bounds__(256) void k_sx_seg_count(const RecT* rec, uint32_t nfeat, uint32_t tpg, int sb, uint32_t* tile_ent,
+                                                      int* tile_lrh) {
     __shared__ uint32_t tmp[4];
-    const int tid = threadIdx.x;
+    __shared__ int s_lrh;
+    const uint32_t tid = threadIdx.x, t = blockIdx.x, slot = blockIdx.y;
+    const RecT* r = rec + (size_t)slot * nfeat;
+    const uint32_t j0 = t * (uint32_t)SG_TILE + tid * (uint32_t)SG_ITEMS;
+    if (tid == 0) s_lrh = -1;
+    RecT prev = (j0 > 0 && j0 <= nfeat) ? r[j0 - 1] : (RecT)0;
+    uint32_t n = 0;
+    int lrh = -1;  // among this thread's entries, the last one that starts a run
+#pragma unroll
+    for (int q = 0; q < SG_ITEMS; ++q) {
+        const uint32_t j = j0 + (uint32_t)q;
+        if (j < nfeat) {
+            const RecT cur = r[j];
+            if (j == 0 || cur != prev) {
+                if (j == 0 || (cur >> sb) != (prev >> sb)) lrh = (int)n;
+                ++n;
+            }
+            prev = cur;
+        }
+    }
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan_256<uint32_t>(n, tmp, &tot);
+    if (lrh >= 0) atomicMax(&s_lrh, (int)ex + lrh);
+    __syncthreads();
+    if (tid == 0) {
+        tile_ent[(size_t)slot * tpg + t] = tot;
+        tile_lrh[(size_t)slot * tpg + t] = s_lrh;  // tile-local index of the last entry that starts a run, or -1
+    }
+}
+
+// single workgroup: ebase[tile] = entries before the tile (ebase[ntiles] = D); tile_rs[tile] = global
+// index of the last run start before the tile (the run the tile's first entries may continue)
+__global__ __launch_bounds__(256) void k_sx_seg_scan(const uint32_t* tile_ent, const int* tile_lrh, uint32_t ntiles, uint32_t* ebase,
+                                                     int* tile_rs) {
+    __shared__ uint32_t tmp[4];
+    __shared__ int tmpi[4];
+    const uint32_t tid = threadIdx.x;
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < n_slices; base += 256) {
-        const uint32_t i = base + (uint32_t)tid;
-        const uint32_t v = i < n_slices ? totals_in[i] : 0u;
+    int carry_h = -1;
+    for (uint32_t base = 0; base < ntiles; base += 256) {
+        const uint32_t i = base + tid;
+        const uint32_t v = i < ntiles ? tile_ent[i] : 0u;
         uint32_t tot;
         const uint32_t ex = block_excl_scan_256<uint32_t>(v, tmp, &tot) + carry;
-        if (i < n_slices) slice_off[i] = ex;
+        const int lr = i < ntiles ? tile_lrh[i] : -1;
+        const int h = lr >= 0 ? (int)ex + lr : -1;
+        int htot;
+        const int hx = block_excl_maxscan_256(h, tmpi, &htot);
+        if (i < ntiles) {
+            ebase[i] = ex;
+            tile_rs[i] = hx > carry_h ? hx : carry_h;
+        }
         carry += tot;
+        if (htot > carry_h) carry_h = htot;
     }
-    if (tid == 0) slice_off[n_slices] = carry;
+    if (tid == 0) ebase[ntiles] = carry;
 }
 
-// pass D: scatter self-contained work records {seq, multiplicity, first partner, last partner}
-// into the slice's bucket (LDS cursors; the order inside a bucket is free). An entry with many
-// partners is split into up to BK_SPLIT records so that the lanes of the pair kernel carry
-// similar loads. The dependent lookups (run -> run start) are paid here, where thousands of
-// workgroups hide them.
-__global__ __launch_bounds__(256) void k_bucket_scatter(const uint32_t* totals, const uint2* epair, const uint32_t* erun,
-                                                        const uint32_t* rstart, uint32_t rps, uint32_t n_slices,
-                                                        uint32_t nblocks, const uint32_t* blockhist, const uint32_t* slice_off,
-                                                        uint4* list) {
-    __shared__ uint32_t cur[BK_MAX_SLICES];
-    const uint32_t D = totals[0];
-    const int tid = threadIdx.x;
-    for (uint32_t i = tid; i < n_slices; i += 256) cur[i] = slice_off[i] + blockhist[(size_t)i * nblocks + blockIdx.x];
-    __syncthreads();
-    const uint32_t base = blockIdx.x * BK_TILE;
-    for (int it = 0; it < BK_TILE / 256; ++it) {
-        const uint32_t e = base + (uint32_t)it * 256u + (uint32_t)tid;
-        if (e < D) {
-            const uint2 sc = epair[e];
-            const uint32_t rs = rstart[erun[e]];
-            const uint32_t P = e - rs + 1u, ch = bk_chunk(P), nr = bk_records(P);
-            const uint32_t dst = atomicAdd(&cur[sc.x / rps], nr);
-            for (uint32_t q = 0; q < nr; ++q) {  // {seq, multiplicity, first partner, last partner}
-                const uint32_t lo = rs + q * ch, hi = lo + ch - 1u < e ? lo + ch - 1u : e;
-                list[dst + q] = make_uint4(sc.x, sc.y, lo, hi);
+// Owner band of row i: band o holds the rows whose first cell index tri_index(i, 0) lies in
+// [o << own_shift, (o + 1) << own_shift), i.e. owner_r0[o] <= i < owner_r0[o + 1].
+__device__ __forceinline__ uint32_t sx_owner_of(uint32_t seq, int own_shift) {
+    return (uint32_t)(tri_index((u64)seq, 0) >> own_shift);
+}
+// update words one (entry, partner) pair becomes: 1 while multiplicity * max_windows cannot overflow the
+// product field, i.e. multiplicity <= cmax = maxprod / max_windows (everything but extreme
+// low-complexity sequences); beyond that every pair of the entry takes `S` words
+__device__ __forceinline__ uint32_t sx_words_per_pair(uint32_t count, uint32_t cmax, uint32_t max_win, uint32_t maxprod) {
+    if (count <= cmax) return 1u;
+    return (uint32_t)(((u64)count * max_win + maxprod - 1) / maxprod);
+}
+
+// Entries of one tile: E (sequence, multiplicity), Pk (rank in run), and — unless `ucount` is null —
+// the number of update words the tile will emit per owner band, ucount[tile][owner].
+// stats[0] += pairs (the reference's `+=` count U), stats[1] += update words.
+template <typename RecT>
+__global__ __launch_bounds__(256) void k_sx_seg_write(const RecT* rec, uint32_t nfeat, uint32_t tpg, int sb, const uint32_t* ebase,
+                                                      const int* tile_rs, uint2* E, uint32_t* Pk, int own_shift, uint32_t n_owners,
+                                                      uint32_t* ucount, uint32_t row0, uint32_t row1, uint32_t max_win,
+                                                      uint32_t maxprod, uint32_t cmax, u64* tile_stat) {
+    __shared__ uint32_t tmp[4];
+    __shared__ int tmpi[4];
+    __shared__ __attribute__((aligned(8))) uint32_t s_pos[SG_TILE + 2];
+    __shared__ uint2 s_ent[SG_TILE];
+    __shared__ uint32_t s_P[SG_TILE];
+    __shared__ uint32_t s_cnt[SX_MAX_OWNERS];
+    __shared__ uint32_t s_end;
+    const uint32_t tid = threadIdx.x, t = blockIdx.x, slot = blockIdx.y;
+    const uint32_t tile = slot * tpg + t;
+    const RecT* r = rec + (size_t)slot * nfeat;
+    const uint32_t first = t * (uint32_t)SG_TILE;
+    const uint32_t j0 = first + tid * (uint32_t)SG_ITEMS;
+    if (ucount)
+        for (uint32_t i = tid; i < n_owners; i += 256) s_cnt[i] = 0u;
+    RecT cur[SG_ITEMS];
+    uint32_t eh = 0, rh = 0, n = 0;
+    int lrh = -1;
+    {
+        RecT prev = (j0 > 0 && j0 <= nfeat) ? r[j0 - 1] : (RecT)0;
+#pragma unroll
+        for (int q = 0; q < SG_ITEMS; ++q) {
+            const uint32_t j = j0 + (uint32_t)q;
+            cur[q] = j < nfeat ? r[j] : (RecT)0;
+            if (j < nfeat) {
+                if (j == 0 || cur[q] != prev) {
+                    eh |= 1u << q;
+                    if (j == 0 || (cur[q] >> sb) != (prev >> sb)) { rh |= 1u << q; lrh = (int)n; }
+                    ++n;
+                }
+                prev = cur[q];
             }
         }
     }
-}
-
-// One workgroup per slice of `rps` rows: sums every (run, pair) update whose row it owns in LDS,
-// then flushes the non-zero cells. dynamic LDS: rps * N u32. Partners are fetched four at a time
-// so that their loads overlap.
-__global__ __launch_bounds__(256) void k_slice_pairs(const uint32_t* slice_off, const uint4* list, const uint2* epair,
-                                                     uint32_t rps, uint32_t N, uint32_t slice0, u64 row0, u64 row1, u64* K,
-                                                     u64* U) {
-    FSK_DYN_SHARED(uint32_t, sk);
-    const int tid = threadIdx.x;
-    const uint32_t slice = slice0 + blockIdx.x;
-    const uint32_t r_lo = slice * rps;
-    const uint32_t cells = rps * N;
-    for (uint32_t i = tid; i < cells; i += 256) sk[i] = 0u;
-    __syncthreads();
-    const uint32_t lo = slice_off[slice], hi = slice_off[slice + 1];
-    u64 work = 0;
-    for (uint32_t base = lo; base < hi; base += 256) {
-        const uint32_t t = base + (uint32_t)tid;
-        if (t < hi) {
-            const uint4 rec = list[t];  // {seq_a, cnt_a, first partner, last partner}
-            if (rec.x >= row0 && rec.x < row1) {
-                uint32_t* row = sk + (size_t)(rec.x - r_lo) * N;
-                uint32_t b = rec.z;
-                for (; b + 3 <= rec.w; b += 4) {
-                    const uint2 p0 = epair[b], p1 = epair[b + 1], p2 = epair[b + 2], p3 = epair[b + 3];
-                    atomicAdd(&row[p0.x], rec.y * p0.y);  // seq_b <= seq_a
-                    atomicAdd(&row[p1.x], rec.y * p1.y);
-                    atomicAdd(&row[p2.x], rec.y * p2.y);
-                    atomicAdd(&row[p3.x], rec.y * p3.y);
-                }
-                for (; b <= rec.w; ++b) {
-                    const uint2 p = epair[b];
-                    atomicAdd(&row[p.x], rec.y * p.y);
-                }
-                work += (u64)(rec.w - rec.z + 1u);
+    if (tid == 255) {
+        // where the tile's last entry ends: it may run on into the following tiles (bounded by the
+        // number of windows of one sequence); the first look-ahead load rides with the loads above
+        const uint32_t nv = nfeat - first < (uint32_t)SG_TILE ? nfeat - first : (uint32_t)SG_TILE;
+        uint32_t j = first + nv;
+        if (nv == (uint32_t)SG_TILE && j < nfeat && r[j] == cur[SG_ITEMS - 1]) {
+            ++j;
+            while (j < nfeat && r[j] == r[j - 1]) ++j;
+        }
+        s_end = j - first;
+    }
+    uint32_t n_tile;
+    const uint32_t ex = block_excl_scan_256<uint32_t>(n, tmp, &n_tile);
+    // tile-local index of the run start that governs this thread's first entries (-1: before the tile)
+    int head = block_excl_maxscan_256(lrh >= 0 ? (int)ex + lrh : -1, tmpi, nullptr);
+    const uint32_t eb = ebase[tile];
+    const int before = tile_rs[tile];
+    const RecT seq_mask = (RecT)(((u64)1 << sb) - 1);
+    {
+        uint32_t e = ex;
+#pragma unroll
+        for (int q = 0; q < SG_ITEMS; ++q) {
+            if (eh & (1u << q)) {
+                if (rh & (1u << q)) head = (int)e;
+                const uint32_t rs = head >= 0 ? eb + (uint32_t)head : (uint32_t)before;
+                s_pos[e] = tid * (uint32_t)SG_ITEMS + (uint32_t)q;
+                s_P[e] = eb + e - rs + 1u;
+                s_ent[e].x = (uint32_t)(cur[q] & seq_mask);
+                ++e;
             }
         }
     }
     __syncthreads();
-    for (uint32_t i = tid; i < cells; i += 256) {
-        const uint32_t v = sk[i];
-        if (v) {
-            const u64 r = (u64)r_lo + i / N, c = i % N;
-            atomicAdd(&K[tri_index(r, c)], (u64)v);
+    u64 pairs = 0, words = 0;
+    for (uint32_t e = tid; e < n_tile; e += 256) {
+        const uint32_t c = (e + 1 < n_tile ? s_pos[e + 1] : s_end) - s_pos[e];
+        const uint32_t seq = s_ent[e].x, P = s_P[e];
+        E[(size_t)eb + e] = make_uint2(seq, c);
+        Pk[(size_t)eb + e] = P;
+        if (seq >= row0 && seq < row1) {
+            const u64 w = (u64)P * sx_words_per_pair(c, cmax, max_win, maxprod);
+            pairs += P;
+            words += w;
+            if (ucount) atomicAdd(&s_cnt[sx_owner_of(seq, own_shift)], (uint32_t)w);
         }
+    }
+    if (ucount) {
+        __syncthreads();
+        for (uint32_t o = tid; o < n_owners; o += 256) ucount[(size_t)tile * n_owners + o] = s_cnt[o];
+    }
+    // (one record per tile, summed by k_sx_stat_sum: hundreds of thousands of atomics on one address
+    // would serialise at the memory side)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        pairs += __shfl_xor(pairs, d);
+        words += __shfl_xor(words, d);
+    }
+    __syncthreads();  // s_pos is free now
+    u64* red = reinterpret_cast<u64*>(s_pos);
+    if ((tid & 63u) == 0) { red[2 * (tid >> 6)] = pairs; red[2 * (tid >> 6) + 1] = words; }
+    __syncthreads();
+    if (tid == 0) {
+        tile_stat[2 * (size_t)tile] = red[0] + red[2] + red[4] + red[6];
+        tile_stat[2 * (size_t)tile + 1] = red[1] + red[3] + red[5] + red[7];
+    }
+}
+
+// stats[0] += sum of tile_stat[2t], stats[1] += sum of tile_stat[2t + 1]; grid = 32 workgroups
+__global__ __launch_bounds__(256) void k_sx_stat_sum(const u64* tile_stat, uint32_t ntiles, u64* stats) {
+    u64 a = 0, b = 0;
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < ntiles; t += gridDim.x * 256u) {
+        a += tile_stat[2 * (size_t)t];
+        b += tile_stat[2 * (size_t)t + 1];
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) work += __shfl_xor(work, d);
-    if ((tid & 63) == 0 && work) atomicAdd(U, work);
+    for (int d = 32; d >= 1; d >>= 1) {
+        a += __shfl_xor(a, d);
+        b += __shfl_xor(b, d);
+    }
+    if ((threadIdx.x & 63u) == 0 && (a | b)) {
+        atomicAdd(&stats[0], a);
+        atomicAdd(&stats[1], b);
+    }
+}
+
+// ---- offsets of the update streams: column scan of ucount[tile][owner] -----------------------
+constexpr int UC_CHUNK = 64;  // tiles per chunk
+// chunk_tot[chunk][owner] = words of the chunk's tiles for the owner; grid = chunks
+__global__ __launch_bounds__(256) void k_sx_ucol_sum(const uint32_t* ucount, uint32_t ntiles, uint32_t n_owners, uint32_t* chunk_tot) {
+    const uint32_t chunk = blockIdx.x, t0 = chunk * (uint32_t)UC_CHUNK;
+    const uint32_t t1 = t0 + UC_CHUNK < ntiles ? t0 + UC_CHUNK : ntiles;
+    for (uint32_t o = threadIdx.x; o < n_owners; o += 256) {
+        uint32_t s = 0;
+#pragma unroll 8
+        for (uint32_t t = t0; t < t1; ++t) s += ucount[(size_t)t * n_owners + o];
+        chunk_tot[(size_t)chunk * n_owners + o] = s;
+    }
+}
+// per owner: exclusive scan over the chunks in place, owner total to utot; grid = ceil(owners / 256)
+__global__ __launch_bounds__(256) void k_sx_ucol_scan(uint32_t* chunk_tot, uint32_t nchunks, uint32_t n_owners, uint32_t* utot) {
+    const uint32_t o = blockIdx.x * 256u + threadIdx.x;
+    if (o >= n_owners) return;
+    uint32_t run = 0;
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        const uint32_t v = chunk_tot[(size_t)c * n_owners + o];
+        chunk_tot[(size_t)c * n_owners + o] = run;
+        run += v;
+    }
+    utot[o] = run;
+}
+// ucount[tile][owner] -> words of the owner emitted by earlier tiles; grid = chunks
+__global__ __launch_bounds__(256) void k_sx_ucol_apply(uint32_t* ucount, uint32_t ntiles, uint32_t n_owners, const uint32_t* chunk_tot) {
+    const uint32_t chunk = blockIdx.x, t0 = chunk * (uint32_t)UC_CHUNK;
+    const uint32_t t1 = t0 + UC_CHUNK < ntiles ? t0 + UC_CHUNK : ntiles;
+    for (uint32_t o = threadIdx.x; o < n_owners; o += 256) {
+        uint32_t run = chunk_tot[(size_t)chunk * n_owners + o];
+        for (uint32_t t = t0; t < t1; ++t) {
+            const uint32_t v = ucount[(size_t)t * n_owners + o];
+            ucount[(size_t)t * n_owners + o] = run;
+            run += v;
+        }
+    }
+}
+
+// ---- pair updates ----------------------------------------------------------------------------
+// Entry e = (i, c) with rank P in its run pairs with entries e-P+1 .. e = (j <= i, c_j): K[i][j] += c * c_j.
+// Update word = (cell - first cell of the owner band) << pb | product, cell = tri_index(i, j).
+// One workgroup of 512 threads per entry tile (the entries one k_sx_seg_write tile produced).
+// DIRECT: 64-bit atomicAdd per pair straight into K instead of update words.
+constexpr int EM_THREADS = 512, EM_WAVES = EM_THREADS / 64;
+constexpr uint32_t EM_STAGE = (uint32_t)EM_THREADS * SX_SHORT;  // one short entry per thread and round
+template <bool DIRECT>
+__global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const uint32_t* Pk, const uint32_t* ebase,
+                                                        const uint32_t* owner_r0, int own_shift, uint32_t n_owners,
+                                                        const uint32_t* list_off, const uint32_t* tile_off, uint32_t* list,
+                                                        uint32_t row0, uint32_t row1, uint32_t max_win, uint32_t maxprod,
+                                                        uint32_t cmax, int pb, u64* K) {
+    __shared__ uint2 s_ent[SG_TILE];
+    __shared__ uint32_t s_P[SG_TILE];
+    __shared__ uint32_t s_r0[SX_MAX_OWNERS + 1];
+    __shared__ uint32_t s_cur[SX_MAX_OWNERS];   // next free word of this tile's share of each owner's stream
+    __shared__ uint32_t s_cnt[SX_MAX_OWNERS];
+    __shared__ uint32_t s_seg[SX_MAX_OWNERS];
+    __shared__ uint32_t stage_w[EM_STAGE];
+    __shared__ uint16_t stage_o[EM_STAGE];
+    __shared__ uint16_t s_long[SG_TILE];
+    __shared__ uint32_t s_nlong, s_total;
+    __shared__ uint32_t tmp[EM_WAVES];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t e0 = ebase[tile], n = ebase[tile + 1] - e0;
+    if (!DIRECT) {
+        for (uint32_t i = tid; i <= n_owners; i += EM_THREADS) s_r0[i] = owner_r0[i];
+        for (uint32_t o = tid; o < n_owners; o += EM_THREADS) s_cur[o] = list_off[o] + tile_off[(size_t)tile * n_owners + o];
+    }
+    for (uint32_t e = tid; e < n; e += EM_THREADS) {
+        s_ent[e] = E[(size_t)e0 + e];
+        s_P[e] = Pk[(size_t)e0 + e];
+    }
+    if (tid == 0) s_nlong = 0u;
+    __syncthreads();
+    // partner `ge` of an entry: the tile's own entries sit in LDS, a run that started before the tile
+    // continues in global memory
+#define SX_PARTNER(ge) ((ge) >= e0 ? s_ent[(ge) - e0] : E[(ge)])
+    // entries with many partners (or a product that needs several words): one wave each, below
+    for (uint32_t e = tid; e < n; e += EM_THREADS) {
+        const uint2 a = s_ent[e];
+        if (a.x >= row0 && a.x < row1 && (s_P[e] > SX_SHORT || (!DIRECT && sx_words_per_pair(a.y, cmax, max_win, maxprod) > 1u)))
+            s_long[atomicAdd(&s_nlong, 1u)] = (uint16_t)e;
+    }
+    // ---- short entries, one per thread and round
+    for (uint32_t rb = 0; rb < n; rb += EM_THREADS) {
+        const uint32_t e = rb + tid;
+        bool mine = false;
+        uint2 a = make_uint2(0u, 0u);
+        uint32_t P = 0, my_o = 0, my_pos = 0;
+        if (e < n) {
+            a = s_ent[e];
+            P = s_P[e];
+            mine = a.x >= row0 && a.x < row1 && P <= SX_SHORT && (DIRECT || sx_words_per_pair(a.y, cmax, max_win, maxprod) == 1u);
+        }
+        if (DIRECT) {
+            if (mine) {
+                u64* row = K + tri_index((u64)a.x, 0);
+                for (uint32_t b = 0; b < P; ++b) {
+                    const uint2 pq = SX_PARTNER(e0 + e - P + 1u + b);
+                    atomicAdd(&row[pq.x], (u64)a.y * pq.y);
+                }
+            }
+            continue;
+        }
+        for (uint32_t o = tid; o < n_owners; o += EM_THREADS) s_cnt[o] = 0u;
+        __syncthreads();
+        if (mine) {
+            my_o = sx_owner_of(a.x, own_shift);
+            my_pos = atomicAdd(&s_cnt[my_o], P);
+        }
+        __syncthreads();
+        {   // exclusive scan of the owner counts (n_owners <= 512 = one per thread)
+            const uint32_t v = tid < n_owners ? s_cnt[tid] : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<uint32_t, EM_WAVES>(v, tmp, &tot);
+            if (tid < n_owners) s_seg[tid] = ex;
+            if (tid == 0) s_total = tot;
+        }
+        __syncthreads();
+        if (mine) {
+            const uint32_t cbase = (uint32_t)(tri_index((u64)a.x, 0) - tri_index((u64)s_r0[my_o], 0));
+            const uint32_t at = s_seg[my_o] + my_pos;
+            for (uint32_t b = 0; b < P; ++b) {
+                const uint2 pq = SX_PARTNER(e0 + e - P + 1u + b);
+                stage_w[at + b] = ((cbase + pq.x) << pb) | (a.y * pq.y);
+                stage_o[at + b] = (uint16_t)my_o;
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < s_total; i += EM_THREADS) {  // owner-sorted: neighbours go to neighbouring addresses
+            const uint32_t o = stage_o[i];
+            list[s_cur[o] + (i - s_seg[o])] = stage_w[i];
+        }
+        __syncthreads();
+        if (tid < n_owners) s_cur[tid] += s_cnt[tid];
+        // (the barriers of the next round, or the one below, order this against its readers)
+    }
+    __syncthreads();
+    // ---- long entries: the lanes of a wave take the partners, the words of an entry are contiguous
+    const uint32_t nlong = s_nlong;
+    for (uint32_t q = wave; q < nlong; q += EM_WAVES) {
+        const uint32_t e = s_long[q];
+        const uint2 a = s_ent[e];
+        const uint32_t P = s_P[e];
+        if (DIRECT) {
+            u64* row = K + tri_index((u64)a.x, 0);
+            for (uint32_t b = lane; b < P; b += 64) {
+                const uint2 pq = SX_PARTNER(e0 + e - P + 1u + b);
+                atomicAdd(&row[pq.x], (u64)a.y * pq.y);
+            }
+        } else {
+            const uint32_t S = sx_words_per_pair(a.y, cmax, max_win, maxprod);
+            const uint32_t o = sx_owner_of(a.x, own_shift);
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(&s_cur[o], P * S);
+            at = __shfl(at, 0);
+            const uint32_t cbase = (uint32_t)(tri_index((u64)a.x, 0) - tri_index((u64)s_r0[o], 0));
+            const uint32_t trips = (P + 63u) / 64u;  // same for every lane: the shuffle above needs all of them
+            for (uint32_t tr = 0; tr < trips; ++tr) {
+                const uint32_t b = tr * 64u + lane;
+                if (b < P) {
+                    const uint2 pq = SX_PARTNER(e0 + e - P + 1u + b);
+                    u64 prod = (u64)a.y * pq.y;
+                    for (uint32_t w = 0; w < S; ++w) {
+                        const uint32_t part = prod < maxprod ? (uint32_t)prod : maxprod;
+                        list[at + b * S + w] = ((cbase + pq.x) << pb) | part;
+                        prod -= part;
+                    }
+                }
+            }
+        }
+    }
+#undef SX_PARTNER
+}
+
+// Streams differ a lot in length (a band that holds a long or low-complexity sequence receives many
+// times the average), so a stream is cut into parts of about `target` words, one workgroup each:
+// part_base[o] = parts of the bands before o (single workgroup of 512 threads, n_owners <= 512).
+__global__ __launch_bounds__(512) void k_sx_parts(const uint32_t* list_off, uint32_t n_owners, uint32_t target, uint32_t* part_base) {
+    __shared__ uint32_t tmp[8];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t len = tid < n_owners ? list_off[tid + 1] - list_off[tid] : 0u;
+    const uint32_t parts = (len + target - 1u) / target;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan<uint32_t, 8>(parts, tmp, &tot);
+    if (tid < n_owners) part_base[tid] = ex;
+    if (tid == 0) part_base[n_owners] = tot;
+}
+
+// One workgroup of 1024 threads per (part of an owner band's stream, round): sums its words into `cap`
+// u32 cells in LDS and adds the non-zero ones into K — a plain read-modify-write when the band has a
+// single part (a cell then has one writer and launches are ordered on the stream), 64-bit atomics
+// otherwise. A band larger than `cap` cells takes several rounds over its stream.
+// dynamic LDS: cap * 4 bytes. grid = (upper bound of the number of parts, rounds)
+constexpr uint32_t CS_THREADS = 1024;
+__global__ __launch_bounds__(1024) void k_sx_consume(const uint32_t* list, const uint32_t* list_off, const uint32_t* owner_r0,
+                                                     const uint32_t* part_base, uint32_t n_owners, uint32_t target, uint32_t cap,
+                                                     int pb, u64* K) {
+    FSK_DYN_SHARED(uint32_t, cells);
+    __shared__ uint32_t s_base[SX_MAX_OWNERS + 1];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i <= n_owners; i += CS_THREADS) s_base[i] = part_base[i];
+    __syncthreads();
+    const uint32_t slot = blockIdx.x, r = blockIdx.y;
+    if (slot >= s_base[n_owners]) return;
+    uint32_t o = 0, hi = n_owners;  // s_base[o] <= slot < s_base[hi]; bands without words share their successor's base
+    while (hi - o > 1u) {
+        const uint32_t mid = (o + hi) >> 1;
+        if (s_base[mid] <= slot) o = mid; else hi = mid;
+    }
+    const uint32_t part = slot - s_base[o], nparts = s_base[o + 1] - s_base[o];
+    const u64 c0 = tri_index((u64)owner_r0[o], 0), c1 = tri_index((u64)owner_r0[o + 1], 0);
+    const uint32_t ncell = (uint32_t)(c1 - c0);
+    const uint32_t lo = r * cap;
+    if (lo >= ncell) return;
+    const uint32_t span = ncell - lo < cap ? ncell - lo : cap;
+    const uint32_t a = list_off[o] + part * target;
+    const uint32_t end = list_off[o + 1];
+    const uint32_t b = end - a < target ? end : a + target;
+    for (uint32_t i = tid; i < span; i += CS_THREADS) cells[i] = 0u;
+    __syncthreads();
+    const uint32_t mask = (1u << pb) - 1u;
+    uint32_t i = a + tid;
+    for (; i + 3u * CS_THREADS < b; i += 4u * CS_THREADS) {  // four independent loads in flight per thread
+        const uint32_t w0 = list[i], w1 = list[i + CS_THREADS], w2 = list[i + 2u * CS_THREADS], w3 = list[i + 3u * CS_THREADS];
+        const uint32_t x0 = (w0 >> pb) - lo, x1 = (w1 >> pb) - lo, x2 = (w2 >> pb) - lo, x3 = (w3 >> pb) - lo;
+        if (x0 < span) atomicAdd(&cells[x0], w0 & mask);
+        if (x1 < span) atomicAdd(&cells[x1], w1 & mask);
+        if (x2 < span) atomicAdd(&cells[x2], w2 & mask);
+        if (x3 < span) atomicAdd(&cells[x3], w3 & mask);
+    }
+    for (; i < b; i += CS_THREADS) {
+        const uint32_t w = list[i];
+        const uint32_t x = (w >> pb) - lo;
+        if (x < span) atomicAdd(&cells[x], w & mask);
+    }
+    __syncthreads();
+    u64* dst = K + c0 + lo;
+    if (nparts == 1u) {
+        for (uint32_t c = tid; c < span; c += CS_THREADS) {
+            const uint32_t v = cells[c];
+            if (v) dst[c] += (u64)v;
+        }
+    } else {
+        for (uint32_t c = tid; c < span; c += CS_THREADS) {
+            const uint32_t v = cells[c];
+            if (v) atomicAdd(&dst[c], (u64)v);
+        }
+    }
 }
 
 // =============================================================================================

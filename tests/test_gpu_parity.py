@@ -176,9 +176,46 @@ def test_low_complexity_counts_above_255(native, port):
         e.close()
 
 
+def diag_by_definition(X, rows, g, m):
+    """K_ii = sum over combos and k-mers v of cnt_i(combo, v)^2, straight from the definition
+    (SURVEY section 0), for the given rows of a fixed-length token matrix with tokens 1..4."""
+    import itertools
+    S = (X[rows] - 1).astype(np.int64)
+    n, L = S.shape
+    W, k = L - g + 1, g - m
+    out = np.zeros(n, dtype=np.uint64)
+    base = np.arange(n, dtype=np.int64)[:, None] * (4 ** k)
+    for pos in itertools.combinations(range(g), k):
+        key = np.zeros((n, W), dtype=np.int64)
+        for p in pos:
+            key = key * 4 + S[:, p:p + W]
+        cnt = np.bincount((key + base).ravel(), minlength=n * 4 ** k).reshape(n, 4 ** k)
+        out += (cnt.astype(np.uint64) ** 2).sum(axis=1)
+    return out
+
+
+def check_random_subset(native, port, e, X, g, m, n_sub, seed, threads):
+    """Sub-block property on a RANDOM subset of sequences: the oracle run on just those sequences
+    must equal, cell for cell, the corresponding scattered cells of the big triangle — touches
+    essentially every tile row and column."""
+    N = X.shape[0]
+    rng = np.random.Generator(np.random.PCG64(seed))
+    idx = np.sort(rng.choice(N, size=n_sub, replace=False))
+    st, so = native.flatten(X[idx])
+    ncomb = native.library().num_combos(g, m)
+    want, _, _ = port.raw_counts(st, so, g, m, np.arange(ncomb), threads=threads)
+    a, b = np.tril_indices(n_sub)
+    got = e.get_counts_cells(idx[a], idx[b])
+    assert np.array_equal(got, want)
+    # the same cells asked for transposed (column > row) are the same cells
+    assert np.array_equal(e.get_counts_cells(idx[b][:5000], idx[a][:5000]), want[:5000])
+    return idx
+
+
 def test_config5_shape_mid_size_sub_blocks(native, port):
-    """N = 16384 x 300 DNA, g=12 m=8, all 495 combos: sub-blocks against the oracle run on just
-    those sequences (sub-block property), plus structural invariants."""
+    """N = 16384 x 300 DNA, g=12 m=8, all 495 combos: sub-blocks and a random 1200-sequence subset
+    against the oracle run on just those sequences (sub-block property), diagonals from the
+    definition, plus structural invariants."""
     N, L, g, m = 16384, 300, 12, 8
     tokens, offsets = synthetic_dna(N, L)
     e = native.Engine(g, m)
@@ -187,6 +224,7 @@ def test_config5_shape_mid_size_sub_blocks(native, port):
     e.finalize()
     assert e.stats()["path_used"] == 1
     X = tokens.reshape(N, L)
+    threads = min(32, os.cpu_count() or 8)
     for (a0, a1), (b0, b1) in [((0, 96), (0, 96)), ((16300, 16384), (37, 101)), ((8190, 8260), (8100, 8200))]:
         idx = np.concatenate([np.arange(b0, b1), np.arange(a0, a1)])
         idx = np.unique(idx)
@@ -202,6 +240,9 @@ def test_config5_shape_mid_size_sub_blocks(native, port):
         gotn = e.get_block(a0, a1, b0, b1)
         off = ra[:, None] != rb[None, :]
         assert np.array_equal(gotn[off], wantn[np.ix_(ra, rb)][off])
+    check_random_subset(native, port, e, X, g, m, 1200, seed=16384, threads=threads)
+    rows = np.sort(np.random.Generator(np.random.PCG64(7)).choice(N, size=2000, replace=False))
+    assert np.array_equal(e.get_counts_cells(rows, rows), diag_by_definition(X, rows, g, m))
     diag = e.get_counts_block(5000, 5001, 5000, 5001)[0, 0]
     assert diag >= 495 * (L - g + 1)
     blk = e.get_block(100, 228, 100, 228)
@@ -210,37 +251,117 @@ def test_config5_shape_mid_size_sub_blocks(native, port):
 
 
 def test_config5_full_size_100k(native, port):
-    """BASELINE config 5 at full size (100k x 300, 495 combos) on one GPU: parity through the
-    sub-block property on three blocks spread over the triangle + invariants."""
+    """BASELINE config 5 at full size (100k x 300, 495 combos) on one GPU, in BOTH forms the product
+    runs it: one un-banded launch after fsk_reset_counts (the storing flush bench.py times) and the
+    row-banded form of the multi-GPU path. The two 5*10^9-cell triangles must be identical on the
+    device; a random 1500-sequence subset (1.1 M scattered cells over every tile row and column,
+    including rows beyond 46,340 where the reference's int index overflows, shared.cpp:97-117) must
+    equal the oracle run on just those sequences; 4000 random diagonals must equal the definition."""
     import torch
     free, total = torch.cuda.mem_get_info()
-    if total < 100e9:
-        pytest.skip("needs ~60 GB of HBM")
+    if free < 100e9:
+        pytest.skip("needs ~85 GB of free HBM (two 40 GB triangles)")
     N, L, g, m = 100000, 300, 12, 8
     tokens, offsets = synthetic_dna(N, L)
+    X = tokens.reshape(N, L)
     from fastsk_amd.distributed import band_edges
+    pairs = N * (N + 1) // 2
+    K = torch.zeros(pairs, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
     e = native.Engine(g, m)
+    e.bind_counts(K.data_ptr(), pairs, keepalive=K)
     e.load_sequences(tokens, offsets, N, 0)
     combos = np.arange(495, dtype=np.int32)
-    edges = band_edges(N, 4)  # the row-band form the multi-GPU path uses (panels counted once)
-    for lo, hi in zip(edges[:-1], edges[1:]):
-        e.accumulate_rows(combos, lo, hi)
+    # ---- form 1: exactly bench.py's step
+    e.reset_counts()
+    e.accumulate(combos)
+    e.synchronize()
     e.finalize()
     st = e.stats()
-    assert st["count_launches"] == 1 and st["n_tile_launches"] == len(edges) - 1 and st["combos_done"] == 495
-    X = tokens.reshape(N, L)
-    for (a0, a1), (b0, b1) in [((99936, 100000), (0, 64)), ((46300, 46400), (46290, 46360)), ((70000, 70064), (12345, 12409)),
-                               ((edges[1] - 40, edges[1] + 40), (edges[1] - 60, edges[1] + 10))]:
-        idx = np.unique(np.concatenate([np.arange(b0, b1), np.arange(a0, a1)]))
-        st, so = native.flatten(X[idx])
-        want, _, _ = port.raw_counts(st, so, g, m, np.arange(495), threads=8)
-        sq = tri_to_square(want, len(idx))
-        ra = np.searchsorted(idx, np.arange(a0, a1))
-        rb = np.searchsorted(idx, np.arange(b0, b1))
-        assert np.array_equal(e.get_counts_block(a0, a1, b0, b1), sq[np.ix_(ra, rb)])
+    assert st["count_launches"] == 1 and st["n_tile_launches"] == 1 and st["combos_done"] == 495
+    threads = min(64, os.cpu_count() or 8)
+    idx = check_random_subset(native, port, e, X, g, m, 1500, seed=100000, threads=threads)
+    assert idx.max() > 46340 and idx.min() < 2000
+    rows = np.sort(np.random.Generator(np.random.PCG64(11)).choice(N, size=4000, replace=False))
+    assert np.array_equal(e.get_counts_cells(rows, rows), diag_by_definition(X, rows, g, m))
     blk = e.get_block(99900, 100000, 99900, 100000)
     assert np.array_equal(blk, blk.T) and np.all(np.diag(blk) == 1.0)
+    K1 = K.clone()
+    torch.cuda.synchronize()
+    # ---- form 2: row bands (panels counted once, one launch per band)
+    edges = band_edges(N, 4)
+    e.reset_counts()
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        e.accumulate_rows(combos, lo, hi)
+    e.synchronize()
+    e.finalize()
+    st = e.stats()
+    assert st["count_launches"] == 2 and st["n_tile_launches"] == 1 + len(edges) - 1 and st["combos_done"] == 495
+    step = 1 << 29
+    for c0 in range(0, pairs, step):
+        assert bool(torch.equal(K[c0:c0 + step], K1[c0:c0 + step])), "banded and un-banded triangles differ in cells %d.." % c0
+    # a contiguous block that straddles a band edge, against the oracle
+    (a0, a1), (b0, b1) = (edges[1] - 40, edges[1] + 40), (edges[1] - 60, edges[1] + 10)
+    sub = np.unique(np.concatenate([np.arange(b0, b1), np.arange(a0, a1)]))
+    st_, so_ = native.flatten(X[sub])
+    want, _, _ = port.raw_counts(st_, so_, g, m, np.arange(495), threads=8)
+    sq = tri_to_square(want, len(sub))
+    ra, rb = np.searchsorted(sub, np.arange(a0, a1)), np.searchsorted(sub, np.arange(b0, b1))
+    assert np.array_equal(e.get_counts_block(a0, a1, b0, b1), sq[np.ix_(ra, rb)])
     e.close()
+
+
+def protein_like(N, lo, hi, seed, sigma=20):
+    """Ragged sequences over `sigma` letters with a skewed composition and shared motifs, so that the
+    k-mer runs have the short-with-a-heavy-tail length distribution of real protein sets."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    p = 1.0 / np.arange(1, sigma + 1) ** 0.7
+    p /= p.sum()
+    lens = rng.integers(lo, hi, size=N)
+    motifs = [rng.choice(sigma, size=24, p=p) + 1 for _ in range(40)]
+    X = []
+    for L in lens:
+        x = rng.choice(sigma, size=int(L), p=p) + 1
+        if rng.random() < 0.5:
+            mtf = motifs[int(rng.integers(len(motifs)))]
+            a = int(rng.integers(0, L - 24))
+            x[a:a + 24] = mtf
+        X.append(x.astype(np.int32))
+    return X
+
+
+@pytest.mark.parametrize("N,lo,hi,ncombo,n_sub", [(12000, 60, 220, 24, 700), (24000, 30, 60, 6, 900)])
+def test_sparse_dataflow_large_n(native, port, N, lo, hi, ncombo, n_sub):
+    """The sparse (sort -> segments -> pair updates) dataflow beyond N = 8192: at 12,000 sequences a
+    band of K takes several LDS rounds over its update stream; at 24,000 no band fits and every pair
+    goes to K with a 64-bit atomic. Random-subset sub-block property against the oracle + U."""
+    g, m = 10, 6
+    X = protein_like(N, lo, hi, seed=N)
+    tokens, offsets = native.flatten(X)
+    combos = np.arange(0, 210, 210 // ncombo, dtype=np.int32)[:ncombo]
+    e = native.Engine(g, m, path=2, profile=True)
+    e.load_sequences(tokens, offsets, N, 0)
+    e.accumulate(combos)
+    e.finalize()
+    st = e.stats()
+    assert st["path_used"] == 2 and st["combos_done"] == ncombo
+    rng = np.random.Generator(np.random.PCG64(5))
+    idx = np.sort(rng.choice(N, size=n_sub, replace=False))
+    stoks, soff = native.flatten([X[i] for i in idx])
+    want, _, _ = port.raw_counts(stoks, soff, g, m, combos, threads=min(32, os.cpu_count() or 8))
+    a, b = np.tril_indices(n_sub)
+    assert np.array_equal(e.get_counts_cells(idx[a], idx[b]), want)
+    # U of the whole run from the definition: sum over (combo, k-mer) of d(d+1)/2, on a slice the oracle can do
+    sub = native.Engine(g, m, path=2)
+    sub.load_sequences(stoks, soff, n_sub, 0)
+    sub.accumulate(combos)
+    sub.finalize()
+    _, _, U = port.raw_counts(stoks, soff, g, m, combos, threads=8)
+    assert sub.stats()["cell_updates"] == U
+    blk = e.get_block(N - 100, N, N - 100, N)
+    assert np.array_equal(blk, blk.T) and np.all(np.diag(blk) == 1.0)
+    e.close()
+    sub.close()
 
 
 def test_pybind_surface_on_gpu(native):

@@ -40,7 +40,7 @@ def main():
             if not profile:
                 wall = dt
         # algorithmic bytes of the direct-atomic dataflow, 16*U + 16*P*nfeat + packed input per combo
-        P = max(1, (d["g"] - d["m"]) * st["bits_per_symbol"] + 7) // 8
+        P = (max(1, int(np.ceil(np.log2(max(2, st["key_space"]))))) + 7) // 8  # 8-bit LSD passes over the packed k-mer
         alg = 16.0 * st["cell_updates"] + st["combos_done"] * (16.0 * P * st["n_feat"] + st["n_feat"] * st["bits_per_symbol"] / 8.0)
         rows.append(dict(case=name, N=ntr + nte, combos=int(st["combos_done"]), gpu_seconds=wall,
                          algorithmic_GB=round(alg / 1e9, 2), algorithmic_GB_per_s=round(alg / 1e9 / wall, 1),
