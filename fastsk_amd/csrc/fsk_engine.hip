@@ -379,11 +379,10 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     FSK_HIP(hipStreamSynchronize(e->stream));  // `pos` is a pageable temporary
 
     RecT* rec[2] = {(RecT*)e->d_keys[0].p, (RecT*)e->d_keys[1].p};
-    const uint32_t fblocks = (nfeat + 255) / 256;
 
     e->tic();
-    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_extract<RecT>), dim3(fblocks, nb), dim3(256), 0, e->stream, e->view(), e->d_featseq.p,
-               e->d_fstart.p, nfeat, e->k, e->sigma, sb, e->d_pos.p, rec[0]);
+    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_extract<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, e->view(), e->d_featseq.p,
+               e->d_fstart.p, nfeat, tps, e->k, e->sigma, sb, e->d_pos.p, rec[0], e->d_blockhist.p);
     e->toc(&e->st.ms_extract);
     e->st.launches += 1;
 
@@ -391,8 +390,9 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     int cur = 0;
     for (int p = 0; p < passes; ++p) {
         const int shift = sb + 8 * p;
-        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_hist<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tps, shift,
-                   e->d_blockhist.p);
+        if (p > 0)  // (the extraction counted the first pass's digits)
+            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_hist<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tps, shift,
+                       e->d_blockhist.p);
         FSK_LAUNCH(fsk::k_sx_scan_slot, dim3(nb), dim3(256), 0, e->stream, e->d_blockhist.p, tps, e->d_totals.p);
         FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_scatter<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, rec[cur], rec[cur ^ 1], nfeat,
                    tps, shift, e->d_blockhist.p, e->d_totals.p);
@@ -418,7 +418,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     u64 words = 0;
     if (lists) {  // where every (tile, owner) share of the update streams starts
         FSK_LAUNCH(fsk::k_sx_ucol_sum, dim3(nchunks), dim3(256), 0, e->stream, (const uint32_t*)e->d_ucount.p, ntiles, O, e->d_uchunk.p);
-        FSK_LAUNCH(fsk::k_sx_ucol_scan, dim3((O + 255) / 256), dim3(256), 0, e->stream, e->d_uchunk.p, nchunks, O, e->d_utot.p);
+        FSK_LAUNCH(fsk::k_sx_ucol_scan, dim3(O), dim3(256), 0, e->stream, e->d_uchunk.p, nchunks, O, e->d_utot.p);
         FSK_LAUNCH(fsk::k_scan_totals, dim3(1), dim3(256), 0, e->stream, (const uint32_t*)e->d_utot.p, O, e->d_list_off.p);
         FSK_LAUNCH(fsk::k_sx_ucol_apply, dim3(nchunks), dim3(256), 0, e->stream, e->d_ucount.p, ntiles, O, (const uint32_t*)e->d_uchunk.p);
         e->st.launches += 4;

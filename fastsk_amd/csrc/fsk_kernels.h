@@ -441,7 +441,7 @@ constexpr int SX_ITEMS = SX_TILE / 256;
 constexpr int SG_TILE = 2048;           // records per segment tile = most entries one emit workgroup holds
 constexpr int SG_ITEMS = SG_TILE / 256;
 constexpr int SX_MAX_OWNERS = 512;      // owner bands of K (bins of the update streams)
-constexpr uint32_t SX_SHORT = 8;        // entries with up to this many partners are staged in LDS
+constexpr uint32_t SX_SHORT = 16;       // entries with up to this many partners are binned by owner in LDS
 
 // block-wide exclusive running maximum of one int per thread (256 threads); identity = -1 (all
 // values are >= -1). Every thread of the block must call it.
@@ -469,20 +469,35 @@ __device__ __forceinline__ int block_excl_maxscan_256(int v, int* tmp, int* tota
     return base > prev ? base : prev;
 }
 
-// rec = (k-mer << sb) | sequence id, one per (slot, g-mer); grid = (ceil(nfeat/256), slots)
+// rec = (k-mer << sb) | sequence id, one per (slot, g-mer), and the first sort pass's digit histogram
+// of the tile (blockhist[slot][tile][digit], digit = bits sb..sb+7); grid = (sort tiles per slot, slots)
 template <typename RecT>
-__global__ __launch_bounds__(256) void k_sx_extract(SeqView S, const uint32_t* feat_seq, const uint32_t* fstart, uint32_t nfeat, int k,
-                                                    uint32_t sigma, int sb, const uint8_t* combo_pos, RecT* rec) {
-    const uint32_t f = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t slot = blockIdx.y;
-    if (f >= nfeat) return;
-    const uint32_t seq = feat_seq[f];
-    const uint32_t j = f - fstart[seq];
-    const uint32_t wbase = S.wstart[seq];
-    const uint8_t* pos = combo_pos + (size_t)slot * k;
-    u64 key = 0;
-    for (int c = 0; c < k; ++c) key = key * sigma + fetch_sym(S.words, wbase, j + pos[c], S.bits);
-    rec[(size_t)slot * nfeat + f] = (RecT)((key << sb) | (u64)seq);
+__global__ __launch_bounds__(256) void k_sx_extract(SeqView S, const uint32_t* feat_seq, const uint32_t* fstart, uint32_t nfeat, uint32_t tps,
+                                                    int k, uint32_t sigma, int sb, const uint8_t* combo_pos, RecT* rec,
+                                                    uint32_t* blockhist) {
+    __shared__ uint32_t h[256];
+    __shared__ uint8_t s_pos[16];
+    const uint32_t tid = threadIdx.x, tile = blockIdx.x, slot = blockIdx.y;
+    h[tid] = 0u;
+    if (tid < 16u) s_pos[tid] = (int)tid < k ? combo_pos[(size_t)slot * k + tid] : (uint8_t)0;
+    __syncthreads();
+    const uint8_t* pos = k <= 16 ? s_pos : combo_pos + (size_t)slot * k;
+    const uint32_t base = tile * (uint32_t)SX_TILE;
+#pragma unroll 4
+    for (int it = 0; it < SX_ITEMS; ++it) {
+        const uint32_t f = base + (uint32_t)it * 256u + tid;
+        if (f < nfeat) {
+            const uint32_t seq = feat_seq[f];
+            const uint32_t j = f - fstart[seq];
+            const uint32_t wbase = S.wstart[seq];
+            u64 key = 0;
+            for (int c = 0; c < k; ++c) key = key * sigma + fetch_sym(S.words, wbase, j + pos[c], S.bits);
+            rec[(size_t)slot * nfeat + f] = (RecT)((key << sb) | (u64)seq);
+            atomicAdd(&h[(uint32_t)key & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    blockhist[((size_t)slot * tps + tile) * 256u + tid] = h[tid];
 }
 
 // digit histogram of one tile of one slot -> blockhist[slot][tile][digit]; grid = (tiles per slot, slots)
@@ -870,17 +885,20 @@ __global__ __launch_bounds__(256) void k_sx_ucol_sum(const uint32_t* ucount, uin
         chunk_tot[(size_t)chunk * n_owners + o] = s;
     }
 }
-// per owner: exclusive scan over the chunks in place, owner total to utot; grid = ceil(owners / 256)
+// per owner: exclusive scan over the chunks in place, owner total to utot; grid = owners
 __global__ __launch_bounds__(256) void k_sx_ucol_scan(uint32_t* chunk_tot, uint32_t nchunks, uint32_t n_owners, uint32_t* utot) {
-    const uint32_t o = blockIdx.x * 256u + threadIdx.x;
-    if (o >= n_owners) return;
-    uint32_t run = 0;
-    for (uint32_t c = 0; c < nchunks; ++c) {
-        const uint32_t v = chunk_tot[(size_t)c * n_owners + o];
-        chunk_tot[(size_t)c * n_owners + o] = run;
-        run += v;
+    __shared__ uint32_t tmp[4];
+    const uint32_t o = blockIdx.x, tid = threadIdx.x;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nchunks; base += 256) {
+        const uint32_t c = base + tid;
+        const uint32_t v = c < nchunks ? chunk_tot[(size_t)c * n_owners + o] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_256<uint32_t>(v, tmp, &tot) + carry;
+        if (c < nchunks) chunk_tot[(size_t)c * n_owners + o] = ex;
+        carry += tot;
     }
-    utot[o] = run;
+    if (tid == 0) utot[o] = carry;
 }
 // ucount[tile][owner] -> words of the owner emitted by earlier tiles; grid = chunks
 __global__ __launch_bounds__(256) void k_sx_ucol_apply(uint32_t* ucount, uint32_t ntiles, uint32_t n_owners, const uint32_t* chunk_tot) {
@@ -915,8 +933,10 @@ __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const ui
     __shared__ uint32_t s_cur[SX_MAX_OWNERS];   // next free word of this tile's share of each owner's stream
     __shared__ uint32_t s_cnt[SX_MAX_OWNERS];
     __shared__ uint32_t s_seg[SX_MAX_OWNERS];
-    __shared__ uint32_t stage_w[EM_STAGE];
-    __shared__ uint16_t stage_o[EM_STAGE];
+    // a round's update words in owner order: slot -> the thread (entry) it belongs to; per entry: its
+    // first slot, the cell of column 0 of its row inside the owner band, and (address in the stream) - slot
+    __shared__ uint16_t slot_ent[EM_STAGE];
+    __shared__ uint32_t ent_at[EM_THREADS], ent_cbase[EM_THREADS], ent_delta[EM_THREADS];
     __shared__ uint16_t s_long[SG_TILE];
     __shared__ uint32_t s_nlong, s_total;
     __shared__ uint32_t tmp[EM_WAVES];
@@ -979,18 +999,22 @@ __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const ui
         }
         __syncthreads();
         if (mine) {
-            const uint32_t cbase = (uint32_t)(tri_index((u64)a.x, 0) - tri_index((u64)s_r0[my_o], 0));
             const uint32_t at = s_seg[my_o] + my_pos;
-            for (uint32_t b = 0; b < P; ++b) {
-                const uint2 pq = SX_PARTNER(e0 + e - P + 1u + b);
-                stage_w[at + b] = ((cbase + pq.x) << pb) | (a.y * pq.y);
-                stage_o[at + b] = (uint16_t)my_o;
-            }
+            ent_at[tid] = at;
+            ent_cbase[tid] = (uint32_t)(tri_index((u64)a.x, 0) - tri_index((u64)s_r0[my_o], 0));
+            ent_delta[tid] = s_cur[my_o] - s_seg[my_o];
+            for (uint32_t b = 0; b < P; ++b) slot_ent[at + b] = (uint16_t)tid;
         }
         __syncthreads();
-        for (uint32_t i = tid; i < s_total; i += EM_THREADS) {  // owner-sorted: neighbours go to neighbouring addresses
-            const uint32_t o = stage_o[i];
-            list[s_cur[o] + (i - s_seg[o])] = stage_w[i];
+        // one update word per thread and trip, whatever the entries' partner counts: slot i is partner
+        // i - ent_at of its entry; neighbouring slots go to neighbouring addresses of one stream
+        const uint32_t total = s_total;
+        for (uint32_t i = tid; i < total; i += EM_THREADS) {
+            const uint32_t t = slot_ent[i];
+            const uint32_t el = rb + t;
+            const uint2 ea = s_ent[el];
+            const uint2 pq = SX_PARTNER(e0 + el - s_P[el] + 1u + (i - ent_at[t]));
+            list[ent_delta[t] + i] = ((ent_cbase[t] + pq.x) << pb) | (ea.y * pq.y);
         }
         __syncthreads();
         if (tid < n_owners) s_cur[tid] += s_cnt[tid];
