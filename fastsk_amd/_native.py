@@ -54,7 +54,7 @@ SYMBOLS = ["fsk_create", "fsk_destroy", "fsk_last_error", "fsk_abi_version", "fs
            "fsk_counts_device_ptr", "fsk_reset_counts", "fsk_reset_counts_rows", "fsk_accumulate", "fsk_accumulate_rows", "fsk_synchronize", "fsk_finalize",
            "fsk_get_block", "fsk_get_block_device", "fsk_get_train", "fsk_get_test", "fsk_get_triangle", "fsk_get_counts",
            "fsk_get_counts_block", "fsk_get_counts_cells", "fsk_get_stdevs", "fsk_save_kernel", "fsk_get_stats", "fsk_num_combos",
-           "fsk_combo_positions", "fsk_stream_wait_engine", "fsk_engine_wait_stream", "fsk_read_fasta"]
+           "fsk_combo_positions", "fsk_stream_wait_engine", "fsk_engine_wait_stream", "fsk_read_fasta", "fsk_sequential_sum"]
 
 
 _hip_shared = False
@@ -129,6 +129,7 @@ class Library:
             "fsk_stream_wait_engine": ([vp, vp], C.c_int),
             "fsk_engine_wait_stream": ([vp, vp], C.c_int),
             "fsk_read_fasta": ([C.c_char_p, vp, C.POINTER(i32), vp, i64, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.c_char_p, i32], C.c_int),
+            "fsk_sequential_sum": ([vp, vp, i64, C.POINTER(C.c_double)], C.c_int),
             "fsk_get_stdevs": ([vp, vp, i32, C.POINTER(i32)], C.c_int),
             "fsk_save_kernel": ([vp, C.c_char_p], C.c_int),
             "fsk_get_stats": ([vp, C.POINTER(Stats)], C.c_int),
@@ -328,6 +329,13 @@ class Engine:
         out = np.empty(len(rows), dtype=np.uint64)
         self._ck(self.lib.L.fsk_get_counts_cells(self.h, rows.ctypes.data, cols.ctypes.data, len(rows), out.ctypes.data))
         return out
+
+    def sequential_sum(self, values):
+        """Sum of ``values`` in index order (the reduction of the reference's get_variance), on the device."""
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        out = C.c_double(0.0)
+        self._ck(self.lib.L.fsk_sequential_sum(self.h, values.ctypes.data, len(values), C.byref(out)))
+        return out.value
 
     def get_stdevs(self):
         n = C.c_int32(0)

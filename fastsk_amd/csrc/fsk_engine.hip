@@ -83,14 +83,14 @@ struct fsk_engine {
     int k = 0;
     int64_t ncomb = 0;
     hipStream_t stream = nullptr;
-    hipStream_t copy_stream = nullptr;   // variance mode: D2H of one iteration under the next one's kernels
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_order = nullptr;       // fsk_stream_wait_engine / fsk_engine_wait_stream
+    hipStream_t chain_stream = nullptr;  // variance mode: the sequential sums of a batch, under the next batches' kernels
     // fsk_reset_counts does not fill K when the next accumulate can STORE its sums instead of adding
     // them (dense dataflow, one workgroup per tile): rows [lazy_lo, lazy_hi) are zero by contract
     // but not in memory until a tile launch stores them or materialise_zero() fills them.
     int64_t lazy_lo = -1, lazy_hi = -1;
-    double* h_prod = nullptr;            // pinned staging of the per-cell variance terms (kept across calls)
+    double* h_prod = nullptr;            // pinned: one sequential sum per iteration in flight (kept across calls)
     size_t h_prod_cap = 0;
 
     // sequences
@@ -119,8 +119,9 @@ struct fsk_engine {
     bool K_owned = false;
     int64_t bound_cells = 0;
     DevBuf<u64> K_store;
-    DevBuf<double> d_Kf64, d_Khat, d_prod, d_diag, d_stage;
-    DevBuf<u64> d_stage_u64;
+    DevBuf<double> d_Kf64, d_Khat, d_prod, d_diag, d_stage, d_bsum;
+    DevBuf<unsigned char> d_seqblk;
+    DevBuf<u64> d_stage_u64, d_Kslots;
     DevBuf<int64_t> d_cell_idx;
 
     // dense scratch
@@ -331,7 +332,7 @@ void plan_owner_bands(fsk_engine* e) {
 }
 
 template <typename RecT>
-int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t row0, int64_t row1) {
+int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t row0, int64_t row1, u64 slot_stride = 0) {
     const uint32_t nfeat = (uint32_t)e->nfeat;
     const size_t nrec = (size_t)nb * nfeat;
     if (nrec == 0) return FSK_OK;
@@ -437,7 +438,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             FSK_HIP(e->d_ulist.reserve((size_t)words));
             FSK_LAUNCH(fsk::k_sx_emit<false>, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
                        (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)e->d_list_off.p,
-                       (const uint32_t*)e->d_ucount.p, e->d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K);
+                       (const uint32_t*)e->d_ucount.p, e->d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg, slot_stride);
             const size_t lds = (size_t)e->sx_cap * sizeof(uint32_t);
 #ifndef FSK_EMU
             FSK_HIP(hipFuncSetAttribute((const void*)fsk::k_sx_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -446,17 +447,23 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             // part (up to sx_cap cells) outweighs the words it summed
             const uint32_t target = (uint32_t)std::max<u64>((u64)4 * e->sx_cap, (words + 1023) / 1024);
             const uint32_t max_parts = O + (uint32_t)((words + target - 1) / target);
-            FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, e->stream, (const uint32_t*)e->d_list_off.p, O, target, e->d_part_base.p);
-            FSK_LAUNCH(fsk::k_sx_consume, dim3(max_parts, e->sx_rounds), dim3(fsk::CS_THREADS), lds, e->stream, (const uint32_t*)e->d_ulist.p,
-                       (const uint32_t*)e->d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)e->d_part_base.p, O, target,
-                       e->sx_cap, e->sx_pb, K);
-            e->st.launches += 1;
+            if (slot_stride != 0) {  // one triangle per slot: a slot's words of a stream are one contiguous piece
+                FSK_LAUNCH(fsk::k_sx_consume, dim3(O, e->sx_rounds, nb), dim3(fsk::CS_THREADS), lds, e->stream, (const uint32_t*)e->d_ulist.p,
+                           (const uint32_t*)e->d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)nullptr, O, target,
+                           e->sx_cap, e->sx_pb, K, (const uint32_t*)e->d_ucount.p, tpg, slot_stride);
+            } else {
+                FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, e->stream, (const uint32_t*)e->d_list_off.p, O, target, e->d_part_base.p);
+                FSK_LAUNCH(fsk::k_sx_consume, dim3(max_parts, e->sx_rounds), dim3(fsk::CS_THREADS), lds, e->stream, (const uint32_t*)e->d_ulist.p,
+                           (const uint32_t*)e->d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)e->d_part_base.p, O, target,
+                           e->sx_cap, e->sx_pb, K, (const uint32_t*)nullptr, tpg, (u64)0);
+                e->st.launches += 1;
+            }
             e->st.launches += 2;
         }
     } else {
         FSK_LAUNCH(fsk::k_sx_emit<true>, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
                    (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)nullptr,
-                   (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K);
+                   (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg, slot_stride);
         e->st.launches += 1;
     }
     e->toc(&e->st.ms_pairs);
@@ -477,7 +484,8 @@ int ensure_featseq(fsk_engine* e) {
 
 int materialise_zero(fsk_engine* e);
 
-int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0, int64_t row1) {
+// slot_stride != 0: combo q of the list goes to its own triangle K + q * slot_stride (variance mode)
+int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0, int64_t row1, u64 slot_stride = 0) {
     { int rcz = materialise_zero(e); if (rcz) return rcz; }
     int rc = ensure_featseq(e);
     if (rc) return rc;
@@ -493,7 +501,8 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     const bool wide = e->sx_keybits + e->sx_sb > 32;
     for (int s = 0; s < n; s += B) {
         const int nb = std::min(B, n - s);
-        rc = wide ? sparse_batch<u64>(e, combos + s, nb, K, row0, row1) : sparse_batch<uint32_t>(e, combos + s, nb, K, row0, row1);
+        u64* Kb = K + (u64)s * slot_stride;
+        rc = wide ? sparse_batch<u64>(e, combos + s, nb, Kb, row0, row1, slot_stride) : sparse_batch<uint32_t>(e, combos + s, nb, Kb, row0, row1, slot_stride);
         if (rc) return rc;
     }
     return FSK_OK;
@@ -798,7 +807,7 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
     return FSK_OK;
 }
 
-int do_accumulate(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0 = 0, int64_t row1 = -1) {
+int do_accumulate(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0 = 0, int64_t row1 = -1, u64 slot_stride = 0) {
     if (row1 < 0) row1 = e->N;
     for (int i = 0; i < n; ++i)
         if (combos[i] < 0 || combos[i] >= e->ncomb) return e->fail(FSK_EINVAL, "combo id %d out of range [0,%lld)", combos[i], (long long)e->ncomb);
@@ -808,7 +817,7 @@ int do_accumulate(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t r
         (void)hipEventCreate(&b);
         (void)hipEventRecord(a, e->stream);
     }
-    int rc = e->path == FSK_PATH_DENSE ? accumulate_dense(e, combos, n, K, row0, row1) : accumulate_sparse(e, combos, n, K, row0, row1);
+    int rc = e->path == FSK_PATH_DENSE ? accumulate_dense(e, combos, n, K, row0, row1) : accumulate_sparse(e, combos, n, K, row0, row1, slot_stride);
     if (e->cfg.profile) {
         (void)hipEventRecord(b, e->stream);
         (void)hipEventSynchronize(b);
@@ -844,6 +853,25 @@ void default_order(fsk_engine* e) {
     }
 }
 
+// the reference's `avg` of get_variance (fastsk_kernel.cpp:116-131): sum of n doubles in index order,
+// on the device (k_seq_prep on all CUs + k_seq_chain); bsum = approximate sums per SQ_BLOCK values
+// (zero on entry, zero again on exit), result to out[0]
+// `count` independent sums laid out `stride` values apart (their block sums / block records / results
+// follow each other); the chains run on `chain_stream`
+int enqueue_sequential_sum(fsk_engine* e, const double* d_vals, u64 n, double* bsum, fsk::SeqBlk* blk, double* out, int count = 1,
+                           u64 stride = 0, hipStream_t chain_stream = nullptr, hipEvent_t handoff = nullptr) {
+    const uint32_t nblocks = (uint32_t)((n + fsk::SQ_BLOCK - 1) / fsk::SQ_BLOCK);
+    if (nblocks > 0)
+        FSK_LAUNCH(fsk::k_seq_prep, dim3(nblocks, count), dim3(256), 0, e->stream, d_vals, n, (const double*)bsum, blk, stride, nblocks);
+    hipStream_t cs = chain_stream ? chain_stream : e->stream;
+    if (chain_stream) {
+        FSK_HIP(hipEventRecord(handoff, e->stream));
+        FSK_HIP(hipStreamWaitEvent(chain_stream, handoff, 0));
+    }
+    FSK_LAUNCH(fsk::k_seq_chain, dim3(count), dim3(64), 0, cs, d_vals, n, (const fsk::SeqBlk*)blk, nblocks, bsum, out, stride);
+    return FSK_OK;
+}
+
 // variance mode: T sequential Welford chains (fastsk_kernel.cpp:188-262, 286-315)
 int run_variance_mode(fsk_engine* e, int T) {
     { int rcz = materialise_zero(e); if (rcz) return rcz; }
@@ -851,13 +879,11 @@ int run_variance_mode(fsk_engine* e, int T) {
     const int64_t train_pairs = (int64_t)((e->n_train / (double)2) * (e->n_train + 1));
     const size_t tp = (size_t)std::max<int64_t>(1, train_pairs);
     // The stop test of iteration i needs avg_variance, a SEQUENTIAL fp64 sum in triangle-index
-    // order (fastsk_kernel.cpp:116-131): it must keep that order for stdevs to match to the last
-    // bit, and one host core streams the freshly copied cells at ~15 GB/s. So the engine runs
-    // ahead of its stop test: iterations are issued in batches of AHEAD, up to DEPTH batches in
-    // flight. The cells of an iteration leave on a copy stream under the next iteration's
-    // kernels; the AHEAD sums of a batch are independent chains, one host thread each, and while
-    // they run this thread already enqueues the batch after next; the Welford state of every
-    // untested iteration is kept in a ring; whatever lies beyond the stopping iteration is dropped.
+    // order (fastsk_kernel.cpp:116-131), to the last bit. It is computed on the device
+    // (enqueue_sequential_sum), so only 8 bytes per iteration come back; the engine still runs AHEAD
+    // of its stop test: iterations are issued in batches of AHEAD with up to DEPTH batches in flight,
+    // the Welford state of every untested iteration is kept in a ring, and whatever lies beyond the
+    // stopping iteration is dropped.
     constexpr int AHEAD = 4, MAX_DEPTH = 3;
     // three batches in flight need 13 Welford buffers: only while that is small next to HBM
     const int DEPTH = (size_t)pairs * sizeof(double) * (MAX_DEPTH * AHEAD + 1) <= ((size_t)8 << 30) ? MAX_DEPTH : 2;
@@ -865,31 +891,37 @@ int run_variance_mode(fsk_engine* e, int T) {
     const bool trace = getenv("FSK_TRACE") != nullptr;  // stderr: where the wall time of this mode goes
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
-    double t_wait = 0, t_sum = 0;
+    double t_wait = 0;
     const auto t_begin = now();
+    const size_t nblk = (tp + fsk::SQ_BLOCK - 1) / fsk::SQ_BLOCK;
+    const size_t slots = (size_t)DEPTH * AHEAD;
     FSK_HIP(e->d_Kf64.reserve((size_t)pairs));
     FSK_HIP(e->d_Khat.reserve((size_t)pairs * RING));
-    FSK_HIP(e->d_prod.reserve(tp * DEPTH * AHEAD));
+    FSK_HIP(e->d_prod.reserve(tp * slots));
+    FSK_HIP(e->d_bsum.reserve(nblk * slots + slots));
+    FSK_HIP(e->d_seqblk.reserve(nblk * slots * sizeof(fsk::SeqBlk)));
     FSK_HIP(hipMemsetAsync(e->d_Kf64.p, 0, (size_t)pairs * sizeof(double), e->stream));
-    if (e->h_prod_cap < tp * DEPTH * AHEAD) {
+    FSK_HIP(hipMemsetAsync(e->d_bsum.p, 0, (nblk * slots + slots) * sizeof(double), e->stream));
+    double* d_avg = e->d_bsum.p + nblk * slots;  // one result per slot, behind the block sums
+    if (e->h_prod_cap < slots) {
         if (e->h_prod) (void)hipHostFree(e->h_prod);
         e->h_prod = nullptr; e->h_prod_cap = 0;
-        FSK_HIP(hipHostMalloc((void**)&e->h_prod, tp * DEPTH * AHEAD * sizeof(double)));
-        e->h_prod_cap = tp * DEPTH * AHEAD;
+        FSK_HIP(hipHostMalloc((void**)&e->h_prod, slots * sizeof(double)));
+        e->h_prod_cap = slots;
     }
-    if (!e->copy_stream) FSK_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-    hipEvent_t ev_cell[MAX_DEPTH * AHEAD], ev_done[MAX_DEPTH];
-    for (auto& ev : ev_cell) FSK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    double* h_avg = e->h_prod;  // pinned
+    if (!e->chain_stream) FSK_HIP(hipStreamCreateWithFlags(&e->chain_stream, hipStreamNonBlocking));
+    hipEvent_t ev_done[MAX_DEPTH], ev_hand[MAX_DEPTH];
     for (auto& ev : ev_done) FSK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (auto& ev : ev_hand) FSK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     struct Cleanup {
         hipEvent_t* a; hipEvent_t* b; fsk_engine* e;
         ~Cleanup() {
-            (void)hipStreamSynchronize(e->stream);       // nothing of this call may still be in flight
-            (void)hipStreamSynchronize(e->copy_stream);
-            for (int i = 0; i < MAX_DEPTH * AHEAD; ++i) (void)hipEventDestroy(a[i]);
-            for (int i = 0; i < MAX_DEPTH; ++i) (void)hipEventDestroy(b[i]);
+            (void)hipStreamSynchronize(e->stream);  // nothing of this call may still be in flight
+            (void)hipStreamSynchronize(e->chain_stream);
+            for (int i = 0; i < MAX_DEPTH; ++i) { (void)hipEventDestroy(a[i]); (void)hipEventDestroy(b[i]); }
         }
-    } cleanup{ev_cell, ev_done, e};
+    } cleanup{ev_done, ev_hand, e};
     const double t_alloc = ms_since(t_begin);
     const uint32_t blocks = (uint32_t)((pairs + 255) / 256);
     const int n_order = (int)e->order.size();
@@ -910,22 +942,42 @@ int run_variance_mode(fsk_engine* e, int T) {
         N.n = plan(N.first_iter, N.first_item);
         return N;
     };
+    // sparse dataflow: the iterations of a batch are sorted and segmented together (one slot each) and
+    // land in AHEAD separate triangles; dense dataflow: one iteration at a time into the engine's triangle
+    const bool grouped = e->path == FSK_PATH_SPARSE;
+    if (grouped) FSK_HIP(e->d_Kslots.reserve((size_t)pairs * AHEAD));
     auto issue = [&](const Batch& B) -> int {
+        if (grouped) {
+            int32_t combos[AHEAD];
+            for (int b = 0; b < B.n; ++b) combos[b] = e->order[B.first_item + b * T];
+            FSK_HIP(hipMemsetAsync(e->d_Kslots.p, 0, (size_t)pairs * sizeof(u64) * (size_t)B.n, e->stream));
+            int rc = do_accumulate(e, combos, B.n, e->d_Kslots.p, 0, -1, (u64)pairs);
+            if (rc) return rc;
+        }
         for (int b = 0; b < B.n; ++b) {
             const size_t slot = (size_t)(B.part * AHEAD + b);
-            FSK_HIP(hipMemsetAsync(e->d_K, 0, (size_t)pairs * sizeof(u64), e->stream));
-            int32_t combo = e->order[B.first_item + b * T];
-            int rc = do_accumulate(e, &combo, 1, e->d_K);
-            if (rc) return rc;
-            FSK_LAUNCH(fsk::k_welford, dim3(blocks), dim3(256), 0, e->stream, e->d_K, (const double*)khat(B.base + b), khat(B.base + b + 1),
-                       e->d_prod.p + slot * tp, (u64)pairs, (u64)train_pairs, (double)(B.first_iter + b));
-            FSK_HIP(hipEventRecord(ev_cell[slot], e->stream));
-            FSK_HIP(hipStreamWaitEvent(e->copy_stream, ev_cell[slot], 0));
-            if (train_pairs > 0)
-                FSK_HIP(hipMemcpyAsync(e->h_prod + slot * tp, e->d_prod.p + slot * tp, (size_t)train_pairs * sizeof(double),
-                                       hipMemcpyDeviceToHost, e->copy_stream));
+            const u64* Ks = grouped ? e->d_Kslots.p + (size_t)b * pairs : e->d_K;
+            if (!grouped) {
+                FSK_HIP(hipMemsetAsync(e->d_K, 0, (size_t)pairs * sizeof(u64), e->stream));
+                int32_t combo = e->order[B.first_item + b * T];
+                int rc = do_accumulate(e, &combo, 1, e->d_K);
+                if (rc) return rc;
+            }
+            double* bsum = e->d_bsum.p + slot * nblk;
+            fsk::SeqBlk* blk = reinterpret_cast<fsk::SeqBlk*>(e->d_seqblk.p) + slot * nblk;
+            FSK_LAUNCH(fsk::k_welford, dim3(blocks), dim3(256), 0, e->stream, Ks, (const double*)khat(B.base + b), khat(B.base + b + 1),
+                       e->d_prod.p + slot * tp, (u64)pairs, (u64)train_pairs, (double)(B.first_iter + b), bsum);
+            (void)blk;
         }
-        FSK_HIP(hipEventRecord(ev_done[B.part], e->copy_stream));
+        // the batch's sums: block totals on all CUs, then one wave per iteration walks its blocks — on a
+        // second stream, under the kernels of the batches that follow
+        const size_t slot0 = (size_t)B.part * AHEAD;
+        int rc = enqueue_sequential_sum(e, e->d_prod.p + slot0 * tp, (u64)train_pairs, e->d_bsum.p + slot0 * nblk,
+                                        reinterpret_cast<fsk::SeqBlk*>(e->d_seqblk.p) + slot0 * nblk, d_avg + slot0, B.n, (u64)tp,
+                                        e->chain_stream, ev_hand[B.part]);
+        if (rc) return rc;
+        FSK_HIP(hipMemcpyAsync(h_avg + slot0, d_avg + slot0, (size_t)B.n * sizeof(double), hipMemcpyDeviceToHost, e->chain_stream));
+        FSK_HIP(hipEventRecord(ev_done[B.part], e->chain_stream));
         return FSK_OK;
     };
     e->stdevs.clear();
@@ -944,8 +996,7 @@ int run_variance_mode(fsk_engine* e, int T) {
         }
         bool working = true;
         while (working) {
-            // keep DEPTH - 1 batches issued before the oldest one is summed ...
-            while ((int)q.size() < DEPTH - 1) {
+            while ((int)q.size() < DEPTH) {  // keep the device DEPTH batches ahead of the stop test
                 Batch N = after(q.back());
                 if (N.n == 0) break;
                 int rc = issue(N);
@@ -956,33 +1007,9 @@ int run_variance_mode(fsk_engine* e, int T) {
             auto t0 = now();
             FSK_HIP(hipEventSynchronize(ev_done[A.part]));
             t_wait += ms_since(t0);
-            t0 = now();
-            double avg[AHEAD] = {0, 0, 0, 0};
-            auto chain = [&](int b) {
-                const double* p = e->h_prod + (size_t)(A.part * AHEAD + b) * tp;
-                double a = 0;
-                for (int64_t i = 0; i < train_pairs; ++i) a += p[i];
-                avg[b] = a;
-            };
-            int rc_issue = FSK_OK;
-            {
-                std::vector<std::thread> helpers;
-                for (int b = 0; b < A.n; ++b) helpers.emplace_back(chain, b);
-                // ... and enqueue one more while the chains run
-                if ((int)q.size() < DEPTH) {
-                    Batch N = after(q.back());
-                    if (N.n > 0) {
-                        rc_issue = issue(N);
-                        if (rc_issue == FSK_OK) q.push_back(N);
-                    }
-                }
-                for (auto& th : helpers) th.join();
-            }
-            if (rc_issue) return rc_issue;
-            t_sum += ms_since(t0);
             int accepted = 0;
             for (int b = 0; b < A.n && working; ++b) {
-                double v = avg[b] / (double)train_pairs;
+                double v = h_avg[(size_t)A.part * AHEAD + b] / (double)train_pairs;
                 if (iter == 1) v = 9999999;
                 else v /= iter - 1;
                 const double sd = std::sqrt(v / iter);
@@ -999,9 +1026,9 @@ int run_variance_mode(fsk_engine* e, int T) {
             q.erase(q.begin());
             if (!working) {
                 for (const Batch& B : q) e->st.combos_done -= B.n;
-                if (!q.empty()) {  // let the dropped batches drain before their buffers are reused
+                if (!q.empty()) {  // dropped batches drain before their buffers are reused
                     FSK_HIP(hipStreamSynchronize(e->stream));
-                    FSK_HIP(hipStreamSynchronize(e->copy_stream));
+                    FSK_HIP(hipStreamSynchronize(e->chain_stream));
                 }
                 break;
             }
@@ -1012,8 +1039,8 @@ int run_variance_mode(fsk_engine* e, int T) {
     e->result_f64 = true;
     FSK_HIP(hipStreamSynchronize(e->stream));
     if (trace)
-        fprintf(stderr, "[fsk] variance mode: setup %.2f ms, waiting for the GPU %.2f ms, host sums %.2f ms, total %.2f ms (%lld cells/iteration, %d batches in flight)\n",
-                t_alloc, t_wait, t_sum, ms_since(t_begin), (long long)train_pairs, DEPTH);
+        fprintf(stderr, "[fsk] variance mode: setup %.2f ms, waiting for the GPU %.2f ms, total %.2f ms (%lld cells/iteration, %d batches in flight)\n",
+                t_alloc, t_wait, ms_since(t_begin), (long long)train_pairs, DEPTH);
     return FSK_OK;
 }
 
@@ -1116,15 +1143,15 @@ void fsk_destroy(fsk_engine* e) {
     DeviceScope on_device(e->cfg.device);
     (void)hipStreamSynchronize(e->stream);
     e->d_words.release(); e->d_wstart.release(); e->d_len.release(); e->d_fstart.release(); e->d_featseq.release();
-    e->d_pos.release(); e->K_store.release(); e->d_Kf64.release(); e->d_Khat.release(); e->d_prod.release();
-    e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_cell_idx.release(); e->d_C4.release(); e->d_C4H.release(); e->d_rowmask.release(); e->d_flag.release(); e->d_tiletab.release(); e->d_keybits.release(); e->d_lut.release(); e->d_vc.release();
+    e->d_pos.release(); e->d_bsum.release(); e->d_seqblk.release(); e->K_store.release(); e->d_Kf64.release(); e->d_Khat.release(); e->d_prod.release();
+    e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_Kslots.release(); e->d_cell_idx.release(); e->d_C4.release(); e->d_C4H.release(); e->d_rowmask.release(); e->d_flag.release(); e->d_tiletab.release(); e->d_keybits.release(); e->d_lut.release(); e->d_vc.release();
     for (int b = 0; b < 2; ++b) e->d_keys[b].release();
     e->d_blockhist.release(); e->d_totals.release(); e->d_tile_ent.release(); e->d_ebase.release(); e->d_Pk.release();
     e->d_owner_r0.release(); e->d_ucount.release(); e->d_uchunk.release(); e->d_part_base.release(); e->d_tile_stat.release(); e->d_utot.release(); e->d_list_off.release(); e->d_ulist.release();
     e->d_tile_lrh.release(); e->d_tile_rs.release(); e->d_E.release(); e->d_sxstat.release(); e->d_U.release(); e->d_U2.release();
     if (e->h_prod) (void)hipHostFree(e->h_prod);
-    if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
     if (e->ev_order) (void)hipEventDestroy(e->ev_order);
+    if (e->chain_stream) { (void)hipStreamSynchronize(e->chain_stream); (void)hipStreamDestroy(e->chain_stream); }
     (void)hipEventDestroy(e->ev0);
     (void)hipEventDestroy(e->ev1);
     (void)hipStreamDestroy(e->stream);
@@ -1606,6 +1633,28 @@ int fsk_get_counts_cells(fsk_engine* e, const int64_t* rows, const int64_t* cols
         FSK_HIP(hipMemcpyAsync(out + c0, e->d_stage_u64.p, (size_t)cnt * sizeof(u64), hipMemcpyDeviceToHost, e->stream));
         FSK_HIP(hipStreamSynchronize(e->stream));
     }
+    return FSK_OK;
+}
+
+int fsk_sequential_sum(fsk_engine* e, const double* values, int64_t n, double* out) {
+    if (!e) return FSK_EINVAL;
+    if (n < 0 || (n > 0 && !values) || !out) return e->fail(FSK_EINVAL, "bad arguments");
+    FSK_ON_DEVICE(e);
+    const size_t nblk = ((size_t)n + fsk::SQ_BLOCK - 1) / fsk::SQ_BLOCK;
+    DevBuf<double> vals, bsum;
+    DevBuf<unsigned char> blk;
+    struct Free { DevBuf<double>&a, &b; DevBuf<unsigned char>& c; ~Free() { a.release(); b.release(); c.release(); } } guard{vals, bsum, blk};
+    FSK_HIP(vals.reserve((size_t)std::max<int64_t>(1, n)));
+    FSK_HIP(bsum.reserve(nblk + 1));
+    FSK_HIP(blk.reserve((nblk + 1) * sizeof(fsk::SeqBlk)));
+    FSK_HIP(hipMemcpyAsync(vals.p, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    FSK_HIP(hipMemsetAsync(bsum.p, 0, (nblk + 1) * sizeof(double), e->stream));
+    if (n > 0)  // approximate block sums (what k_welford accumulates on the way in variance mode)
+        FSK_LAUNCH(fsk::k_block_sums, dim3((uint32_t)nblk), dim3(256), 0, e->stream, (const double*)vals.p, (u64)n, bsum.p);
+    int rc = enqueue_sequential_sum(e, vals.p, (u64)n, bsum.p, reinterpret_cast<fsk::SeqBlk*>(blk.p), bsum.p + nblk);
+    if (rc) return rc;
+    FSK_HIP(hipMemcpyAsync(out, bsum.p + nblk, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    FSK_HIP(hipStreamSynchronize(e->stream));
     return FSK_OK;
 }
 

@@ -926,7 +926,7 @@ __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const ui
                                                         const uint32_t* owner_r0, int own_shift, uint32_t n_owners,
                                                         const uint32_t* list_off, const uint32_t* tile_off, uint32_t* list,
                                                         uint32_t row0, uint32_t row1, uint32_t max_win, uint32_t maxprod,
-                                                        uint32_t cmax, int pb, u64* K) {
+                                                        uint32_t cmax, int pb, u64* K, uint32_t tpg, u64 slot_stride) {
     __shared__ uint2 s_ent[SG_TILE];
     __shared__ uint32_t s_P[SG_TILE];
     __shared__ uint32_t s_r0[SX_MAX_OWNERS + 1];
@@ -943,6 +943,7 @@ __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const ui
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t tile = blockIdx.x;
     const uint32_t e0 = ebase[tile], n = ebase[tile + 1] - e0;
+    if (DIRECT) K += (u64)(tile / tpg) * slot_stride;  // one triangle per slot (variance mode) when slot_stride != 0
     if (!DIRECT) {
         for (uint32_t i = tid; i <= n_owners; i += EM_THREADS) s_r0[i] = owner_r0[i];
         for (uint32_t o = tid; o < n_owners; o += EM_THREADS) s_cur[o] = list_off[o] + tile_off[(size_t)tile * n_owners + o];
@@ -1078,30 +1079,46 @@ __global__ __launch_bounds__(512) void k_sx_parts(const uint32_t* list_off, uint
 // otherwise. A band larger than `cap` cells takes several rounds over its stream.
 // dynamic LDS: cap * 4 bytes. grid = (upper bound of the number of parts, rounds)
 constexpr uint32_t CS_THREADS = 1024;
+// By-slot form (variance mode, slot_stride != 0): grid = (owner bands, rounds, slots); the words a slot
+// put into a band's stream are contiguous (tiles are slot-major), bounded by the tile offsets of the
+// slot's first tile, and go to the slot's own triangle K + slot * slot_stride.
 __global__ __launch_bounds__(1024) void k_sx_consume(const uint32_t* list, const uint32_t* list_off, const uint32_t* owner_r0,
                                                      const uint32_t* part_base, uint32_t n_owners, uint32_t target, uint32_t cap,
-                                                     int pb, u64* K) {
+                                                     int pb, u64* K, const uint32_t* tile_off, uint32_t tpg, u64 slot_stride) {
     FSK_DYN_SHARED(uint32_t, cells);
     __shared__ uint32_t s_base[SX_MAX_OWNERS + 1];
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i <= n_owners; i += CS_THREADS) s_base[i] = part_base[i];
-    __syncthreads();
-    const uint32_t slot = blockIdx.x, r = blockIdx.y;
-    if (slot >= s_base[n_owners]) return;
-    uint32_t o = 0, hi = n_owners;  // s_base[o] <= slot < s_base[hi]; bands without words share their successor's base
-    while (hi - o > 1u) {
-        const uint32_t mid = (o + hi) >> 1;
-        if (s_base[mid] <= slot) o = mid; else hi = mid;
+    const uint32_t r = blockIdx.y;
+    uint32_t o, a, b, nparts = 1u;
+    if (slot_stride != 0) {
+        o = blockIdx.x;
+        const uint32_t slot = blockIdx.z;
+        a = list_off[o] + tile_off[(size_t)slot * tpg * n_owners + o];
+        b = slot + 1u < gridDim.z ? list_off[o] + tile_off[(size_t)(slot + 1u) * tpg * n_owners + o] : list_off[o + 1];
+        K += (u64)slot * slot_stride;
+    } else {
+        for (uint32_t i = tid; i <= n_owners; i += CS_THREADS) s_base[i] = part_base[i];
+        __syncthreads();
+        const uint32_t slot = blockIdx.x;
+        if (slot >= s_base[n_owners]) return;
+        uint32_t hi = n_owners;  // s_base[o] <= slot < s_base[hi]; bands without words share their successor's base
+        o = 0;
+        while (hi - o > 1u) {
+            const uint32_t mid = (o + hi) >> 1;
+            if (s_base[mid] <= slot) o = mid; else hi = mid;
+        }
+        const uint32_t part = slot - s_base[o];
+        nparts = s_base[o + 1] - s_base[o];
+        a = list_off[o] + part * target;
+        const uint32_t end = list_off[o + 1];
+        b = end - a < target ? end : a + target;
     }
-    const uint32_t part = slot - s_base[o], nparts = s_base[o + 1] - s_base[o];
+    if (a == b) return;
     const u64 c0 = tri_index((u64)owner_r0[o], 0), c1 = tri_index((u64)owner_r0[o + 1], 0);
     const uint32_t ncell = (uint32_t)(c1 - c0);
     const uint32_t lo = r * cap;
     if (lo >= ncell) return;
     const uint32_t span = ncell - lo < cap ? ncell - lo : cap;
-    const uint32_t a = list_off[o] + part * target;
-    const uint32_t end = list_off[o + 1];
-    const uint32_t b = end - a < target ? end : a + target;
     for (uint32_t i = tid; i < span; i += CS_THREADS) cells[i] = 0u;
     __syncthreads();
     const uint32_t mask = (1u << pb) - 1u;
@@ -1197,19 +1214,253 @@ __global__ __launch_bounds__(256) void k_triangle(const SrcT* K, const double* d
 // APPROX / VARIANCE MODE  (get_variance, fastsk_kernel.cpp:108-143)
 // =============================================================================================
 // K_hat' = K_hat + (Ks - K_hat)/iter; prod = delta * (Ks - K_hat') for the train x train prefix.
-// The reference then sums prod sequentially in index order; that one reduction stays on the host.
+// The reference then sums prod SEQUENTIALLY in index order (fastsk_kernel.cpp:116-131) and the stop
+// test reads that sum to the last bit; k_seq_prep / k_seq_chain below reproduce it on the device.
 // K_hat is read from one buffer and written to another: the host runs a few iterations ahead of
 // its stop test and keeps the state of every iteration it has not yet accepted.
+// bsum[i / SQ_BLOCK] += prod (any order: only a PREDICTION of the running sum's binade is made from it).
+constexpr int SQ_BLOCK = 8192;
 __global__ __launch_bounds__(256) void k_welford(const u64* Ks, const double* K_hat_in, double* K_hat_out, double* prod, u64 pairs,
-                                                 u64 train_pairs, double iter) {
+                                                 u64 train_pairs, double iter, double* bsum) {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= pairs) return;
-    const double x = (double)Ks[i];
-    const double old = K_hat_in[i];
-    const double delta = __dsub_rn(x, old);
-    const double kh = __dadd_rn(old, __ddiv_rn(delta, iter));
-    K_hat_out[i] = kh;
-    if (i < train_pairs) prod[i] = __dmul_rn(delta, __dsub_rn(x, kh));
+    double pr = 0.0;
+    if (i < pairs) {
+        const double x = (double)Ks[i];
+        const double old = K_hat_in[i];
+        const double delta = __dsub_rn(x, old);
+        const double kh = __dadd_rn(old, __ddiv_rn(delta, iter));
+        K_hat_out[i] = kh;
+        if (i < train_pairs) {
+            pr = __dmul_rn(delta, __dsub_rn(x, kh));
+            prod[i] = pr;
+        }
+    }
+    // a 64-lane group lies inside one SQ_BLOCK (8192 is a multiple of 64)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) pr += __shfl_xor(pr, d);
+    const u64 first = ((u64)blockIdx.x * 256 + threadIdx.x) & ~(u64)63;
+    if ((threadIdx.x & 63) == 0 && first < train_pairs && pr != 0.0) atomicAdd(&bsum[first / SQ_BLOCK], pr);
+}
+
+// ---- exact sequential summation, in parallel ---------------------------------------------------
+// s_i = fl(s_{i-1} + p_i), p_i >= 0, round to nearest even. While the running sum stays inside one
+// binade [2^e, 2^(e+1)) every s_i is a multiple of u = 2^(e-52), so fl(s + p) = s + R(p) with R(p) the
+// multiple of u nearest to p — independent of s unless p lies exactly half-way (a tie: the parity of
+// s decides). Hence for a block of values with no tie whose integer total S/u + sum R(p)/u stays
+// below 2^53 the sequential result is exactly that integer total times u, whatever the order of the
+// additions. k_seq_prep computes sum R(p)/u per block for the binade PREDICTED from approximate block
+// sums, on all CUs; k_seq_chain (one wave) walks the blocks with the exact running sum, accepts a
+// block when the prediction was right and its conditions hold, and otherwise redoes the block
+// itself, in sub-blocks, down to plain sequential additions — so the result is the sequential sum
+// for ANY input; only the speed depends on the values being non-negative.
+struct SeqBlk {
+    int e;            // binade the block's integer total was computed for
+    uint32_t flags;   // 1: negative or NaN value, 2: value too large for the integer total, 4: tie, 8: no prediction,
+                      // 16: every value of the block is zero (the block changes no running sum)
+    u64 Q;            // sum of R(p) / u over the block
+};
+union DblBits { double d; u64 u; };
+// unbiased exponent of a normal positive double within +-900, else INT32_MIN (zero, subnormal, huge, NaN)
+__device__ __forceinline__ int seq_exponent(double s) {
+    DblBits b; b.d = s;
+    if (b.u >> 63) return INT32_MIN;
+    const int e = (int)((b.u >> 52) & 0x7ffu) - 1023;
+    return (e < -900 || e > 900) ? INT32_MIN : e;
+}
+__device__ __forceinline__ double seq_pow2(int e) {  // 2^e, -1022 <= e <= 1023
+    DblBits b; b.u = (u64)(e + 1023) << 52;
+    return b.d;
+}
+// R(p)/u of one value for scale = 1/u, added to q; limit bounds a single value so that q cannot wrap
+__device__ __forceinline__ void seq_classify(double p, double scale, double limit, u64& q, uint32_t& flags) {
+    if (!(p >= 0.0)) { flags |= 1u; return; }  // (-0.0 passes and adds nothing)
+    const double x = p * scale;                // exact: a power of two
+    if (!(x < limit)) { flags |= 2u; return; }
+    if (x - floor(x) == 0.5) flags |= 4u;
+    q += (u64)rint(x);
+}
+
+// bsum[b] = sum of block b in any order (stand-alone use of the summation; variance mode gets these
+// from k_welford); grid = blocks of SQ_BLOCK values
+__global__ __launch_bounds__(256) void k_block_sums(const double* p, u64 n, double* bsum) {
+    __shared__ double part[4];
+    const uint32_t tid = threadIdx.x;
+    const u64 lo = (u64)blockIdx.x * SQ_BLOCK;
+    double a = 0.0;
+    for (int j = 0; j < SQ_BLOCK / 256; ++j) {
+        const u64 i = lo + (u64)j * 256 + tid;
+        if (i < n) a += p[i];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
+    if ((tid & 63u) == 0) part[tid >> 6] = a;
+    __syncthreads();
+    if (tid == 0) bsum[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// grid = blocks of SQ_BLOCK values, 256 threads
+// (blockIdx.y = one of several independent sums laid out `stride` values / `nblk` blocks apart)
+__global__ __launch_bounds__(256) void k_seq_prep(const double* p, u64 n, const double* bsum, SeqBlk* blk, u64 stride, uint32_t nblk) {
+    __shared__ double s_pre[4];
+    __shared__ u64 s_q[4];
+    __shared__ uint32_t s_f[4];
+    const uint32_t tid = threadIdx.x, b = blockIdx.x;
+    p += (u64)blockIdx.y * stride;
+    bsum += (size_t)blockIdx.y * nblk;
+    blk += (size_t)blockIdx.y * nblk;
+    double pre = 0.0;
+    for (uint32_t i = tid; i < b; i += 256) pre += bsum[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d);
+    if ((tid & 63u) == 0) s_pre[tid >> 6] = pre;
+    __syncthreads();
+    pre = (s_pre[0] + s_pre[1]) + (s_pre[2] + s_pre[3]);
+    const int e = seq_exponent(pre);
+    const double scale = seq_pow2(52 - (e == INT32_MIN ? 0 : e));
+    const u64 lo = (u64)b * SQ_BLOCK;
+    u64 q = 0;
+    uint32_t fl = e == INT32_MIN ? 8u : 0u, nonzero = 0u;
+#pragma unroll 4
+    for (int j = 0; j < SQ_BLOCK / 256; ++j) {
+        const u64 i = lo + (u64)j * 256 + tid;
+        if (i < n) {
+            const double v = p[i];
+            if (v != 0.0) nonzero = 1u;  // (NaN counts as non-zero)
+            seq_classify(v, scale, 1125899906842624.0 /* 2^50 */, q, fl);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        q += __shfl_xor(q, d);
+        fl |= __shfl_xor(fl, d);
+        nonzero |= __shfl_xor(nonzero, d);
+    }
+    if ((tid & 63u) == 0) { s_q[tid >> 6] = q; s_f[tid >> 6] = fl | (nonzero << 8); }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t all = s_f[0] | s_f[1] | s_f[2] | s_f[3];
+        blk[b].e = e == INT32_MIN ? 0 : e;
+        blk[b].flags = (all & 0xffu) | ((all >> 8) ? 0u : 16u);
+        blk[b].Q = s_q[0] + s_q[1] + s_q[2] + s_q[3];
+    }
+}
+
+// value of lane `src` (wave-uniform index) in every lane: a scalar read, not an LDS permute
+__device__ __forceinline__ uint32_t wave_bcast_u32(uint32_t x, uint32_t src) {
+#ifdef FSK_EMU
+    return __shfl(x, (int)src);
+#else
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)src);
+#endif
+}
+__device__ __forceinline__ u64 wave_bcast_u64(u64 x, uint32_t src) {
+    return ((u64)wave_bcast_u32((uint32_t)(x >> 32), src) << 32) | wave_bcast_u32((uint32_t)x, src);
+}
+__device__ __forceinline__ double wave_bcast_f64(double x, uint32_t src) {
+    DblBits b; b.d = x;
+    b.u = wave_bcast_u64(b.u, src);
+    return b.d;
+}
+
+// PER values per lane (held in registers; 0.0 where the range ended) added to s as one integer total,
+// if the conditions hold
+template <int PER>
+__device__ __forceinline__ bool seq_try_regs(const double (&v)[PER], double& s) {
+    const int e = seq_exponent(s);
+    const bool usable = e != INT32_MIN && s > 0.0;
+    const double scale = seq_pow2(52 - (usable ? e : 0));
+    u64 q = 0;
+    uint32_t fl = 0, nonzero = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (v[k] != 0.0) nonzero = 1u;
+        seq_classify(v[k], scale, 9007199254740992.0 /* 2^53 */, q, fl);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        q += __shfl_xor(q, d);
+        fl |= __shfl_xor(fl, d);
+        nonzero |= __shfl_xor(nonzero, d);
+    }
+    if (!nonzero) return true;  // zeros change no running sum, whatever it is (s starts at +0 and +0 + -0 = +0)
+    if (!usable) return false;
+    const u64 tot = (u64)(s * scale) + q;
+    if (fl != 0u || tot >= ((u64)1 << 53)) return false;
+    s = (double)tot * seq_pow2(e - 52);
+    return true;
+}
+// The values [lo, hi) added to s: groups of 1024 (16 per lane, value lo + 64 k + lane in register k,
+// the next group's loads in flight meanwhile), then the 16 sub-groups of 64, then plain sequential
+// additions — all from registers — for a group that crosses a binade, holds a tie or a negative value.
+// s and every decision are wave-uniform.
+__device__ __forceinline__ double seq_range(const double* p, u64 lo, u64 hi, double s) {
+    const uint32_t lane = threadIdx.x & 63u;
+    double cur[16], nxt[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const u64 i = lo + (u64)k * 64 + lane;
+        cur[k] = i < hi ? p[i] : 0.0;
+    }
+    for (u64 a0 = lo; a0 < hi; a0 += 1024) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const u64 i = a0 + 1024 + (u64)k * 64 + lane;
+            nxt[k] = i < hi ? p[i] : 0.0;
+        }
+        if (!seq_try_regs<16>(cur, s)) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const double one[1] = {cur[k]};
+                if (!seq_try_regs<1>(one, s)) {
+                    const u64 c0 = a0 + (u64)k * 64;
+                    const uint32_t cn = c0 >= hi ? 0u : (hi - c0 < 64 ? (uint32_t)(hi - c0) : 64u);
+                    for (uint32_t j = 0; j < cn; ++j) s = __dadd_rn(s, wave_bcast_f64(cur[k], j));
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
+    }
+    return s;
+}
+
+// one wave: out[0] = the sequential sum of p[0..n); zeroes bsum for the slot's next use
+// (blockIdx.x = one of several independent sums laid out `stride` values / `nblocks` blocks apart)
+__global__ __launch_bounds__(64) void k_seq_chain(const double* p, u64 n, const SeqBlk* blk, uint32_t nblocks, double* bsum, double* out,
+                                                  u64 stride) {
+    const uint32_t lane = threadIdx.x;
+    p += (u64)blockIdx.x * stride;
+    blk += (size_t)blockIdx.x * nblocks;
+    bsum += (size_t)blockIdx.x * nblocks;
+    out += blockIdx.x;
+    double s = 0.0;
+    for (uint32_t c0 = 0; c0 < nblocks; c0 += 64) {
+        // 64 block records at a time, one per lane, handed round with shuffles (no dependent loads in the chain)
+        SeqBlk mine;
+        mine.e = 0; mine.flags = 8u; mine.Q = 0;
+        if (c0 + lane < nblocks) mine = blk[c0 + lane];
+        const uint32_t cn = nblocks - c0 < 64u ? nblocks - c0 : 64u;
+        for (uint32_t j = 0; j < cn; ++j) {
+            const int ke = (int)wave_bcast_u32((uint32_t)mine.e, j);
+            const uint32_t kf = wave_bcast_u32(mine.flags, j);
+            const u64 kq = wave_bcast_u64(mine.Q, j);
+            if (kf & 16u) continue;  // all zeros
+            bool done = false;
+            if (kf == 0u && seq_exponent(s) == ke && s > 0.0) {
+                const u64 tot = (u64)(s * seq_pow2(52 - ke)) + kq;
+                if (tot < ((u64)1 << 53)) {
+                    s = (double)tot * seq_pow2(ke - 52);
+                    done = true;
+                }
+            }
+            if (!done) {
+                const u64 lo = (u64)(c0 + j) * SQ_BLOCK, hi = lo + SQ_BLOCK < n ? lo + SQ_BLOCK : n;
+                s = seq_range(p, lo, hi, s);
+            }
+        }
+    }
+    if (lane == 0) out[0] = s;
+    for (uint32_t b = lane; b < nblocks; b += 64) bsum[b] = 0.0;
 }
 
 // K += val where val != 0 (fastsk_kernel.cpp:286-315)

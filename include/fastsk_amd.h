@@ -179,6 +179,11 @@ int fsk_get_counts_block(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int6
 /* raw integer cells (rows[q], cols[q]), q < n, of the symmetric matrix: scattered spot checks of a
  * triangle too large to copy out (tri_access of arbitrary pairs, shared.cpp:97-117) */
 int fsk_get_counts_cells(fsk_engine* e, const int64_t* rows, const int64_t* cols, int64_t n, uint64_t* out);
+/* The reduction inside get_variance (fastsk_kernel.cpp:116-131): the sum of n doubles in INDEX ORDER,
+ * s = fl(s + values[i]) for i = 0 .. n-1, to the last bit, computed on the device (the stop test of
+ * approx mode depends on it). `values` is a host array. Exposed so that the summation can be verified
+ * on its own. */
+int fsk_sequential_sum(fsk_engine* e, const double* values, int64_t n, double* out);
 /* approx/variance mode: thread 0's convergence trace, get_stdevs() (fastsk.cpp:219-221) */
 int fsk_get_stdevs(fsk_engine* e, double* out, int32_t cap, int32_t* n);
 /* "%d:%e " text dump, one row per line, 1-based column ids: save_kernel (fastsk.cpp:223-237) */

@@ -644,6 +644,22 @@ def test_variance_mode_stops_anywhere(native, port):
     assert len(lengths) >= 6  # stops landed at many different places inside the batches
 
 
+def test_sequential_sum_on_the_device(native):
+    """The device replacement of get_variance's sequential fp64 sum (fastsk_kernel.cpp:116-131): the
+    adversarial cases of tests/test_sequential_sum.py on the real kernels, plus a 2.7 M-value sum of
+    the size config 1 produces per iteration."""
+    from test_sequential_sum import cases, sequential
+    e = native.Engine(4, 2)
+    for name, x in cases().items():
+        assert np.float64(e.sequential_sum(x)).tobytes() == np.float64(sequential(x)).tobytes(), name
+    rng = np.random.default_rng(3)
+    x = (rng.integers(0, 30, 2_736_630) ** 2) * (1.0 - 1.0 / 11.0)
+    x[rng.random(len(x)) < 0.6] = 0.0
+    want = float(np.add.accumulate(x)[-1])  # accumulate is the plain left-to-right loop
+    assert np.float64(e.sequential_sum(x)).tobytes() == np.float64(want).tobytes()
+    e.close()
+
+
 def test_skip_test_block(native, port):
     """skip_test_block=1: everything a getter of the reference exposes (train x train, test x train,
     hence every diagonal entry) is unchanged; tiles made of test x test cells only are not computed."""
