@@ -154,6 +154,7 @@ struct fsk_engine {
     bool u_known = false, u_pending = false;
     u64 u_value = 0, u_extra = 0;
     int force_global_pairs = 0;  // FSK_SPARSE_GLOBAL=1: per-pair global atomics (testing)
+    u64 sx_max_words = (u64)1 << 31;  // update words per batch beyond which the pairs go to K with atomics (FSK_LIST_MAX_WORDS: testing)
     int tile_dma = 1;            // FSK_TILE_DMA=0: register-staged tile kernel instead of the direct-to-LDS one (testing)
 
     fsk_stats st{};
@@ -301,6 +302,7 @@ int choose_path(fsk_engine* e) {
 constexpr uint32_t SX_CAP = 16384;        // u32 cells of K one k_sx_consume workgroup holds in LDS (64 KiB)
 constexpr uint32_t SX_MAX_ROUNDS = 16;
 constexpr u64 SX_MAX_LIST_WORDS = (u64)1 << 31;
+constexpr int FSK_RETRY_UNGROUPED = 1;  // internal: a per-slot sparse batch has to be redone one combo at a time
 
 void plan_owner_bands(fsk_engine* e) {
     // band o = the rows whose first cell index lies in [o << t, (o + 1) << t): a row's band is a shift
@@ -394,7 +396,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         if (p > 0)  // (the extraction counted the first pass's digits)
             FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_hist<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tps, shift,
                        e->d_blockhist.p);
-        FSK_LAUNCH(fsk::k_sx_scan_slot, dim3(nb), dim3(256), 0, e->stream, e->d_blockhist.p, tps, e->d_totals.p);
+        FSK_LAUNCH(fsk::k_sx_scan_slot, dim3(nb), dim3(1024), 0, e->stream, e->d_blockhist.p, tps, e->d_totals.p);
         FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_scatter<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, rec[cur], rec[cur ^ 1], nfeat,
                    tps, shift, e->d_blockhist.p, e->d_totals.p);
         cur ^= 1;
@@ -432,10 +434,11 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     words = stat[1];
 
     e->tic();
-    const bool use_lists = lists && words < SX_MAX_LIST_WORDS;
+    const bool use_lists = lists && words < e->sx_max_words;
+    if (slot_stride != 0 && !use_lists) return FSK_RETRY_UNGROUPED;  // (nothing of this batch has touched K yet)
     if (use_lists) {
-        if (words > 0) {
-            FSK_HIP(e->d_ulist.reserve((size_t)words));
+        if (words > 0 || slot_stride != 0) {
+            FSK_HIP(e->d_ulist.reserve((size_t)std::max<u64>(1, words)));
             FSK_LAUNCH(fsk::k_sx_emit<false>, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
                        (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)e->d_list_off.p,
                        (const uint32_t*)e->d_ucount.p, e->d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg, slot_stride);
@@ -484,7 +487,8 @@ int ensure_featseq(fsk_engine* e) {
 
 int materialise_zero(fsk_engine* e);
 
-// slot_stride != 0: combo q of the list goes to its own triangle K + q * slot_stride (variance mode)
+// slot_stride != 0 (variance mode): combo q of the list goes to its own u32 triangle (uint32_t*)K + q * slot_stride,
+// written whole; returns FSK_RETRY_UNGROUPED when that form cannot be used for this batch
 int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0, int64_t row1, u64 slot_stride = 0) {
     { int rcz = materialise_zero(e); if (rcz) return rcz; }
     int rc = ensure_featseq(e);
@@ -501,7 +505,8 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     const bool wide = e->sx_keybits + e->sx_sb > 32;
     for (int s = 0; s < n; s += B) {
         const int nb = std::min(B, n - s);
-        u64* Kb = K + (u64)s * slot_stride;
+        // (slot triangles are u32 arrays, slot_stride cells apart)
+        u64* Kb = slot_stride ? reinterpret_cast<u64*>(reinterpret_cast<uint32_t*>(K) + (u64)s * slot_stride) : K;
         rc = wide ? sparse_batch<u64>(e, combos + s, nb, Kb, row0, row1, slot_stride) : sparse_batch<uint32_t>(e, combos + s, nb, Kb, row0, row1, slot_stride);
         if (rc) return rc;
     }
@@ -884,9 +889,10 @@ int run_variance_mode(fsk_engine* e, int T) {
     // of its stop test: iterations are issued in batches of AHEAD with up to DEPTH batches in flight,
     // the Welford state of every untested iteration is kept in a ring, and whatever lies beyond the
     // stopping iteration is dropped.
-    constexpr int AHEAD = 4, MAX_DEPTH = 3;
-    // three batches in flight need 13 Welford buffers: only while that is small next to HBM
-    const int DEPTH = (size_t)pairs * sizeof(double) * (MAX_DEPTH * AHEAD + 1) <= ((size_t)8 << 30) ? MAX_DEPTH : 2;
+    // (two batches in flight: the sums of one run on the second stream under the kernels of the next;
+    // a third would only add iterations that are thrown away when the stop test fires)
+    constexpr int AHEAD = 4, MAX_DEPTH = 2;
+    const int DEPTH = MAX_DEPTH;
     const int RING = DEPTH * AHEAD + 1;
     const bool trace = getenv("FSK_TRACE") != nullptr;  // stderr: where the wall time of this mode goes
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -923,7 +929,8 @@ int run_variance_mode(fsk_engine* e, int T) {
         }
     } cleanup{ev_done, ev_hand, e};
     const double t_alloc = ms_since(t_begin);
-    const uint32_t blocks = (uint32_t)((pairs + 255) / 256);
+    const uint32_t blocks = (uint32_t)((pairs + 255) / 256);                                       // one cell per thread
+    const uint32_t wblocks = (uint32_t)((pairs + 256 * fsk::WF_ITEMS - 1) / (256 * fsk::WF_ITEMS)); // k_welford
     const int n_order = (int)e->order.size();
     auto khat = [&](int i) { return e->d_Khat.p + (size_t)(i % RING) * (size_t)pairs; };
     struct Batch { int n = 0, first_iter = 0, first_item = 0, base = 0, part = 0; };
@@ -944,19 +951,21 @@ int run_variance_mode(fsk_engine* e, int T) {
     };
     // sparse dataflow: the iterations of a batch are sorted and segmented together (one slot each) and
     // land in AHEAD separate triangles; dense dataflow: one iteration at a time into the engine's triangle
-    const bool grouped = e->path == FSK_PATH_SPARSE;
-    if (grouped) FSK_HIP(e->d_Kslots.reserve((size_t)pairs * AHEAD));
+    // (u32 triangles written whole by k_sx_consume; without update streams — huge N — pairs go to K with
+    // atomics and the iterations run one at a time like the dense ones)
+    bool grouped = e->path == FSK_PATH_SPARSE && e->sx_lists && !e->force_global_pairs;
+    if (grouped) FSK_HIP(e->d_Kslots.reserve(((size_t)pairs * AHEAD + 1) / 2));
     auto issue = [&](const Batch& B) -> int {
         if (grouped) {
             int32_t combos[AHEAD];
             for (int b = 0; b < B.n; ++b) combos[b] = e->order[B.first_item + b * T];
-            FSK_HIP(hipMemsetAsync(e->d_Kslots.p, 0, (size_t)pairs * sizeof(u64) * (size_t)B.n, e->stream));
             int rc = do_accumulate(e, combos, B.n, e->d_Kslots.p, 0, -1, (u64)pairs);
-            if (rc) return rc;
+            if (rc == FSK_RETRY_UNGROUPED) grouped = false;  // too many updates for one stream: from here on one iteration at a time
+            else if (rc) return rc;
         }
         for (int b = 0; b < B.n; ++b) {
             const size_t slot = (size_t)(B.part * AHEAD + b);
-            const u64* Ks = grouped ? e->d_Kslots.p + (size_t)b * pairs : e->d_K;
+            const uint32_t* Ks32 = reinterpret_cast<const uint32_t*>(e->d_Kslots.p) + (size_t)b * pairs;
             if (!grouped) {
                 FSK_HIP(hipMemsetAsync(e->d_K, 0, (size_t)pairs * sizeof(u64), e->stream));
                 int32_t combo = e->order[B.first_item + b * T];
@@ -965,8 +974,12 @@ int run_variance_mode(fsk_engine* e, int T) {
             }
             double* bsum = e->d_bsum.p + slot * nblk;
             fsk::SeqBlk* blk = reinterpret_cast<fsk::SeqBlk*>(e->d_seqblk.p) + slot * nblk;
-            FSK_LAUNCH(fsk::k_welford, dim3(blocks), dim3(256), 0, e->stream, Ks, (const double*)khat(B.base + b), khat(B.base + b + 1),
-                       e->d_prod.p + slot * tp, (u64)pairs, (u64)train_pairs, (double)(B.first_iter + b), bsum);
+            if (grouped)
+                FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford<uint32_t>), dim3(wblocks), dim3(256), 0, e->stream, Ks32, (const double*)khat(B.base + b),
+                           khat(B.base + b + 1), e->d_prod.p + slot * tp, (u64)pairs, (u64)train_pairs, (double)(B.first_iter + b), bsum);
+            else
+                FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford<u64>), dim3(wblocks), dim3(256), 0, e->stream, (const u64*)e->d_K, (const double*)khat(B.base + b),
+                           khat(B.base + b + 1), e->d_prod.p + slot * tp, (u64)pairs, (u64)train_pairs, (double)(B.first_iter + b), bsum);
             (void)blk;
         }
         // the batch's sums: block totals on all CUs, then one wave per iteration walks its blocks — on a
@@ -1124,6 +1137,7 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     enumerate_combos(cfg->g, e->k, e->all_pos);
     { const char* f = getenv("FSK_COMPACT"); e->force_compact = f ? atoi(f) : -1; }
     { const char* f = getenv("FSK_SPARSE_GLOBAL"); e->force_global_pairs = f ? atoi(f) : 0; }
+    { const char* f = getenv("FSK_LIST_MAX_WORDS"); if (f && atoll(f) > 0) e->sx_max_words = std::min<u64>(SX_MAX_LIST_WORDS, (u64)atoll(f)); }
     { const char* f = getenv("FSK_TILE_SPLITS"); e->force_splits = f ? atoi(f) : 0; }
     { const char* f = getenv("FSK_TILE_DMA"); e->tile_dma = f ? atoi(f) : 1; }
     { const char* f = getenv("FSK_DENSE_CHUNK"); e->force_chunk = f ? (uint32_t)atoi(f) : 0u; }

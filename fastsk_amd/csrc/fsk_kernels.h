@@ -518,29 +518,37 @@ __global__ __launch_bounds__(256) void k_sx_hist(const RecT* rec, uint32_t nfeat
     blockhist[((size_t)slot * tps + tile) * 256u + tid] = h[tid];
 }
 
-// one workgroup per slot, thread = digit: the digit's tile counts become exclusive offsets inside the
-// digit's block (in place), and dbase[slot][digit] = where that block starts inside the slot
-__global__ __launch_bounds__(256) void k_sx_scan_slot(uint32_t* blockhist, uint32_t tps, uint32_t* dbase) {
-    __shared__ uint32_t tmp[4];
-    const uint32_t tid = threadIdx.x, slot = blockIdx.x;
-    uint32_t* h = blockhist + (size_t)slot * tps * 256u + tid;
-    uint32_t run = 0;
-    uint32_t t = 0;
-    for (; t + 4 <= tps; t += 4) {  // the four loads do not depend on the running sum
-        const uint32_t v0 = h[(size_t)t * 256u], v1 = h[(size_t)(t + 1) * 256u], v2 = h[(size_t)(t + 2) * 256u],
-                       v3 = h[(size_t)(t + 3) * 256u];
-        h[(size_t)t * 256u] = run;
-        h[(size_t)(t + 1) * 256u] = run + v0;
-        h[(size_t)(t + 2) * 256u] = run + v0 + v1;
-        h[(size_t)(t + 3) * 256u] = run + v0 + v1 + v2;
-        run += v0 + v1 + v2 + v3;
+// One workgroup of 1024 threads per slot, thread = (quarter of the slot's tiles, digit): the digit's tile
+// counts become exclusive offsets inside the digit's block (in place), and dbase[slot][digit] = where
+// that block starts inside the slot. Two passes over the quarter (sum, then write), so that four
+// chains of dependent loads run side by side.
+__global__ __launch_bounds__(1024) void k_sx_scan_slot(uint32_t* blockhist, uint32_t tps, uint32_t* dbase) {
+    __shared__ uint32_t part[4][256];
+    __shared__ uint32_t tmp[16];
+    const uint32_t tid = threadIdx.x, digit = tid & 255u, quarter = tid >> 8, slot = blockIdx.x;
+    uint32_t* h = blockhist + (size_t)slot * tps * 256u + digit;
+    const uint32_t per = (tps + 3u) / 4u;
+    const uint32_t t0 = quarter * per < tps ? quarter * per : tps, t1 = t0 + per < tps ? t0 + per : tps;
+    uint32_t sum = 0;
+#pragma unroll 4
+    for (uint32_t t = t0; t < t1; ++t) sum += h[(size_t)t * 256u];
+    part[quarter][digit] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) {
+        const uint32_t v = part[q][digit];
+        if (q < quarter) run += v;
+        total += v;
     }
-    for (; t < tps; ++t) {
+#pragma unroll 4
+    for (uint32_t t = t0; t < t1; ++t) {
         const uint32_t v = h[(size_t)t * 256u];
         h[(size_t)t * 256u] = run;
         run += v;
     }
-    dbase[(size_t)slot * 256u + tid] = block_excl_scan_256<uint32_t>(run, tmp, nullptr);
+    const uint32_t ex = block_excl_scan<uint32_t, 16>(quarter == 0 ? total : 0u, tmp, nullptr);
+    if (quarter == 0) dbase[(size_t)slot * 256u + digit] = ex;
 }
 
 // one workgroup per row: exclusive scan of the row in place, row total to totals[row]
@@ -1081,7 +1089,8 @@ __global__ __launch_bounds__(512) void k_sx_parts(const uint32_t* list_off, uint
 constexpr uint32_t CS_THREADS = 1024;
 // By-slot form (variance mode, slot_stride != 0): grid = (owner bands, rounds, slots); the words a slot
 // put into a band's stream are contiguous (tiles are slot-major), bounded by the tile offsets of the
-// slot's first tile, and go to the slot's own triangle K + slot * slot_stride.
+// slot's first tile, and the sums are STORED as u32 into the slot's own triangle (uint32_t*)K + slot *
+// slot_stride — every cell of it, so it needs no zero fill.
 __global__ __launch_bounds__(1024) void k_sx_consume(const uint32_t* list, const uint32_t* list_off, const uint32_t* owner_r0,
                                                      const uint32_t* part_base, uint32_t n_owners, uint32_t target, uint32_t cap,
                                                      int pb, u64* K, const uint32_t* tile_off, uint32_t tpg, u64 slot_stride) {
@@ -1090,12 +1099,13 @@ __global__ __launch_bounds__(1024) void k_sx_consume(const uint32_t* list, const
     const uint32_t tid = threadIdx.x;
     const uint32_t r = blockIdx.y;
     uint32_t o, a, b, nparts = 1u;
+    uint32_t* K32 = nullptr;  // by-slot form: the slot's triangle is a u32 array that this launch WRITES (no zero fill needed)
     if (slot_stride != 0) {
         o = blockIdx.x;
         const uint32_t slot = blockIdx.z;
         a = list_off[o] + tile_off[(size_t)slot * tpg * n_owners + o];
         b = slot + 1u < gridDim.z ? list_off[o] + tile_off[(size_t)(slot + 1u) * tpg * n_owners + o] : list_off[o + 1];
-        K += (u64)slot * slot_stride;
+        K32 = reinterpret_cast<uint32_t*>(K) + (u64)slot * slot_stride;
     } else {
         for (uint32_t i = tid; i <= n_owners; i += CS_THREADS) s_base[i] = part_base[i];
         __syncthreads();
@@ -1113,7 +1123,7 @@ __global__ __launch_bounds__(1024) void k_sx_consume(const uint32_t* list, const
         const uint32_t end = list_off[o + 1];
         b = end - a < target ? end : a + target;
     }
-    if (a == b) return;
+    if (a == b && !K32) return;
     const u64 c0 = tri_index((u64)owner_r0[o], 0), c1 = tri_index((u64)owner_r0[o + 1], 0);
     const uint32_t ncell = (uint32_t)(c1 - c0);
     const uint32_t lo = r * cap;
@@ -1137,6 +1147,10 @@ __global__ __launch_bounds__(1024) void k_sx_consume(const uint32_t* list, const
         if (x < span) atomicAdd(&cells[x], w & mask);
     }
     __syncthreads();
+    if (K32) {
+        for (uint32_t c = tid; c < span; c += CS_THREADS) K32[c0 + lo + c] = cells[c];
+        return;
+    }
     u64* dst = K + c0 + lo;
     if (nparts == 1u) {
         for (uint32_t c = tid; c < span; c += CS_THREADS) {
@@ -1220,26 +1234,39 @@ __global__ __launch_bounds__(256) void k_triangle(const SrcT* K, const double* d
 // its stop test and keeps the state of every iteration it has not yet accepted.
 // bsum[i / SQ_BLOCK] += prod (any order: only a PREDICTION of the running sum's binade is made from it).
 constexpr int SQ_BLOCK = 8192;
-__global__ __launch_bounds__(256) void k_welford(const u64* Ks, const double* K_hat_in, double* K_hat_out, double* prod, u64 pairs,
+constexpr int WF_ITEMS = 4;  // cells per thread: 1024 per workgroup, SQ_BLOCK / 1024 workgroups add to one block sum
+template <typename SrcT>
+__global__ __launch_bounds__(256) void k_welford(const SrcT* Ks, const double* K_hat_in, double* K_hat_out, double* prod, u64 pairs,
                                                  u64 train_pairs, double iter, double* bsum) {
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    __shared__ double part[4];
+    const u64 base = (u64)blockIdx.x * (256 * WF_ITEMS);
     double pr = 0.0;
-    if (i < pairs) {
-        const double x = (double)Ks[i];
-        const double old = K_hat_in[i];
-        const double delta = __dsub_rn(x, old);
-        const double kh = __dadd_rn(old, __ddiv_rn(delta, iter));
-        K_hat_out[i] = kh;
-        if (i < train_pairs) {
-            pr = __dmul_rn(delta, __dsub_rn(x, kh));
-            prod[i] = pr;
+#pragma unroll
+    for (int q = 0; q < WF_ITEMS; ++q) {
+        const u64 i = base + (u64)q * 256 + threadIdx.x;
+        if (i < pairs) {
+            const double x = (double)Ks[i];
+            const double old = K_hat_in[i];
+            const double delta = __dsub_rn(x, old);
+            const double kh = __dadd_rn(old, __ddiv_rn(delta, iter));
+            K_hat_out[i] = kh;
+            if (i < train_pairs) {
+                const double v = __dmul_rn(delta, __dsub_rn(x, kh));
+                prod[i] = v;
+                pr += v;
+            }
         }
     }
-    // a 64-lane group lies inside one SQ_BLOCK (8192 is a multiple of 64)
+    // (any order: the block sum only PREDICTS the running sum's binade; the 1024 cells of a workgroup lie
+    // inside one SQ_BLOCK)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) pr += __shfl_xor(pr, d);
-    const u64 first = ((u64)blockIdx.x * 256 + threadIdx.x) & ~(u64)63;
-    if ((threadIdx.x & 63) == 0 && first < train_pairs && pr != 0.0) atomicAdd(&bsum[first / SQ_BLOCK], pr);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = pr;
+    __syncthreads();
+    if (threadIdx.x == 0 && base < train_pairs) {
+        const double t = (part[0] + part[1]) + (part[2] + part[3]);
+        if (t != 0.0) atomicAdd(&bsum[base / SQ_BLOCK], t);
+    }
 }
 
 // ---- exact sequential summation, in parallel ---------------------------------------------------

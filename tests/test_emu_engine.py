@@ -387,6 +387,23 @@ def test_emu_sparse_pair_accumulation_variants(emu_lib, port, monkeypatch, globa
     assert e.stats()["cell_updates"] == U
 
 
+@pytest.mark.parametrize("env", [{"FSK_SPARSE_GLOBAL": "1"}, {"FSK_LIST_MAX_WORDS": "2000"}, {}])
+def test_emu_variance_mode_sparse_fallbacks(emu_lib, monkeypatch, env):
+    """Variance mode on the sparse dataflow: the iterations of a batch share one sparse pass (a u32
+    triangle per slot), unless no update streams exist (atomics) or a batch has too many update words
+    for one stream (then: one iteration at a time) — the three forms give the reference's stdevs."""
+    from fastsk_amd import _native
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    d = load_golden("f5_prot11_variance_T1_it9")
+    e = _native.Engine(d["g"], d["m"], t=d["t"], approx=True, delta=d["delta"], max_iters=d["max_iters"], path=2, lib=emu_lib)
+    e.set_combo_order(d["order"])
+    e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+    assert np.array_equal(e.get_stdevs(), d["stdevs"])
+    assert np.array_equal(e.get_triangle(), d["tri"])
+    e.close()
+
+
 @pytest.mark.parametrize("g,m,force", [(8, 4, None), (9, 4, None), (8, 4, "1"), (7, 5, "1")])
 def test_emu_key_compaction_rare_symbol(emu_lib, port, monkeypatch, g, m, force):
     """DNA with a few 'n': the 5^k key space is mostly empty; the dense dataflow counts only the

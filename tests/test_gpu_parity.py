@@ -660,6 +660,29 @@ def test_sequential_sum_on_the_device(native):
     e.close()
 
 
+@pytest.mark.parametrize("env", [{"FSK_SPARSE_GLOBAL": "1"}, {"FSK_LIST_MAX_WORDS": "200000"}, {}])
+def test_variance_mode_sparse_forms(native, monkeypatch, env):
+    """Variance mode through the sparse dataflow in its three forms (grouped batches with a u32 triangle
+    per slot; atomics; ungrouped after a batch too large for one stream): the reference's stdevs and
+    triangle, bit for bit, on the protein slice and on BASELINE config 1 at full size."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name in ("f5_prot11_variance_T1", "f7_cfg1_prot11_approx_t1"):
+        d = load_golden(name)
+        if "tokens" in d:
+            tokens, offsets, ntr, nte = d["tokens"], d["offsets"], d["n_train"], d["n_test"]
+        else:
+            tokens, offsets, ntr, nte, _, _ = load_tokens(d["data"])
+        e = engine_for(native, d, path=2)
+        e.compute(tokens, offsets, ntr, nte)
+        assert np.array_equal(e.get_stdevs(), d["stdevs"]), name
+        if "tri" in d:
+            assert np.array_equal(e.get_triangle(), d["tri"]), name
+        else:
+            assert sha(e.get_triangle()) == d["tri_sha256"], name
+        e.close()
+
+
 def test_skip_test_block(native, port):
     """skip_test_block=1: everything a getter of the reference exposes (train x train, test x train,
     hence every diagonal entry) is unchanged; tiles made of test x test cells only are not computed."""
