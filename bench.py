@@ -108,20 +108,23 @@ def cpu_baseline(g, m, L, n_full, budget_s, sizes=(4000, 8000)):
     KernelFunction::compute_kernel itself (thread pool, private uint32 triangles, locked reduce,
     normalisation) on T combos — approx/skip_variance/max_iters=1 makes every thread take exactly one
     combo, i.e. the budget is kept by trimming combos, never N. A row predicted (from the rows before
-    it: time ~ N^2 per combo, at least constant in T) not to fit the remaining budget is skipped and
-    says so."""
+    it: time ~ N^2 per combo, and no better than proportional to the combos) not to fit the remaining
+    budget is skipped and says so."""
     from oracle import loader
     phys, logical, model = host_cpus()
     kind = "reference" if loader.have_ref() else "port"
     ncomb = int(loader.port().num_combos(g, m))
-    rows, spent, per_unit = [], 0.0, None  # per_unit: seconds per (N^2 * round) of the slowest row so far
-    plan = [(n, t) for n in sizes for t in (20, phys)]
+    rows, spent, per_unit = [], 0.0, None  # per_unit: seconds per (N^2 * combo) of the slowest row so far
+    # T = 20 at both sizes first, then T = physical cores (measured on the 2 x 64-core EPYC 9575F of the GPU
+    # box: 128 threads take 7.4x as long as 20 for 6.4x the combos — the reference is memory-bound, more
+    # threads buy nothing — so the last row, N = 8000 at T = 128, needs ~200 s: profiles/ holds one full run)
+    plan = [(n, 20) for n in sizes] + [(n, phys) for n in sizes]
     for n, T in plan:
         T = max(1, min(T, ncomb))
         tokens, offsets, _ = synthetic(n, L)
         pairs = n * (n + 1) // 2
         need = T * pairs * 4 + pairs * 16 + n * L * 64
-        predicted = None if per_unit is None else per_unit * n * n
+        predicted = None if per_unit is None else per_unit * n * n * T
         row = {"n": n, "threads": T, "combos": T}
         if need > 0.6 * mem_available_bytes():
             row["skipped"] = "needs %.0f GB of host memory for %d private triangles" % (need / 1e9, T)
@@ -138,7 +141,7 @@ def cpu_baseline(g, m, L, n_full, budget_s, sizes=(4000, 8000)):
             spent += dt
             row.update(seconds=dt, combos_per_s=T / dt,
                        extrapolated_combos_per_s_at_full_n=T / dt * (n / n_full) ** 2)
-            per_unit = max(per_unit or 0.0, dt / (n * n))
+            per_unit = max(per_unit or 0.0, dt / (n * n * T))
         rows.append(row)
     done = [r for r in rows if "combos_per_s" in r]
     best = max(done, key=lambda r: (r["n"], r["combos_per_s"])) if done else None
@@ -230,7 +233,7 @@ def parse_args():
     ap.add_argument("--seq-len", type=int, default=300)
     ap.add_argument("-g", type=int, default=None)
     ap.add_argument("-m", type=int, default=None)
-    ap.add_argument("--cpu-seconds", type=float, default=60.0, help="budget of the CPU baseline (rows that do not fit are skipped)")
+    ap.add_argument("--cpu-seconds", type=float, default=100.0, help="budget of the CPU baseline (rows that do not fit are skipped)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra measurements of configs 1-4 (profiling runs)")
     ap.add_argument("--bands", type=int, default=None, help="row bands of the overlapped all-reduce (default: auto)")

@@ -269,14 +269,13 @@ bool dense_is_cheaper(const fsk_engine* e) {
     const double dense = 0.5 * N * N * (double)(((e->Vq + 1) / 2) * 8) / (N < 8192.0 ? 2.4e14 : 3.0e14) +
                          (double)e->nfeat * (1e-12 + (sweeps - 1.0) * sweep_cost) + N * V * 7e-13;
     // sparse: sort + segments per g-mer, then one update per (run, pair). d = sequences holding a
-    // given key. Owner-slice LDS accumulation (N <= 8192) runs at 4e10 updates/s on short runs
-    // and up to 2.4e11 on long ones (partner ranges become contiguous reads); per-pair global
-    // atomics at 1.6e10. Sort + segments: 3.5e-11 s per g-mer.
+    // given key. Update streams summed in LDS by the owner bands (N up to ~23,000): 1.7e11 updates/s
+    // through emit + consume, a band with several LDS rounds re-reads its stream once per round;
+    // per-pair global atomics beyond that: 1.6e10/s. Extraction + sort + segments: 3.1e-11 s per g-mer.
     const double d = N * (1.0 - std::exp(-W / V));
     const double U = V * d * (d + 1.0) / 2.0;
-    const bool owner_slices = N <= 8192.0;
-    const double rate = owner_slices ? 4.0e10 * std::min(6.0, std::max(1.0, d / 4.0)) : 1.6e10;
-    const double sparse = U / rate + (double)e->nfeat * 3.5e-11;
+    const double rate = e->sx_lists ? 1.7e11 / (1.0 + 0.3 * ((double)e->sx_rounds - 1.0)) : 1.6e10;
+    const double sparse = U / rate + (double)e->nfeat * 3.1e-11;
     return dense <= sparse;
 }
 

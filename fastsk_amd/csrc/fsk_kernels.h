@@ -1460,32 +1460,43 @@ __global__ __launch_bounds__(64) void k_seq_chain(const double* p, u64 n, const 
     blk += (size_t)blockIdx.x * nblocks;
     bsum += (size_t)blockIdx.x * nblocks;
     out += blockIdx.x;
+    // the running sum is kept either as a double s, or — between accepted blocks of one binade — as the
+    // integer S = s / 2^(e-52) in [2^52, 2^53), so that an accepted block is one 64-bit add and a compare
     double s = 0.0;
+    bool as_int = false;
+    int e = 0;
+    u64 S = 0;
     for (uint32_t c0 = 0; c0 < nblocks; c0 += 64) {
-        // 64 block records at a time, one per lane, handed round with shuffles (no dependent loads in the chain)
+        // 64 block records at a time, one per lane, handed round with scalar reads (no dependent loads in the chain)
         SeqBlk mine;
         mine.e = 0; mine.flags = 8u; mine.Q = 0;
         if (c0 + lane < nblocks) mine = blk[c0 + lane];
         const uint32_t cn = nblocks - c0 < 64u ? nblocks - c0 : 64u;
         for (uint32_t j = 0; j < cn; ++j) {
-            const int ke = (int)wave_bcast_u32((uint32_t)mine.e, j);
             const uint32_t kf = wave_bcast_u32(mine.flags, j);
-            const u64 kq = wave_bcast_u64(mine.Q, j);
             if (kf & 16u) continue;  // all zeros
-            bool done = false;
-            if (kf == 0u && seq_exponent(s) == ke && s > 0.0) {
-                const u64 tot = (u64)(s * seq_pow2(52 - ke)) + kq;
-                if (tot < ((u64)1 << 53)) {
-                    s = (double)tot * seq_pow2(ke - 52);
-                    done = true;
+            if (kf == 0u) {
+                const int ke = (int)wave_bcast_u32((uint32_t)mine.e, j);
+                const u64 kq = wave_bcast_u64(mine.Q, j);
+                if (!as_int && s > 0.0 && seq_exponent(s) == ke) {
+                    e = ke;
+                    S = (u64)(s * seq_pow2(52 - e));
+                    as_int = true;
+                }
+                if (as_int && e == ke && S + kq < ((u64)1 << 53)) {
+                    S += kq;
+                    continue;
                 }
             }
-            if (!done) {
-                const u64 lo = (u64)(c0 + j) * SQ_BLOCK, hi = lo + SQ_BLOCK < n ? lo + SQ_BLOCK : n;
-                s = seq_range(p, lo, hi, s);
+            if (as_int) {
+                s = (double)S * seq_pow2(e - 52);
+                as_int = false;
             }
+            const u64 lo = (u64)(c0 + j) * SQ_BLOCK, hi = lo + SQ_BLOCK < n ? lo + SQ_BLOCK : n;
+            s = seq_range(p, lo, hi, s);
         }
     }
+    if (as_int) s = (double)S * seq_pow2(e - 52);
     if (lane == 0) out[0] = s;
     for (uint32_t b = lane; b < nblocks; b += 64) bsum[b] = 0.0;
 }

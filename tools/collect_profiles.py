@@ -65,10 +65,24 @@ def main():
                "kernel_files": kernel_hashes(), "commit": commit + ("+uncommitted csrc changes" if dirty else ""),
                "source": "profiles/%s_pmc_bench100k.json (the 495-combo launch): FETCH_SIZE KiB x1024 x2 (gfx950 correction) + "
                          "WRITE_SIZE KiB x1024" % TAG}, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
-    for src, dst in (("configs.jsonl", TAG + "_configs1-4_gpu_timings.jsonl"), ("large_g.jsonl", TAG + "_large_g_regime.jsonl")):
+    for src, dst in (("configs.jsonl", TAG + "_configs1-4_gpu_timings.jsonl"), ("large_g.jsonl", TAG + "_large_g_regime.jsonl"),
+                     ("n_series.jsonl", TAG + "_n_series.jsonl"), ("bench_config4.json", TAG + "_bench_config4.json"),
+                     ("bench_rccl_world1.json", TAG + "_bench_rccl_world1.json")):
+        if not os.path.exists(os.path.join(SRC, src)):
+            continue
         lines = [l for l in open(os.path.join(SRC, src)) if l.startswith("{")]
         if lines:
             open(os.path.join(DST, dst), "w").writelines(lines)
+    try:
+        shutil.copy(newest(os.path.join(SRC, "stats_configs", "*", "*_kernel_stats.csv")), os.path.join(DST, TAG + "_kernel_stats_configs1-4.csv"))
+    except ValueError:
+        pass
+    for tag, dst in ((TAG + "_cfg4", TAG + "_pmc_sparse_config4.json"), (TAG + "_cfg1", TAG + "_pmc_sparse_config1.json")):
+        src = os.path.join(ROOT, "gpurun_out", "pmc", tag, "summary.json")
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(DST, dst))
+    if os.path.exists(os.path.join(SRC, "ubench_mfma_i8.txt")):
+        shutil.copy(os.path.join(SRC, "ubench_mfma_i8.txt"), os.path.join(DST, TAG + "_ubench_mfma_i8_vs_dot8.txt"))
     print("profiles/ refreshed from", SRC)
 
 
