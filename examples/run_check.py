@@ -42,8 +42,9 @@ def main():
     clf = CalibratedClassifierCV(LinearSVC(C=1), cv=5).fit(Ktr, Ytrain)
     acc = clf.score(Kte, np.array(Ytest))
     auc = roc_auc_score(Ytest, clf.predict_proba(Kte)[:, 1])
-    print("Linear SVM:\n\tAcc = {}, AUC = {}".format(acc, auc))
-    assert auc >= 0.9, "AUC is not correct. Should be >= 0.9. Received: {}".format(auc)
+    print("calibrated linear SVM on the kernel rows: accuracy %.4f, test AUC %.4f" % (acc, auc))
+    if auc < 0.9:  # the reference's acceptance threshold (test/run_check.py:64)
+        raise SystemExit("test AUC %.4f is below 0.9" % auc)
 
 
 if __name__ == "__main__":

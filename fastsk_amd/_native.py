@@ -60,18 +60,37 @@ SYMBOLS = ["fsk_create", "fsk_destroy", "fsk_last_error", "fsk_abi_version", "fs
 _hip_shared = False
 
 
+def _mapped_runtimes():
+    """Paths of the libamdhip64 / libhsa-runtime64 images mapped into this process."""
+    found = {}
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(None, 1)[-1]
+                base = os.path.basename(path)
+                for stem in ("libamdhip64.so", "libhsa-runtime64.so"):
+                    if base.startswith(stem):
+                        found.setdefault(stem, set()).add(path)
+    except OSError:
+        pass
+    return found
+
+
 def share_hip_runtime_with_torch():
     """One HIP runtime per process. A PyTorch-ROCm wheel carries its own libamdhip64 /
     libhsa-runtime64; if this engine binds /opt/rocm's copy first and torch is imported later, the
     process ends up with two HSA runtimes and the second one to initialise finds no GPU. So when
-    torch is installed but not imported yet, its copies (same SONAMEs) are loaded first and the
-    engine binds to them — exactly what happens anyway when torch is imported before this package.
+    torch is installed but not imported yet, and no HIP runtime is mapped yet (a profiler's preload, an
+    earlier import), its copies (same SONAMEs) are loaded first and the engine binds to them —
+    exactly what happens anyway when torch is imported before this package.
     No torch installed: nothing to do, /opt/rocm's runtime is used."""
     global _hip_shared
     if _hip_shared or "torch" in sys.modules:
         _hip_shared = True
         return
     _hip_shared = True
+    if _mapped_runtimes():
+        return  # a runtime is already in the process: loading torch's copy by path would add a second image
     try:
         import importlib.util
         spec = importlib.util.find_spec("torch")
@@ -86,6 +105,17 @@ def share_hip_runtime_with_torch():
         pass
 
 
+def check_single_hip_runtime():
+    """Warn when two different libamdhip64 images ended up in the process (e.g. a torch wheel built
+    against another ROCm major: different SONAME, so the preload above cannot unify them)."""
+    images = _mapped_runtimes().get("libamdhip64.so", set())
+    real = {os.path.realpath(p) for p in images}
+    if len(real) > 1:
+        import warnings
+        warnings.warn("two HIP runtimes are mapped into this process (%s): the engine and torch will not see the same "
+                      "GPU state; import torch before fastsk_amd, or use a torch wheel built for this ROCm" % ", ".join(sorted(real)))
+
+
 class Library:
     """The loaded shared library with typed entry points."""
 
@@ -98,6 +128,8 @@ class Library:
                 "%s not found: build the HIP engine first (python -c 'import __graft_entry__ as g; g.build()'). "
                 "fastsk_amd has no CPU fallback." % path)
         L = C.CDLL(path)
+        if path == LIB_PATH:
+            check_single_hip_runtime()
         self.path = path
         vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
         sig = {

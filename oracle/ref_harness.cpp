@@ -13,9 +13,9 @@
 //                         whole normalised triangle incl. the never-exposed test x test block
 //   ref_raw_counts        replay of fastsk_kernel.cpp:216-241 per combo with the reference's own
 //                         extractFeatures / getCombinations / cntsrtna / countAndUpdateTri,
-//                         summing the uint32 partial kernels (the API itself only returns fp64)
-//   ref_timed_counts      same, timed, T threads round-robin (fastsk_kernel.cpp:148,275) for the
-//                         cpu_baseline leg of bench.py ("kind": "reference")
+//                         summing the uint32 partial kernels (the API itself only returns fp64);
+//                         T threads round-robin (fastsk_kernel.cpp:148,275), returns the seconds
+// (bench.py's cpu_baseline times ref_full_triangle: the reference's own thread pool and reduce)
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
