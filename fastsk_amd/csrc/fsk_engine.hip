@@ -156,6 +156,8 @@ struct fsk_engine {
     int force_global_pairs = 0;  // FSK_SPARSE_GLOBAL=1: per-pair global atomics (testing)
     u64 sx_max_words = (u64)1 << 31;  // update words per batch beyond which the pairs go to K with atomics (FSK_LIST_MAX_WORDS: testing)
     int tile_dma = 1;            // FSK_TILE_DMA=0: register-staged tile kernel instead of the direct-to-LDS one (testing)
+    int compact_dma = 0;         // FSK_COMPACT_DMA=1: direct-to-LDS k_dense_tile_dma_compact for key-compacted panels (measured slower on
+                                 // config 3: its flagged rows take the generic remainder, not k_dense_tile_compact's side-aware one)
 
     fsk_stats st{};
 
@@ -786,7 +788,10 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
             }
         }
         e->tic();
-        if (compact)
+        if (compact && e->compact_dma)
+            FSK_LAUNCH(fsk::k_dense_tile_dma_compact, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C4.p, e->d_C4H.p,
+                       e->d_rowmask.p, e->d_tiletab.p, nb, Vq8, nst, (uint32_t)e->N, K, slots_per_split, 0, (const uint16_t*)e->d_vc.p);
+        else if (compact)
             FSK_LAUNCH(fsk::k_dense_tile_compact, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C4.p,
                        e->d_C4H.p, e->d_rowmask.p, e->d_tiletab.p, nb, Vq8, nst, (uint32_t)e->N, K, slots_per_split,
                        (const uint16_t*)e->d_vc.p);
@@ -1139,6 +1144,7 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     { const char* f = getenv("FSK_LIST_MAX_WORDS"); if (f && atoll(f) > 0) e->sx_max_words = std::min<u64>(SX_MAX_LIST_WORDS, (u64)atoll(f)); }
     { const char* f = getenv("FSK_TILE_SPLITS"); e->force_splits = f ? atoi(f) : 0; }
     { const char* f = getenv("FSK_TILE_DMA"); e->tile_dma = f ? atoi(f) : 1; }
+    { const char* f = getenv("FSK_COMPACT_DMA"); e->compact_dma = f ? atoi(f) : 0; }
     { const char* f = getenv("FSK_DENSE_CHUNK"); e->force_chunk = f ? (uint32_t)atoi(f) : 0u; }
     if (hipStreamCreate(&e->stream) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
         hipEventCreate(&e->ev1) != hipSuccess) {

@@ -409,7 +409,16 @@ __global__ __launch_bounds__(64) void k_dense_distinct(const uint32_t* C4, const
 #include "fsk_tile_kernel.inc"
 #undef FSK_TILE_KERNEL
 #undef FSK_TILE_COMPACT
+#define FSK_DMA_KERNEL k_dense_tile_dma
+#define FSK_DMA_COMPACT 0
 #include "fsk_tile_kernel_dma.inc"
+#undef FSK_DMA_KERNEL
+#undef FSK_DMA_COMPACT
+#define FSK_DMA_KERNEL k_dense_tile_dma_compact
+#define FSK_DMA_COMPACT 1
+#include "fsk_tile_kernel_dma.inc"
+#undef FSK_DMA_KERNEL
+#undef FSK_DMA_COMPACT
 
 // =============================================================================================
 // SPARSE PATH — the reference's dataflow (gather -> sort -> run-length -> K +=), as streams
