@@ -138,9 +138,9 @@ struct fsk_engine {
     bool prep_valid = false, prep_overflow = false;
     // sparse scratch
     DevBuf<unsigned char> d_keys[2];      // packed sort records (u32 or u64), double-buffered
-    DevBuf<uint32_t> d_blockhist, d_totals, d_tile_ent, d_ebase, d_Pk, d_owner_r0, d_ucount, d_uchunk, d_utot, d_list_off, d_ulist, d_part_base;
+    DevBuf<uint32_t> d_blockhist, d_totals, d_tile_ent, d_ebase, d_Pk, d_Tk, d_owner_r0, d_ucount, d_uchunk, d_utot, d_list_off, d_ulist, d_part_base;
     DevBuf<u64> d_tile_stat;
-    DevBuf<int> d_tile_lrh, d_tile_rs;
+    DevBuf<int> d_tile_lrh, d_tile_rs, d_tile_lth, d_tile_ts;
     DevBuf<uint2> d_E;                    // entries: {sequence, multiplicity}
     DevBuf<u64> d_sxstat, d_U;
     std::vector<uint32_t> h_owner_r0;     // owner bands of K: rows [r0[o], r0[o+1])
@@ -359,6 +359,14 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     FSK_HIP(e->d_ebase.reserve((size_t)ntiles + 1));
     FSK_HIP(e->d_E.reserve(nrec));
     FSK_HIP(e->d_Pk.reserve(nrec));
+    // skip_test_block: test rows pair only with the train entries of their runs (and themselves)
+    const uint32_t skip_from = e->cfg.skip_test_block && e->n_test > 0 ? (uint32_t)e->n_train : 0xffffffffu;
+    const bool skipping = skip_from != 0xffffffffu;
+    if (skipping) {
+        FSK_HIP(e->d_Tk.reserve(nrec));
+        FSK_HIP(e->d_tile_lth.reserve(ntiles));
+        FSK_HIP(e->d_tile_ts.reserve(ntiles));
+    }
     FSK_HIP(e->d_sxstat.reserve(2));
     FSK_HIP(e->d_tile_stat.reserve((size_t)2 * ntiles));
     FSK_HIP(e->d_pos.reserve((size_t)nb * e->k));
@@ -411,12 +419,13 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     const uint32_t maxprod = (1u << e->sx_pb) - 1u;
     const uint32_t cmax = maxprod / std::max<uint32_t>(1u, e->maxW);  // multiplicities up to here: one word per pair
     FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_seg_count<RecT>), dim3(tpg, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tpg, sb,
-               e->d_tile_ent.p, e->d_tile_lrh.p);
+               e->d_tile_ent.p, e->d_tile_lrh.p, skip_from, skipping ? e->d_tile_lth.p : (int*)nullptr);
     FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(1), dim3(256), 0, e->stream, e->d_tile_ent.p, e->d_tile_lrh.p, ntiles, e->d_ebase.p,
-               e->d_tile_rs.p);
+               e->d_tile_rs.p, skipping ? (const int*)e->d_tile_lth.p : (const int*)nullptr, skipping ? e->d_tile_ts.p : (int*)nullptr);
     FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_seg_write<RecT>), dim3(tpg, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tpg, sb,
                e->d_ebase.p, e->d_tile_rs.p, e->d_E.p, e->d_Pk.p, e->sx_own_shift, O,
-               lists ? e->d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->d_tile_stat.p);
+               lists ? e->d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->d_tile_stat.p,
+               skip_from, skipping ? (const int*)e->d_tile_ts.p : (const int*)nullptr, skipping ? e->d_Tk.p : (uint32_t*)nullptr);
     FSK_LAUNCH(fsk::k_sx_stat_sum, dim3(32), dim3(256), 0, e->stream, (const u64*)e->d_tile_stat.p, ntiles, e->d_sxstat.p);
     e->st.launches += 4;
     u64 words = 0;
@@ -440,9 +449,12 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     if (use_lists) {
         if (words > 0 || slot_stride != 0) {
             FSK_HIP(e->d_ulist.reserve((size_t)std::max<u64>(1, words)));
-            FSK_LAUNCH(fsk::k_sx_emit<false>, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
+            // (function pointers: a template-id with a comma cannot pass through the launch macro)
+            auto k_emit = skipping ? fsk::k_sx_emit<false, true> : fsk::k_sx_emit<false, false>;
+            FSK_LAUNCH(k_emit, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
                        (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)e->d_list_off.p,
-                       (const uint32_t*)e->d_ucount.p, e->d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg, slot_stride);
+                       (const uint32_t*)e->d_ucount.p, e->d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
+                       slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr);
             const size_t lds = (size_t)e->sx_cap * sizeof(uint32_t);
 #ifndef FSK_EMU
             FSK_HIP(hipFuncSetAttribute((const void*)fsk::k_sx_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -465,9 +477,11 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             e->st.launches += 2;
         }
     } else {
-        FSK_LAUNCH(fsk::k_sx_emit<true>, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
+        auto k_emit = skipping ? fsk::k_sx_emit<true, true> : fsk::k_sx_emit<true, false>;
+        FSK_LAUNCH(k_emit, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
                    (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)nullptr,
-                   (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg, slot_stride);
+                   (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
+                   slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr);
         e->st.launches += 1;
     }
     e->toc(&e->st.ms_pairs);
@@ -1167,7 +1181,7 @@ void fsk_destroy(fsk_engine* e) {
     for (int b = 0; b < 2; ++b) e->d_keys[b].release();
     e->d_blockhist.release(); e->d_totals.release(); e->d_tile_ent.release(); e->d_ebase.release(); e->d_Pk.release();
     e->d_owner_r0.release(); e->d_ucount.release(); e->d_uchunk.release(); e->d_part_base.release(); e->d_tile_stat.release(); e->d_utot.release(); e->d_list_off.release(); e->d_ulist.release();
-    e->d_tile_lrh.release(); e->d_tile_rs.release(); e->d_E.release(); e->d_sxstat.release(); e->d_U.release(); e->d_U2.release();
+    e->d_tile_lrh.release(); e->d_tile_rs.release(); e->d_tile_lth.release(); e->d_tile_ts.release(); e->d_Tk.release(); e->d_E.release(); e->d_sxstat.release(); e->d_U.release(); e->d_U2.release();
     if (e->h_prod) (void)hipHostFree(e->h_prod);
     if (e->ev_order) (void)hipEventDestroy(e->ev_order);
     if (e->chain_stream) { (void)hipStreamSynchronize(e->chain_stream); (void)hipStreamDestroy(e->chain_stream); }

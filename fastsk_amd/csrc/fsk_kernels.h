@@ -688,25 +688,31 @@ __global__ __launch_bounds__(256) void k_sx_scatter(const RecT* in, RecT* out, u
 // Inside a slot, record j starts an ENTRY when it differs from record j-1 (new k-mer or new sequence)
 // and a RUN when its k-mer differs; j = 0 starts both. Thread t of a tile looks at SG_ITEMS
 // consecutive records.
+// skip_from (skip_test_block): sequences >= skip_from are test sequences. Inside a run the entries are
+// in sequence order, train entries first; the first test entry of a run is a TEST HEAD. tile_lth gets the
+// tile-local index of the tile's last test head (only when skip_from != 0xffffffff).
 template <typename RecT>
 __global__ __launch_bounds__(256) void k_sx_seg_count(const RecT* rec, uint32_t nfeat, uint32_t tpg, int sb, uint32_t* tile_ent,
-                                                      int* tile_lrh) {
+                                                      int* tile_lrh, uint32_t skip_from, int* tile_lth) {
     __shared__ uint32_t tmp[4];
-    __shared__ int s_lrh;
+    __shared__ int s_lrh, s_lth;
     const uint32_t tid = threadIdx.x, t = blockIdx.x, slot = blockIdx.y;
     const RecT* r = rec + (size_t)slot * nfeat;
     const uint32_t j0 = t * (uint32_t)SG_TILE + tid * (uint32_t)SG_ITEMS;
-    if (tid == 0) s_lrh = -1;
+    if (tid == 0) { s_lrh = -1; s_lth = -1; }
+    const RecT seq_mask = (RecT)(((u64)1 << sb) - 1);
     RecT prev = (j0 > 0 && j0 <= nfeat) ? r[j0 - 1] : (RecT)0;
     uint32_t n = 0;
-    int lrh = -1;  // among this thread's entries, the last one that starts a run
+    int lrh = -1, lth = -1;  // among this thread's entries, the last one that starts a run / is a test head
 #pragma unroll
     for (int q = 0; q < SG_ITEMS; ++q) {
         const uint32_t j = j0 + (uint32_t)q;
         if (j < nfeat) {
             const RecT cur = r[j];
             if (j == 0 || cur != prev) {
-                if (j == 0 || (cur >> sb) != (prev >> sb)) lrh = (int)n;
+                const bool run_head = j == 0 || (cur >> sb) != (prev >> sb);
+                if (run_head) lrh = (int)n;
+                if ((uint32_t)(cur & seq_mask) >= skip_from && (run_head || (uint32_t)(prev & seq_mask) < skip_from)) lth = (int)n;
                 ++n;
             }
             prev = cur;
@@ -715,22 +721,25 @@ __global__ __launch_bounds__(256) void k_sx_seg_count(const RecT* rec, uint32_t 
     uint32_t tot;
     const uint32_t ex = block_excl_scan_256<uint32_t>(n, tmp, &tot);
     if (lrh >= 0) atomicMax(&s_lrh, (int)ex + lrh);
+    if (lth >= 0) atomicMax(&s_lth, (int)ex + lth);
     __syncthreads();
     if (tid == 0) {
         tile_ent[(size_t)slot * tpg + t] = tot;
         tile_lrh[(size_t)slot * tpg + t] = s_lrh;  // tile-local index of the last entry that starts a run, or -1
+        if (tile_lth) tile_lth[(size_t)slot * tpg + t] = s_lth;
     }
 }
 
 // single workgroup: ebase[tile] = entries before the tile (ebase[ntiles] = D); tile_rs[tile] = global
-// index of the last run start before the tile (the run the tile's first entries may continue)
+// index of the last run start before the tile (the run the tile's first entries may continue);
+// tile_ts[tile] = likewise the last test head before the tile (skip_test_block only)
 __global__ __launch_bounds__(256) void k_sx_seg_scan(const uint32_t* tile_ent, const int* tile_lrh, uint32_t ntiles, uint32_t* ebase,
-                                                     int* tile_rs) {
+                                                     int* tile_rs, const int* tile_lth, int* tile_ts) {
     __shared__ uint32_t tmp[4];
     __shared__ int tmpi[4];
     const uint32_t tid = threadIdx.x;
     uint32_t carry = 0;
-    int carry_h = -1;
+    int carry_h = -1, carry_t = -1;
     for (uint32_t base = 0; base < ntiles; base += 256) {
         const uint32_t i = base + tid;
         const uint32_t v = i < ntiles ? tile_ent[i] : 0u;
@@ -743,6 +752,14 @@ __global__ __launch_bounds__(256) void k_sx_seg_scan(const uint32_t* tile_ent, c
         if (i < ntiles) {
             ebase[i] = ex;
             tile_rs[i] = hx > carry_h ? hx : carry_h;
+        }
+        if (tile_lth) {  // (uniform)
+            const int lt = i < ntiles ? tile_lth[i] : -1;
+            const int th = lt >= 0 ? (int)ex + lt : -1;
+            int ttot;
+            const int tx = block_excl_maxscan_256(th, tmpi, &ttot);
+            if (i < ntiles) tile_ts[i] = tx > carry_t ? tx : carry_t;
+            if (ttot > carry_t) carry_t = ttot;
         }
         carry += tot;
         if (htot > carry_h) carry_h = htot;
@@ -766,11 +783,16 @@ __device__ __forceinline__ uint32_t sx_words_per_pair(uint32_t count, uint32_t c
 // Entries of one tile: E (sequence, multiplicity), Pk (rank in run), and — unless `ucount` is null —
 // the number of update words the tile will emit per owner band, ucount[tile][owner].
 // stats[0] += pairs (the reference's `+=` count U), stats[1] += update words.
+// skip_test_block (skip_from != 0xffffffff): Tk[e] = how many of the P partners of entry e, counted from
+// the run start, it really pairs with before itself: all P - 1 for a train row; for a test row only the
+// run's train entries (test x test cells other than the diagonal are left alone) — P minus its rank among
+// the run's test entries. An entry then has Tk + 1 partners: Tk from the run start, and itself.
 template <typename RecT>
 __global__ __launch_bounds__(256) void k_sx_seg_write(const RecT* rec, uint32_t nfeat, uint32_t tpg, int sb, const uint32_t* ebase,
                                                       const int* tile_rs, uint2* E, uint32_t* Pk, int own_shift, uint32_t n_owners,
                                                       uint32_t* ucount, uint32_t row0, uint32_t row1, uint32_t max_win,
-                                                      uint32_t maxprod, uint32_t cmax, u64* tile_stat) {
+                                                      uint32_t maxprod, uint32_t cmax, u64* tile_stat, uint32_t skip_from,
+                                                      const int* tile_ts, uint32_t* Tk) {
     __shared__ uint32_t tmp[4];
     __shared__ int tmpi[4];
     __shared__ __attribute__((aligned(8))) uint32_t s_pos[SG_TILE + 2];
@@ -786,8 +808,9 @@ __global__ __launch_bounds__(256) void k_sx_seg_write(const RecT* rec, uint32_t 
     if (ucount)
         for (uint32_t i = tid; i < n_owners; i += 256) s_cnt[i] = 0u;
     RecT cur[SG_ITEMS];
-    uint32_t eh = 0, rh = 0, n = 0;
-    int lrh = -1;
+    uint32_t eh = 0, rh = 0, th = 0, n = 0;
+    int lrh = -1, lth = -1;
+    const RecT seq_mask = (RecT)(((u64)1 << sb) - 1);
     {
         RecT prev = (j0 > 0 && j0 <= nfeat) ? r[j0 - 1] : (RecT)0;
 #pragma unroll
@@ -797,7 +820,12 @@ __global__ __launch_bounds__(256) void k_sx_seg_write(const RecT* rec, uint32_t 
             if (j < nfeat) {
                 if (j == 0 || cur[q] != prev) {
                     eh |= 1u << q;
-                    if (j == 0 || (cur[q] >> sb) != (prev >> sb)) { rh |= 1u << q; lrh = (int)n; }
+                    const bool run_head = j == 0 || (cur[q] >> sb) != (prev >> sb);
+                    if (run_head) { rh |= 1u << q; lrh = (int)n; }
+                    if ((uint32_t)(cur[q] & seq_mask) >= skip_from && (run_head || (uint32_t)(prev & seq_mask) < skip_from)) {
+                        th |= 1u << q;
+                        lth = (int)n;
+                    }
                     ++n;
                 }
                 prev = cur[q];
@@ -819,19 +847,33 @@ __global__ __launch_bounds__(256) void k_sx_seg_write(const RecT* rec, uint32_t 
     const uint32_t ex = block_excl_scan_256<uint32_t>(n, tmp, &n_tile);
     // tile-local index of the run start that governs this thread's first entries (-1: before the tile)
     int head = block_excl_maxscan_256(lrh >= 0 ? (int)ex + lrh : -1, tmpi, nullptr);
+    const bool skipping = skip_from != 0xffffffffu;  // (uniform)
+    int thead = -1;
+    if (skipping) thead = block_excl_maxscan_256(lth >= 0 ? (int)ex + lth : -1, tmpi, nullptr);
     const uint32_t eb = ebase[tile];
     const int before = tile_rs[tile];
-    const RecT seq_mask = (RecT)(((u64)1 << sb) - 1);
+    const int before_t = skipping ? tile_ts[tile] : -1;
     {
         uint32_t e = ex;
 #pragma unroll
         for (int q = 0; q < SG_ITEMS; ++q) {
             if (eh & (1u << q)) {
                 if (rh & (1u << q)) head = (int)e;
+                if (th & (1u << q)) thead = (int)e;
                 const uint32_t rs = head >= 0 ? eb + (uint32_t)head : (uint32_t)before;
+                const uint32_t seq = (uint32_t)(cur[q] & seq_mask);
+                const uint32_t P = eb + e - rs + 1u;
                 s_pos[e] = tid * (uint32_t)SG_ITEMS + (uint32_t)q;
-                s_P[e] = eb + e - rs + 1u;
-                s_ent[e].x = (uint32_t)(cur[q] & seq_mask);
+                s_P[e] = P;
+                s_ent[e].x = seq;
+                // partners before itself: everything from the run start (train row), or only the run's train
+                // entries = P - (rank among the run's test entries)
+                uint32_t T = P - 1u;
+                if (seq >= skip_from) {
+                    const uint32_t ts = thead >= 0 ? eb + (uint32_t)thead : (uint32_t)before_t;
+                    T = P - (eb + e - ts + 1u);
+                }
+                s_ent[e].y = T;  // (parked here until the multiplicity is known)
                 ++e;
             }
         }
@@ -840,12 +882,13 @@ __global__ __launch_bounds__(256) void k_sx_seg_write(const RecT* rec, uint32_t 
     u64 pairs = 0, words = 0;
     for (uint32_t e = tid; e < n_tile; e += 256) {
         const uint32_t c = (e + 1 < n_tile ? s_pos[e + 1] : s_end) - s_pos[e];
-        const uint32_t seq = s_ent[e].x, P = s_P[e];
+        const uint32_t seq = s_ent[e].x, P = s_P[e], T = s_ent[e].y;
         E[(size_t)eb + e] = make_uint2(seq, c);
         Pk[(size_t)eb + e] = P;
+        if (Tk) Tk[(size_t)eb + e] = T;
         if (seq >= row0 && seq < row1) {
-            const u64 w = (u64)P * sx_words_per_pair(c, cmax, max_win, maxprod);
-            pairs += P;
+            const u64 w = (u64)(T + 1u) * sx_words_per_pair(c, cmax, max_win, maxprod);
+            pairs += T + 1u;
             words += w;
             if (ucount) atomicAdd(&s_cnt[sx_owner_of(seq, own_shift)], (uint32_t)w);
         }
@@ -938,14 +981,17 @@ __global__ __launch_bounds__(256) void k_sx_ucol_apply(uint32_t* ucount, uint32_
 // DIRECT: 64-bit atomicAdd per pair straight into K instead of update words.
 constexpr int EM_THREADS = 512, EM_WAVES = EM_THREADS / 64;
 constexpr uint32_t EM_STAGE = (uint32_t)EM_THREADS * SX_SHORT;  // one short entry per thread and round
-template <bool DIRECT>
+template <bool DIRECT, bool SKIP>
 __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const uint32_t* Pk, const uint32_t* ebase,
                                                         const uint32_t* owner_r0, int own_shift, uint32_t n_owners,
                                                         const uint32_t* list_off, const uint32_t* tile_off, uint32_t* list,
                                                         uint32_t row0, uint32_t row1, uint32_t max_win, uint32_t maxprod,
-                                                        uint32_t cmax, int pb, u64* K, uint32_t tpg, u64 slot_stride) {
+                                                        uint32_t cmax, int pb, u64* K, uint32_t tpg, u64 slot_stride,
+                                                        const uint32_t* Tk) {
     __shared__ uint2 s_ent[SG_TILE];
     __shared__ uint32_t s_P[SG_TILE];
+    // partners before the entry itself, from its run's start: P - 1 unless skip_test_block (SKIP)
+    __shared__ uint32_t s_T[SKIP ? SG_TILE : 1];
     __shared__ uint32_t s_r0[SX_MAX_OWNERS + 1];
     __shared__ uint32_t s_cur[SX_MAX_OWNERS];   // next free word of this tile's share of each owner's stream
     __shared__ uint32_t s_cnt[SX_MAX_OWNERS];
@@ -967,17 +1013,22 @@ __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const ui
     }
     for (uint32_t e = tid; e < n; e += EM_THREADS) {
         s_ent[e] = E[(size_t)e0 + e];
-        s_P[e] = Pk[(size_t)e0 + e];
+        const uint32_t P = Pk[(size_t)e0 + e];
+        s_P[e] = P;
+        if (SKIP) s_T[e] = Tk[(size_t)e0 + e];
     }
     if (tid == 0) s_nlong = 0u;
     __syncthreads();
     // partner `ge` of an entry: the tile's own entries sit in LDS, a run that started before the tile
     // continues in global memory
 #define SX_PARTNER(ge) ((ge) >= e0 ? s_ent[(ge) - e0] : E[(ge)])
+    // partner number b (0 .. T) of tile-local entry el: the run's first T entries, then the entry itself
+#define SX_NPART(el) (SKIP ? s_T[el] + 1u : s_P[el])
+#define SX_PARTNER_OF(el, b) SX_PARTNER((!SKIP || (b) < s_T[el]) ? e0 + (el) - s_P[el] + 1u + (b) : e0 + (el))
     // entries with many partners (or a product that needs several words): one wave each, below
     for (uint32_t e = tid; e < n; e += EM_THREADS) {
         const uint2 a = s_ent[e];
-        if (a.x >= row0 && a.x < row1 && (s_P[e] > SX_SHORT || (!DIRECT && sx_words_per_pair(a.y, cmax, max_win, maxprod) > 1u)))
+        if (a.x >= row0 && a.x < row1 && (SX_NPART(e) > SX_SHORT || (!DIRECT && sx_words_per_pair(a.y, cmax, max_win, maxprod) > 1u)))
             s_long[atomicAdd(&s_nlong, 1u)] = (uint16_t)e;
     }
     // ---- short entries, one per thread and round
@@ -988,14 +1039,14 @@ __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const ui
         uint32_t P = 0, my_o = 0, my_pos = 0;
         if (e < n) {
             a = s_ent[e];
-            P = s_P[e];
+            P = SX_NPART(e);  // partners of this entry
             mine = a.x >= row0 && a.x < row1 && P <= SX_SHORT && (DIRECT || sx_words_per_pair(a.y, cmax, max_win, maxprod) == 1u);
         }
         if (DIRECT) {
             if (mine) {
                 u64* row = K + tri_index((u64)a.x, 0);
                 for (uint32_t b = 0; b < P; ++b) {
-                    const uint2 pq = SX_PARTNER(e0 + e - P + 1u + b);
+                    const uint2 pq = SX_PARTNER_OF(e, b);
                     atomicAdd(&row[pq.x], (u64)a.y * pq.y);
                 }
             }
@@ -1031,7 +1082,7 @@ __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const ui
             const uint32_t t = slot_ent[i];
             const uint32_t el = rb + t;
             const uint2 ea = s_ent[el];
-            const uint2 pq = SX_PARTNER(e0 + el - s_P[el] + 1u + (i - ent_at[t]));
+            const uint2 pq = SX_PARTNER_OF(el, i - ent_at[t]);
             list[ent_delta[t] + i] = ((ent_cbase[t] + pq.x) << pb) | (ea.y * pq.y);
         }
         __syncthreads();
@@ -1044,11 +1095,11 @@ __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const ui
     for (uint32_t q = wave; q < nlong; q += EM_WAVES) {
         const uint32_t e = s_long[q];
         const uint2 a = s_ent[e];
-        const uint32_t P = s_P[e];
+        const uint32_t P = SX_NPART(e);
         if (DIRECT) {
             u64* row = K + tri_index((u64)a.x, 0);
             for (uint32_t b = lane; b < P; b += 64) {
-                const uint2 pq = SX_PARTNER(e0 + e - P + 1u + b);
+                const uint2 pq = SX_PARTNER_OF(e, b);
                 atomicAdd(&row[pq.x], (u64)a.y * pq.y);
             }
         } else {
@@ -1062,7 +1113,7 @@ __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const ui
             for (uint32_t tr = 0; tr < trips; ++tr) {
                 const uint32_t b = tr * 64u + lane;
                 if (b < P) {
-                    const uint2 pq = SX_PARTNER(e0 + e - P + 1u + b);
+                    const uint2 pq = SX_PARTNER_OF(e, b);
                     u64 prod = (u64)a.y * pq.y;
                     for (uint32_t w = 0; w < S; ++w) {
                         const uint32_t part = prod < maxprod ? (uint32_t)prod : maxprod;
@@ -1073,6 +1124,8 @@ __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const ui
             }
         }
     }
+#undef SX_PARTNER_OF
+#undef SX_NPART
 #undef SX_PARTNER
 }
 

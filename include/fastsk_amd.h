@@ -68,7 +68,8 @@ typedef struct fsk_config {
     int32_t skip_test_block; /* 1: cells with both sequences in the test set (other than the diagonal)
                                 may be left at zero — no getter of the reference exposes them
                                 (fastsk.cpp:190-217). Dense dataflow: whole tiles of such cells
-                                are not computed; the sparse dataflow computes everything.     */
+                                are not computed; sparse dataflow: a test row pairs only with the
+                                train sequences of its k-mer runs (and itself).                 */
     int32_t reserved[4];
 } fsk_config;
 

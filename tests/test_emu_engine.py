@@ -255,6 +255,27 @@ def test_emu_skip_test_block(emu_lib, port):
     got = tri_to_square(e.get_counts(), N)
     assert not got[300, 130] and not got[399, 255] and got[300, 290] and got[399, 399]
     e.close()
+    # sparse dataflow: a test row pairs only with the train entries of its runs and with itself —
+    # exactly the test x test cells off the diagonal stay zero (also in row bands, also with atomics)
+    raw, _, _ = port.raw_counts(tokens, offsets, 7, 4, np.arange(35, dtype=np.int32), threads=4)
+    ref = tri_to_square(raw, N).astype(np.int64)
+    i, j = np.tril_indices(N, -1)
+    tt = j >= ntr
+    for bands in (False, True):
+        e = _native.Engine(7, 4, path=2, lib=emu_lib, skip_test_block=True)
+        e.load_sequences(tokens, offsets, ntr, N - ntr)
+        if bands:
+            for lo, hi in ((0, 128), (128, 384), (384, N)):
+                e.accumulate_rows(np.arange(35, dtype=np.int32), lo, hi)
+        else:
+            e.accumulate(np.arange(35, dtype=np.int32))
+        e.finalize()
+        got = tri_to_square(e.get_counts(), N).astype(np.int64)
+        assert np.array_equal(np.diag(got), np.diag(ref))
+        assert not got[i[tt], j[tt]].any() and ref[i[tt], j[tt]].any()
+        assert np.array_equal(got[i[~tt], j[~tt]], ref[i[~tt], j[~tt]])
+        assert np.array_equal(e.get_train(), sq[:ntr, :ntr]) and np.array_equal(e.get_test(), sq[ntr:, :ntr])
+        e.close()
 
 
 def test_emu_relabelled_and_wide_alphabets(emu_lib, port):

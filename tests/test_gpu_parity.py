@@ -712,6 +712,40 @@ def test_skip_test_block(native, port):
         e.close()
 
 
+@pytest.mark.parametrize("global_pairs", ["0", "1"])
+def test_skip_test_block_sparse(native, port, monkeypatch, global_pairs):
+    """skip_test_block=1 on the sparse dataflow: a test row pairs only with the train entries of its k-mer
+    runs and with itself, so exactly the test x test cells off the diagonal stay zero and everything a
+    getter of the reference exposes is unchanged — update streams and atomics, whole and in row bands."""
+    monkeypatch.setenv("FSK_SPARSE_GLOBAL", global_pairs)
+    X = protein_like(1400, 40, 160, seed=21)
+    N, ntr, g, m = len(X), 500, 10, 6
+    tokens, offsets = native.flatten(X)
+    combos = np.arange(0, 210, 7, dtype=np.int32)
+    raw, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=8)
+    ref = tri_to_square(raw, N).astype(np.int64)
+    i, j = np.tril_indices(N, -1)
+    tt = j >= ntr
+    for bands in (False, True):
+        e = native.Engine(g, m, path=2, skip_test_block=True)
+        e.load_sequences(tokens, offsets, ntr, N - ntr)
+        if bands:
+            for lo, hi in ((0, 384), (384, 1024), (1024, N)):
+                e.accumulate_rows(combos, lo, hi)
+        else:
+            e.accumulate(combos)
+        e.finalize()
+        got = tri_to_square(e.get_counts(), N).astype(np.int64)
+        assert np.array_equal(np.diag(got), np.diag(ref))
+        assert not got[i[tt], j[tt]].any() and ref[i[tt], j[tt]].any()
+        assert np.array_equal(got[i[~tt], j[~tt]], ref[i[~tt], j[~tt]])
+        assert e.stats()["cell_updates"] < U   # fewer `+=` than the reference issues
+        dg = np.diag(ref).astype(np.float64)
+        want_test = ref[ntr:, :ntr] / np.sqrt(dg[ntr:, None] * dg[None, :ntr])
+        assert np.array_equal(e.get_test(), want_test)
+        e.close()
+
+
 def test_device_resident_block_getter(native):
     """fsk_get_block_device: the normalised block straight into a torch tensor on the GPU."""
     d = load_golden("f4_ep300_exact")
