@@ -345,6 +345,8 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     while (keybits < 62 && ((u64)1 << keybits) < (u64)e->V) ++keybits;
     const int sb = e->sx_sb;
     const int passes = (keybits + 7) / 8;
+    const int nbits = (keybits + passes - 1) / passes;  // the k-mer bits split evenly: 19 bits sort as 7 + 6 + 6, not 8 + 8 + 3
+    const uint32_t dmask = (1u << nbits) - 1u;
     const uint32_t tps = (nfeat + fsk::SX_TILE - 1) / fsk::SX_TILE;   // sort tiles per slot
     const uint32_t tpg = (nfeat + fsk::SG_TILE - 1) / fsk::SG_TILE;   // segment tiles per slot
     const uint32_t ntiles = tpg * (uint32_t)nb;
@@ -394,20 +396,20 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
 
     e->tic();
     FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_extract<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, e->view(), e->d_featseq.p,
-               e->d_fstart.p, nfeat, tps, e->k, e->sigma, sb, e->d_pos.p, rec[0], e->d_blockhist.p);
+               e->d_fstart.p, nfeat, tps, e->k, e->sigma, sb, e->d_pos.p, rec[0], e->d_blockhist.p, dmask);
     e->toc(&e->st.ms_extract);
     e->st.launches += 1;
 
     e->tic();
     int cur = 0;
     for (int p = 0; p < passes; ++p) {
-        const int shift = sb + 8 * p;
+        const int shift = sb + nbits * p;
         if (p > 0)  // (the extraction counted the first pass's digits)
-            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_hist<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tps, shift,
+            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_hist<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tps, shift, dmask,
                        e->d_blockhist.p);
         FSK_LAUNCH(fsk::k_sx_scan_slot, dim3(nb), dim3(1024), 0, e->stream, e->d_blockhist.p, tps, e->d_totals.p);
         FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_scatter<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, rec[cur], rec[cur ^ 1], nfeat,
-                   tps, shift, e->d_blockhist.p, e->d_totals.p);
+                   tps, shift, nbits, e->d_blockhist.p, e->d_totals.p);
         cur ^= 1;
         e->st.launches += 3;
     }

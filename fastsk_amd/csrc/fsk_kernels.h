@@ -479,11 +479,11 @@ __device__ __forceinline__ int block_excl_maxscan_256(int v, int* tmp, int* tota
 }
 
 // rec = (k-mer << sb) | sequence id, one per (slot, g-mer), and the first sort pass's digit histogram
-// of the tile (blockhist[slot][tile][digit], digit = bits sb..sb+7); grid = (sort tiles per slot, slots)
+// of the tile (blockhist[slot][tile][digit], digit = the lowest k-mer bits under dmask); grid = (sort tiles per slot, slots)
 template <typename RecT>
 __global__ __launch_bounds__(256) void k_sx_extract(SeqView S, const uint32_t* feat_seq, const uint32_t* fstart, uint32_t nfeat, uint32_t tps,
                                                     int k, uint32_t sigma, int sb, const uint8_t* combo_pos, RecT* rec,
-                                                    uint32_t* blockhist) {
+                                                    uint32_t* blockhist, uint32_t dmask) {
     __shared__ uint32_t h[256];
     __shared__ uint8_t s_pos[16];
     const uint32_t tid = threadIdx.x, tile = blockIdx.x, slot = blockIdx.y;
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void k_sx_extract(SeqView S, const uint32_t* f
             u64 key = 0;
             for (int c = 0; c < k; ++c) key = key * sigma + fetch_sym(S.words, wbase, j + pos[c], S.bits);
             rec[(size_t)slot * nfeat + f] = (RecT)((key << sb) | (u64)seq);
-            atomicAdd(&h[(uint32_t)key & 255u], 1u);
+            atomicAdd(&h[(uint32_t)key & dmask], 1u);
         }
     }
     __syncthreads();
@@ -511,7 +511,8 @@ __global__ __launch_bounds__(256) void k_sx_extract(SeqView S, const uint32_t* f
 
 // digit histogram of one tile of one slot -> blockhist[slot][tile][digit]; grid = (tiles per slot, slots)
 template <typename RecT>
-__global__ __launch_bounds__(256) void k_sx_hist(const RecT* rec, uint32_t nfeat, uint32_t tps, int shift, uint32_t* blockhist) {
+__global__ __launch_bounds__(256) void k_sx_hist(const RecT* rec, uint32_t nfeat, uint32_t tps, int shift, uint32_t dmask,
+                                                 uint32_t* blockhist) {
     __shared__ uint32_t h[256];
     const uint32_t tid = threadIdx.x, tile = blockIdx.x, slot = blockIdx.y;
     h[tid] = 0u;
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(256) void k_sx_hist(const RecT* rec, uint32_t nfeat
 #pragma unroll
     for (int it = 0; it < SX_ITEMS; ++it) {
         const uint32_t i = base + (uint32_t)it * 256u + tid;
-        if (i < nfeat) atomicAdd(&h[(uint32_t)(r[i] >> shift) & 255u], 1u);
+        if (i < nfeat) atomicAdd(&h[(uint32_t)(r[i] >> shift) & dmask], 1u);
     }
     __syncthreads();
     blockhist[((size_t)slot * tps + tile) * 256u + tid] = h[tid];
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(256) void k_scan_totals(const uint32_t* totals_in, 
 // and meet at ONE barrier; the records are then permuted into digit order in LDS and written out
 // so that equal digits go to consecutive addresses. grid = (tiles per slot, slots)
 template <typename RecT>
-__global__ __launch_bounds__(256) void k_sx_scatter(const RecT* in, RecT* out, uint32_t nfeat, uint32_t tps, int shift,
+__global__ __launch_bounds__(256) void k_sx_scatter(const RecT* in, RecT* out, uint32_t nfeat, uint32_t tps, int shift, int nbits,
                                                     const uint32_t* blockhist, const uint32_t* dbase) {
     __shared__ uint32_t goff[256];         // destination, inside the slot, of this tile's first record of each digit
     __shared__ uint32_t wave_run[4][256];  // per wave: records of the digit so far; later: where the wave's share starts in LDS
@@ -618,6 +619,7 @@ __global__ __launch_bounds__(256) void k_sx_scatter(const RecT* in, RecT* out, u
     __shared__ RecT s_rec[SX_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t tile = blockIdx.x, slot = blockIdx.y;
+    const uint32_t dmask = (1u << nbits) - 1u;
     const RecT* r = in + (size_t)slot * nfeat;
     RecT* o = out + (size_t)slot * nfeat;
     goff[tid] = dbase[(size_t)slot * 256u + tid] + blockhist[((size_t)slot * tps + tile) * 256u + tid];
@@ -638,13 +640,15 @@ __global__ __launch_bounds__(256) void k_sx_scatter(const RecT* in, RecT* out, u
         const uint32_t i = base + (uint32_t)it * 64u + (uint32_t)lane;
         const bool valid = i < nfeat;
         key[it] = valid ? r[i] : (RecT)0;
-        const uint32_t digit = (uint32_t)(key[it] >> shift) & 255u;
+        const uint32_t digit = (uint32_t)(key[it] >> shift) & dmask;
         u64 peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-            const bool bit = (digit >> b) & 1u;
-            const u64 m = __ballot(bit);
-            peers &= bit ? m : ~m;
+            if (b < nbits) {  // (uniform) a pass sorts nbits <= 8 bits: the k-mer bits are split evenly over the passes
+                const bool bit = (digit >> b) & 1u;
+                const u64 m = __ballot(bit);
+                peers &= bit ? m : ~m;
+            }
         }
         const uint32_t rank_in_wave = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
         const uint32_t prior = valid ? my_run[digit] : 0u;
@@ -666,7 +670,7 @@ __global__ __launch_bounds__(256) void k_sx_scatter(const RecT* in, RecT* out, u
 #pragma unroll
     for (int it = 0; it < SX_ITEMS; ++it) {
         if (rank[it] != 0xffffffffu) {
-            const uint32_t digit = (uint32_t)(key[it] >> shift) & 255u;
+            const uint32_t digit = (uint32_t)(key[it] >> shift) & dmask;
             s_rec[wave_run[wave][digit] + rank[it]] = key[it];
         }
     }
@@ -678,7 +682,7 @@ __global__ __launch_bounds__(256) void k_sx_scatter(const RecT* in, RecT* out, u
         const uint32_t p = (uint32_t)it * 256u + (uint32_t)tid;
         if (p < nvalid) {
             const RecT kx = s_rec[p];
-            const uint32_t digit = (uint32_t)(kx >> shift) & 255u;
+            const uint32_t digit = (uint32_t)(kx >> shift) & dmask;
             o[goff[digit] + (p - blk_start[digit])] = kx;
         }
     }
@@ -997,9 +1001,10 @@ __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const ui
     __shared__ uint32_t s_cnt[SX_MAX_OWNERS];
     __shared__ uint32_t s_seg[SX_MAX_OWNERS];
     // a round's update words in owner order: slot -> the thread (entry) it belongs to; per entry: its
-    // first slot, the cell of column 0 of its row inside the owner band, and (address in the stream) - slot
+    // first slot, the cell of column 0 of its row inside the owner band, (address in the stream) - slot
+    // and the global index of its first partner (one 16-byte LDS read per word)
     __shared__ uint16_t slot_ent[EM_STAGE];
-    __shared__ uint32_t ent_at[EM_THREADS], ent_cbase[EM_THREADS], ent_delta[EM_THREADS];
+    __shared__ uint4 ent_info[EM_THREADS];  // {first slot, cell of column 0, address - slot, index of the first partner}
     __shared__ uint16_t s_long[SG_TILE];
     __shared__ uint32_t s_nlong, s_total;
     __shared__ uint32_t tmp[EM_WAVES];
@@ -1069,9 +1074,8 @@ __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const ui
         __syncthreads();
         if (mine) {
             const uint32_t at = s_seg[my_o] + my_pos;
-            ent_at[tid] = at;
-            ent_cbase[tid] = (uint32_t)(tri_index((u64)a.x, 0) - tri_index((u64)s_r0[my_o], 0));
-            ent_delta[tid] = s_cur[my_o] - s_seg[my_o];
+            ent_info[tid] = make_uint4(at, (uint32_t)(tri_index((u64)a.x, 0) - tri_index((u64)s_r0[my_o], 0)), s_cur[my_o] - s_seg[my_o],
+                                       e0 + e - s_P[e] + 1u);
             for (uint32_t b = 0; b < P; ++b) slot_ent[at + b] = (uint16_t)tid;
         }
         __syncthreads();
@@ -1081,9 +1085,11 @@ __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const ui
         for (uint32_t i = tid; i < total; i += EM_THREADS) {
             const uint32_t t = slot_ent[i];
             const uint32_t el = rb + t;
-            const uint2 ea = s_ent[el];
-            const uint2 pq = SX_PARTNER_OF(el, i - ent_at[t]);
-            list[ent_delta[t] + i] = ((ent_cbase[t] + pq.x) << pb) | (ea.y * pq.y);
+            const uint4 inf = ent_info[t];
+            const uint32_t b = i - inf.x;
+            const uint32_t ge = (!SKIP || b < s_T[el]) ? inf.w + b : e0 + el;
+            const uint2 pq = SX_PARTNER(ge);
+            list[inf.z + i] = ((inf.y + pq.x) << pb) | (s_ent[el].y * pq.y);
         }
         __syncthreads();
         if (tid < n_owners) s_cur[tid] += s_cnt[tid];
