@@ -214,6 +214,20 @@ void enumerate_combos(int g, int k, std::vector<uint8_t>& out) {
     }
 }
 
+// host-side helpers of fsk_load_sequences: contiguous ranges of [0, n) on a few threads
+int host_threads_for(int64_t work_items) {
+    if (work_items < ((int64_t)1 << 21)) return 1;
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(8u, hw ? hw : 1u));
+}
+template <typename F>
+void parallel_ranges(int64_t n, int nt, F&& fn) {
+    if (nt <= 1) { fn(0, (int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { fn(t, n * t / nt, n * (t + 1) / nt); });
+    for (auto& x : th) x.join();
+}
+
 uint64_t splitmix64(uint64_t& s) {
     uint64_t z = (s += 0x9E3779B97F4A7C15ull);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -450,7 +464,8 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     if (slot_stride != 0 && !use_lists) return FSK_RETRY_UNGROUPED;  // (nothing of this batch has touched K yet)
     if (use_lists) {
         if (words > 0 || slot_stride != 0) {
-            FSK_HIP(e->d_ulist.reserve((size_t)std::max<u64>(1, words)));
+            if ((size_t)words > e->d_ulist.cap)  // (grown with headroom: the batches of a pass differ by a few percent)
+                FSK_HIP(e->d_ulist.reserve((size_t)std::max<u64>(1, words + words / 4)));
             // (function pointers: a template-id with a comma cannot pass through the launch macro)
             auto k_emit = skipping ? fsk::k_sx_emit<false, true> : fsk::k_sx_emit<false, false>;
             FSK_LAUNCH(k_emit, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
@@ -1247,10 +1262,23 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
     {
         tok_hist.assign(65536, 0);
         bool small = true;
-        for (int64_t i = 0; i < total; ++i) {
-            const uint32_t t = (uint32_t)tokens[i];
-            if (t < 65536u) tok_hist[t]++;
-            else { small = false; break; }
+        {   // (a few host threads: at 100k x 300 tokens this scan and the packing below are the load time)
+            const int nt = host_threads_for(total);
+            std::vector<std::vector<int64_t>> part((size_t)nt);
+            std::vector<char> ok((size_t)nt, 1);
+            parallel_ranges(total, nt, [&](int t, int64_t lo, int64_t hi) {
+                std::vector<int64_t>& h = part[(size_t)t];
+                h.assign(65536, 0);
+                for (int64_t i = lo; i < hi; ++i) {
+                    const uint32_t v = (uint32_t)tokens[i];
+                    if (v < 65536u) h[v]++;
+                    else { ok[(size_t)t] = 0; break; }
+                }
+            });
+            for (int t = 0; t < nt; ++t) {
+                if (!ok[(size_t)t]) small = false;
+                for (int v = 0; v < 65536; ++v) tok_hist[(size_t)v] += part[(size_t)t][(size_t)v];
+            }
         }
         if (small) {
             for (int32_t v = 0; v < 65536; ++v)
@@ -1307,22 +1335,24 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
             for (size_t r = 0; r < distinct.size(); ++r) sym_freq[r] = tok_hist[(size_t)distinct[r]];
             const uint32_t per_word = 32u / (uint32_t)bits;
             const uint8_t* lt = lut.data();
-            for (int64_t i = 0; i < N; ++i) {
-                const int32_t* sq = tokens + (offsets[i] - off0);
-                uint32_t* w = words.data() + wstart[i];
-                const uint32_t len = len32[i];
-                uint32_t p = 0;
-                for (; p + per_word <= len; p += per_word) {
-                    uint32_t word = 0;
-                    for (uint32_t q = 0; q < per_word; ++q) word |= (uint32_t)lt[sq[p + q] - base] << (q * (uint32_t)bits);
-                    *w++ = word;
+            parallel_ranges(N, host_threads_for(total), [&](int, int64_t s_lo, int64_t s_hi) {  // a sequence's words are its own
+                for (int64_t i = s_lo; i < s_hi; ++i) {
+                    const int32_t* sq = tokens + (offsets[i] - off0);
+                    uint32_t* w = words.data() + wstart[i];
+                    const uint32_t len = len32[i];
+                    uint32_t p = 0;
+                    for (; p + per_word <= len; p += per_word) {
+                        uint32_t word = 0;
+                        for (uint32_t q = 0; q < per_word; ++q) word |= (uint32_t)lt[sq[p + q] - base] << (q * (uint32_t)bits);
+                        *w++ = word;
+                    }
+                    if (p < len) {
+                        uint32_t word = 0;
+                        for (uint32_t q = 0; p + q < len; ++q) word |= (uint32_t)lt[sq[p + q] - base] << (q * (uint32_t)bits);
+                        *w = word;
+                    }
                 }
-                if (p < len) {
-                    uint32_t word = 0;
-                    for (uint32_t q = 0; p + q < len; ++q) word |= (uint32_t)lt[sq[p + q] - base] << (q * (uint32_t)bits);
-                    *w = word;
-                }
-            }
+            });
         } else {
             for (int64_t i = 0; i < N; ++i) {
                 const int32_t* sq = tokens + (offsets[i] - off0);

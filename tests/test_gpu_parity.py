@@ -176,6 +176,31 @@ def test_low_complexity_counts_above_255(native, port):
         e.close()
 
 
+@pytest.mark.parametrize("global_pairs", ["0", "1"])
+def test_sparse_products_beyond_one_update_word(native, port, monkeypatch, global_pairs):
+    """Sparse dataflow with multiplicities so large that a product does not fit the product field of a
+    32-bit update word (a 1500-long homopolymer and a long dinucleotide repeat among 300 ordinary
+    sequences: multiplicity x max windows ~ 2.2e6 > 2^18): such entries spend several words per pair."""
+    monkeypatch.setenv("FSK_SPARSE_GLOBAL", global_pairs)
+    rng = np.random.default_rng(8)
+    X = [rng.integers(1, 6, size=int(L)).astype(np.int32) for L in rng.integers(12, 90, size=300)]
+    X[17] = np.full(1500, 3, dtype=np.int32)
+    X[201] = np.array([1, 2] * 600, dtype=np.int32)
+    X[202] = np.concatenate([np.full(700, 3, dtype=np.int32), rng.integers(1, 6, size=40).astype(np.int32)])
+    tokens, offsets = native.flatten(X)
+    g, m = 10, 6
+    combos = np.arange(0, 210, 10, dtype=np.int32)
+    want, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=8)
+    for ntr in (300, 180):
+        e = native.Engine(g, m, path=2)
+        e.load_sequences(tokens, offsets, ntr, 300 - ntr)
+        e.accumulate(combos)
+        e.finalize()
+        assert np.array_equal(e.get_counts(), want)
+        assert e.stats()["cell_updates"] == U
+        e.close()
+
+
 def diag_by_definition(X, rows, g, m):
     """K_ii = sum over combos and k-mers v of cnt_i(combo, v)^2, straight from the definition
     (SURVEY section 0), for the given rows of a fixed-length token matrix with tokens 1..4."""

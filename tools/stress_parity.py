@@ -50,6 +50,18 @@ def main(iters=150, seed=0):
             e.finalize()
             res[name] = (e.get_counts(), e.get_triangle())
             e.close()
+        if N - ntr > 0:  # skip_test_block on the sparse dataflow: exactly the test x test cells off the diagonal stay zero
+            os.environ["FSK_SPARSE_GLOBAL"] = "0" if it % 2 else "1"
+            e = _native.Engine(g, m, path=2, skip_test_block=True)
+            e.load_sequences(tokens, offsets, ntr, N - ntr)
+            e.accumulate(combos)
+            e.finalize()
+            got = e.get_counts()
+            e.close()
+            i, j = np.tril_indices(N)
+            masked = res["sparse"][0].copy()
+            masked[(j >= ntr) & (i != j)] = 0
+            assert np.array_equal(got, masked), (it, "skip_test_block", sigma, g, m, N, hi, ntr)
         names = list(res)
         for n in names[1:]:
             assert np.array_equal(res[names[0]][0], res[n][0]), (it, "counts", names[0], n, sigma, g, m, N, hi)
