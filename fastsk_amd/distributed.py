@@ -111,7 +111,7 @@ def accumulate_owned_rows(eng, K, combos, group=None, replicate=False, n_sub=Non
     if narrow is None:
         narrow = len(combos) * eng.stats()["max_windows"] ** 2 < 2 ** 31
     subs = [sub_edges(edges[r], edges[r + 1], n_sub) for r in range(world)]
-    stream = _torch_stream(K)
+    side = _side_stream(K)
     pending = []
 
     def drain(keep):
@@ -124,25 +124,27 @@ def accumulate_owned_rows(eng, K, combos, group=None, replicate=False, n_sub=Non
     for k in range(max(len(s) for s in subs) - 1):
         if k < len(subs[rank]) - 1:
             eng.accumulate_rows(combos, subs[rank][k], subs[rank][k + 1])
-            if stream is None:
+            if side is None:
                 eng.synchronize()
             else:
-                eng.stream_wait_engine(stream)  # the sub-band is final before its broadcast reads it
-        for r in range(world):  # same order on every rank
-            if k >= len(subs[r]) - 1:
-                continue
-            seg = K[cell(subs[r][k]):cell(subs[r][k + 1])]
-            seg32 = None
-            if narrow:
-                seg32 = seg.to(torch.int32) if r == rank else torch.empty(seg.shape, dtype=torch.int32, device=K.device)
-            src = dist.get_global_rank(group, r) if group is not None else r
-            work = dist.broadcast(seg32 if narrow else seg, src=src, group=group, async_op=True)
-            pending.append((work, seg, seg32, r == rank))
-        drain(2 * world)
-    drain(0)
-    if stream is not None:
-        eng.engine_wait_stream(stream)
-        torch.cuda.synchronize(K.device)
+                eng.stream_wait_engine(side.cuda_stream)  # the sub-band is final before its broadcast reads it
+        with _on(side):
+            for r in range(world):  # same order on every rank
+                if k >= len(subs[r]) - 1:
+                    continue
+                seg = K[cell(subs[r][k]):cell(subs[r][k + 1])]
+                seg32 = None
+                if narrow:
+                    seg32 = seg.to(torch.int32) if r == rank else torch.empty(seg.shape, dtype=torch.int32, device=K.device)
+                src = dist.get_global_rank(group, r) if group is not None else r
+                work = dist.broadcast(seg32 if narrow else seg, src=src, group=group, async_op=True)
+                pending.append((work, seg, seg32, r == rank))
+            drain(2 * world)
+    with _on(side):
+        drain(0)
+    if side is not None:
+        eng.engine_wait_stream(side.cuda_stream)
+        side.synchronize()
     eng.synchronize()
     return lo, hi
 
@@ -163,11 +165,39 @@ def get_block_distributed(eng, i0, i1, j0, j1, group=None, device=None):
     return blk
 
 
-def _torch_stream(K):
-    """Raw hipStream_t of torch's current stream on K's device (what RCCL collectives are ordered
-    after), or None for a host tensor."""
+_side_streams = {}
+
+
+def _side_stream(K):
+    """A torch stream of its own for the exchange (narrowing copies, RCCL collectives — ordered behind
+    the stream they are issued on — and widening copies): torch's default stream is HIP's legacy
+    stream, which serialises against every other blocking stream, the engine's included; on a side
+    stream the copies run under the engine's tile kernels (VALU-bound: the HBM bandwidth is free).
+    None for a host tensor."""
     import torch
-    return torch.cuda.current_stream(K.device).cuda_stream if K.is_cuda else None
+    if not K.is_cuda:
+        return None
+    key = (K.device.type, K.device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=K.device)
+    return _side_streams[key]
+
+
+class _on:
+    """`with _on(stream):` = torch.cuda.stream(stream), or nothing for a host tensor."""
+
+    def __init__(self, stream):
+        self.stream, self.ctx = stream, None
+
+    def __enter__(self):
+        if self.stream is not None:
+            import torch
+            self.ctx = torch.cuda.stream(self.stream)
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
 
 
 def accumulate_and_reduce(eng, K, combos, group=None, n_bands=None, narrow=None, n_combos_total=None, force=False):
@@ -191,31 +221,33 @@ def accumulate_and_reduce(eng, K, combos, group=None, n_bands=None, narrow=None,
         total = n_combos_total if n_combos_total is not None else eng.lib.num_combos(eng.g, eng.m)
         narrow = total * eng.stats()["max_windows"] ** 2 < 2 ** 31
     edges = band_edges(N, n_bands)
-    stream = _torch_stream(K)
+    side = _side_stream(K)
     pending = []
 
     def drain(keep):
         while len(pending) > keep:
             work, seg, seg32 = pending.pop(0)
-            work.wait()
+            work.wait()  # (the current stream waits, not the host)
             if seg32 is not None:
                 seg.copy_(seg32)  # widen back into the uint64 triangle
 
     for lo, hi in zip(edges[:-1], edges[1:]):
         eng.accumulate_rows(combos, lo, hi)
-        if stream is None:
+        if side is None:
             eng.synchronize()
         else:
-            eng.stream_wait_engine(stream)  # the band is final before anything torch / RCCL does to it
-        seg = K[cell(lo):cell(hi)]
-        seg32 = seg.to(torch.int32) if narrow else None
-        work = dist.all_reduce(seg32 if narrow else seg, op=dist.ReduceOp.SUM, group=group, async_op=True)
-        pending.append((work, seg, seg32))
-        drain(2)
-    drain(0)
-    if stream is not None:
-        eng.engine_wait_stream(stream)  # the engine's next pass starts after the reduced cells are in place
-        torch.cuda.synchronize(K.device)
+            eng.stream_wait_engine(side.cuda_stream)  # the band is final before anything torch / RCCL does to it
+        with _on(side):
+            seg = K[cell(lo):cell(hi)]
+            seg32 = seg.to(torch.int32) if narrow else None
+            work = dist.all_reduce(seg32 if narrow else seg, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            pending.append((work, seg, seg32))
+            drain(2)
+    with _on(side):
+        drain(0)
+    if side is not None:
+        eng.engine_wait_stream(side.cuda_stream)  # the engine's next pass starts after the reduced cells are in place
+        side.synchronize()
     eng.synchronize()  # (fills rows a reset left for a storing launch that never came: none on this path)
 
 
