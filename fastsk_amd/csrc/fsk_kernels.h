@@ -1115,7 +1115,19 @@ __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const ui
             if (lane == 0) at = atomicAdd(&s_cur[o], P * S);
             at = __shfl(at, 0);
             const uint32_t cbase = (uint32_t)(tri_index((u64)a.x, 0) - tri_index((u64)s_r0[o], 0));
-            const uint32_t trips = (P + 63u) / 64u;  // same for every lane: the shuffle above needs all of them
+            if (S == 1u && !SKIP) {
+                // the common case, kept lean (long runs make this loop most of the kernel): partner b is
+                // entry first + b — in LDS from `split` on, in global memory before — one word each
+                uint32_t* dst = list + at;
+                const uint32_t first = e0 + e - P + 1u;                 // global index of partner 0
+                const uint32_t split = first < e0 ? e0 - first : 0u;    // partners before the tile
+                for (uint32_t b = lane; b < P; b += 64u) {
+                    const uint2 pq = b >= split ? s_ent[first - e0 + b] : E[first + b];
+                    dst[b] = ((cbase + pq.x) << pb) | (a.y * pq.y);
+                }
+                continue;
+            }
+            const uint32_t trips = (P + 63u) / 64u;
             for (uint32_t tr = 0; tr < trips; ++tr) {
                 const uint32_t b = tr * 64u + lane;
                 if (b < P) {
