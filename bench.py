@@ -468,7 +468,7 @@ def main():
             alg_gbs = alg_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0
             fam = {"extract": d("ms_extract"), "sort": d("ms_sort"), "segment": d("ms_segment"), "pairs": d("ms_pairs")}
             roofline = {
-                "bound": "hbm", "kernel": "sparse pipeline (k_sparse_extract + k_rs_* + k_seg_* + pair accumulation); largest family: %s" % max(fam, key=fam.get),
+                "bound": "hbm", "kernel": "sparse pipeline (k_sx_extract, k_sx_hist/scan_slot/scatter, k_sx_seg_*, k_sx_emit + k_sx_consume); largest family: %s" % max(fam, key=fam.get),
                 "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS, "traffic": None,
                 "traffic_source": "not collected in this run (profiles/ holds the rocprofv3 --pmc passes of the sparse kernels)",
                 "algorithmic_bytes_per_step": alg_bytes, "cell_updates_per_step": U, "gpu_ms_per_step": gpu_ms,

@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64) void k_dense_distinct(const uint32_t* C4, const
 //   k_sx_extract   one packed record per (slot, g-mer): rec = (k-mer << sb) | sequence id, u32 when
 //                  that fits 32 bits (every BASELINE config) else u64; slot s owns rec[s*nfeat ..):
 //                  the slot is implicit in the position, so B independent sorts run in one launch.
-//   k_sx_hist / k_rs_scan_rows / k_sx_scatter   stable LSD radix sort over the k-mer bits only
+//   k_sx_hist / k_sx_scan_slot / k_sx_scatter   stable LSD radix sort over the k-mer bits only
 //                  (records are generated in sequence order and every pass is stable), 8-bit digits,
 //                  4096-record tiles ranked with wave64 ballot matching, permuted in LDS and written
 //                  out in digit runs.
@@ -559,33 +559,6 @@ __global__ __launch_bounds__(1024) void k_sx_scan_slot(uint32_t* blockhist, uint
     }
     const uint32_t ex = block_excl_scan<uint32_t, 16>(quarter == 0 ? total : 0u, tmp, nullptr);
     if (quarter == 0) dbase[(size_t)slot * 256u + digit] = ex;
-}
-
-// one workgroup per row: exclusive scan of the row in place, row total to totals[row]
-__global__ __launch_bounds__(256) void k_rs_scan_rows(uint32_t* blockhist, uint32_t nblocks, uint32_t* totals) {
-    __shared__ uint32_t tmp[4];
-    uint32_t* row = blockhist + (size_t)blockIdx.x * nblocks;
-    const int tid = threadIdx.x;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < nblocks; base += 1024) {
-        uint32_t v[4], s = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t i = base + (uint32_t)tid * 4u + q;
-            v[q] = i < nblocks ? row[i] : 0u;
-            s += v[q];
-        }
-        uint32_t tot;
-        uint32_t ex = block_excl_scan_256<uint32_t>(s, tmp, &tot) + carry;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t i = base + (uint32_t)tid * 4u + q;
-            if (i < nblocks) row[i] = ex;
-            ex += v[q];
-        }
-        carry += tot;
-    }
-    if (tid == 0) totals[blockIdx.x] = carry;
 }
 
 // exclusive scan of n totals (single workgroup), off[n] = grand total
