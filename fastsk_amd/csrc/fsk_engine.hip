@@ -436,7 +436,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     const uint32_t cmax = maxprod / std::max<uint32_t>(1u, e->maxW);  // multiplicities up to here: one word per pair
     FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_seg_count<RecT>), dim3(tpg, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tpg, sb,
                e->d_tile_ent.p, e->d_tile_lrh.p, skip_from, skipping ? e->d_tile_lth.p : (int*)nullptr);
-    FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(1), dim3(256), 0, e->stream, e->d_tile_ent.p, e->d_tile_lrh.p, ntiles, e->d_ebase.p,
+    FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(1), dim3(1024), 0, e->stream, e->d_tile_ent.p, e->d_tile_lrh.p, ntiles, e->d_ebase.p,
                e->d_tile_rs.p, skipping ? (const int*)e->d_tile_lth.p : (const int*)nullptr, skipping ? e->d_tile_ts.p : (int*)nullptr);
     FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_seg_write<RecT>), dim3(tpg, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tpg, sb,
                e->d_ebase.p, e->d_tile_rs.p, e->d_E.p, e->d_Pk.p, e->sx_own_shift, O,

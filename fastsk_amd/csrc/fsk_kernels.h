@@ -707,34 +707,60 @@ __global__ __launch_bounds__(256) void k_sx_seg_count(const RecT* rec, uint32_t 
     }
 }
 
-// single workgroup: ebase[tile] = entries before the tile (ebase[ntiles] = D); tile_rs[tile] = global
-// index of the last run start before the tile (the run the tile's first entries may continue);
-// tile_ts[tile] = likewise the last test head before the tile (skip_test_block only)
-__global__ __launch_bounds__(256) void k_sx_seg_scan(const uint32_t* tile_ent, const int* tile_lrh, uint32_t ntiles, uint32_t* ebase,
-                                                     int* tile_rs, const int* tile_lth, int* tile_ts) {
-    __shared__ uint32_t tmp[4];
-    __shared__ int tmpi[4];
+// running maximum, exclusive, over a block of NW waves; identity -1. tmp: >= NW ints.
+template <int NW>
+__device__ __forceinline__ int block_excl_maxscan(int v, int* tmp, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d && y > x) x = y;
+    }
+    int prev = __shfl_up(x, 1);
+    if (lane == 0) prev = -1;
+    __syncthreads();
+    if (lane == 63) tmp[wave] = x;
+    __syncthreads();
+    int base = -1, tot = -1;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const int t = tmp[w];
+        if (w < wave && t > base) base = t;
+        if (t > tot) tot = t;
+    }
+    if (total) *total = tot;
+    return base > prev ? base : prev;
+}
+
+// single workgroup of 1024 threads: ebase[tile] = entries before the tile (ebase[ntiles] = D);
+// tile_rs[tile] = global index of the last run start before the tile (the run the tile's first entries
+// may continue); tile_ts[tile] = likewise the last test head before the tile (skip_test_block only)
+__global__ __launch_bounds__(1024) void k_sx_seg_scan(const uint32_t* tile_ent, const int* tile_lrh, uint32_t ntiles, uint32_t* ebase,
+                                                      int* tile_rs, const int* tile_lth, int* tile_ts) {
+    __shared__ uint32_t tmp[16];
+    __shared__ int tmpi[16];
     const uint32_t tid = threadIdx.x;
     uint32_t carry = 0;
     int carry_h = -1, carry_t = -1;
-    for (uint32_t base = 0; base < ntiles; base += 256) {
+    for (uint32_t base = 0; base < ntiles; base += 1024) {
         const uint32_t i = base + tid;
         const uint32_t v = i < ntiles ? tile_ent[i] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan_256<uint32_t>(v, tmp, &tot) + carry;
         const int lr = i < ntiles ? tile_lrh[i] : -1;
+        const int lt = (tile_lth && i < ntiles) ? tile_lth[i] : -1;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<uint32_t, 16>(v, tmp, &tot) + carry;
         const int h = lr >= 0 ? (int)ex + lr : -1;
         int htot;
-        const int hx = block_excl_maxscan_256(h, tmpi, &htot);
+        const int hx = block_excl_maxscan<16>(h, tmpi, &htot);
         if (i < ntiles) {
             ebase[i] = ex;
             tile_rs[i] = hx > carry_h ? hx : carry_h;
         }
         if (tile_lth) {  // (uniform)
-            const int lt = i < ntiles ? tile_lth[i] : -1;
             const int th = lt >= 0 ? (int)ex + lt : -1;
             int ttot;
-            const int tx = block_excl_maxscan_256(th, tmpi, &ttot);
+            const int tx = block_excl_maxscan<16>(th, tmpi, &ttot);
             if (i < ntiles) tile_ts[i] = tx > carry_t ? tx : carry_t;
             if (ttot > carry_t) carry_t = ttot;
         }
