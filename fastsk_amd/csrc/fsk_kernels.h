@@ -983,7 +983,9 @@ __global__ __launch_bounds__(256) void k_sx_ucol_apply(uint32_t* ucount, uint32_
 // One workgroup of 512 threads per entry tile (the entries one k_sx_seg_write tile produced).
 // DIRECT: 64-bit atomicAdd per pair straight into K instead of update words.
 constexpr int EM_THREADS = 512, EM_WAVES = EM_THREADS / 64;
-constexpr uint32_t EM_STAGE = (uint32_t)EM_THREADS * SX_SHORT;  // one short entry per thread and round
+constexpr int EM_PER = SG_TILE / EM_THREADS;              // entries per thread when a tile's short entries go in one pass
+constexpr uint32_t EM_SLOTS = 12288;                      // update words of short entries binned per pass (u16 each in LDS)
+static_assert((SG_TILE / 4) * SX_SHORT <= EM_SLOTS, "a quarter tile of short entries must always fit one pass");
 template <bool DIRECT, bool SKIP>
 __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const uint32_t* Pk, const uint32_t* ebase,
                                                         const uint32_t* owner_r0, int own_shift, uint32_t n_owners,
@@ -998,15 +1000,16 @@ __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const ui
     __shared__ uint32_t s_r0[SX_MAX_OWNERS + 1];
     __shared__ uint32_t s_cur[SX_MAX_OWNERS];   // next free word of this tile's share of each owner's stream
     __shared__ uint32_t s_cnt[SX_MAX_OWNERS];
-    __shared__ uint32_t s_seg[SX_MAX_OWNERS];
-    // a round's update words in owner order: slot -> the thread (entry) it belongs to; per entry: its
-    // first slot, the cell of column 0 of its row inside the owner band, (address in the stream) - slot
-    // and the global index of its first partner (one 16-byte LDS read per word)
-    __shared__ uint16_t slot_ent[EM_STAGE];
-    __shared__ uint4 ent_info[EM_THREADS];  // {first slot, cell of column 0, address - slot, index of the first partner}
-    __shared__ uint16_t s_long[SG_TILE];
+    __shared__ uint32_t s_seg[SX_MAX_OWNERS];   // first slot of the owner's segment; then (address in the stream) - slot
+    // a pass's update words in owner order: slot -> the entry it belongs to; per entry: its first slot,
+    // the cell of column 0 of its row inside the owner band, its owner. (After the short entries the
+    // slot array holds the list of long entries.)
+    __shared__ uint16_t slot_ent[EM_SLOTS];
+    __shared__ uint16_t ent_at[SG_TILE], ent_o[SG_TILE];
+    __shared__ uint32_t ent_cbase[SG_TILE];
     __shared__ uint32_t s_nlong, s_total;
     __shared__ uint32_t tmp[EM_WAVES];
+    uint16_t* const s_long = slot_ent;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t tile = blockIdx.x;
     const uint32_t e0 = ebase[tile], n = ebase[tile + 1] - e0;
@@ -1021,7 +1024,6 @@ __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const ui
         s_P[e] = P;
         if (SKIP) s_T[e] = Tk[(size_t)e0 + e];
     }
-    if (tid == 0) s_nlong = 0u;
     __syncthreads();
     // partner `ge` of an entry: the tile's own entries sit in LDS, a run that started before the tile
     // continues in global memory
@@ -1029,71 +1031,88 @@ __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const ui
     // partner number b (0 .. T) of tile-local entry el: the run's first T entries, then the entry itself
 #define SX_NPART(el) (SKIP ? s_T[el] + 1u : s_P[el])
 #define SX_PARTNER_OF(el, b) SX_PARTNER((!SKIP || (b) < s_T[el]) ? e0 + (el) - s_P[el] + 1u + (b) : e0 + (el))
-    // entries with many partners (or a product that needs several words): one wave each, below
-    for (uint32_t e = tid; e < n; e += EM_THREADS) {
-        const uint2 a = s_ent[e];
-        if (a.x >= row0 && a.x < row1 && (SX_NPART(e) > SX_SHORT || (!DIRECT && sx_words_per_pair(a.y, cmax, max_win, maxprod) > 1u)))
-            s_long[atomicAdd(&s_nlong, 1u)] = (uint16_t)e;
-    }
-    // ---- short entries, one per thread and round
-    for (uint32_t rb = 0; rb < n; rb += EM_THREADS) {
-        const uint32_t e = rb + tid;
-        bool mine = false;
-        uint2 a = make_uint2(0u, 0u);
-        uint32_t P = 0, my_o = 0, my_pos = 0;
-        if (e < n) {
-            a = s_ent[e];
-            P = SX_NPART(e);  // partners of this entry
-            mine = a.x >= row0 && a.x < row1 && P <= SX_SHORT && (DIRECT || sx_words_per_pair(a.y, cmax, max_win, maxprod) == 1u);
-        }
-        if (DIRECT) {
-            if (mine) {
+    // an entry is SHORT (binned below) with up to SX_SHORT partners and one word per pair, else LONG (a wave each, further down)
+#define SX_IS_SHORT(el) (SX_NPART(el) <= SX_SHORT && (DIRECT || sx_words_per_pair(s_ent[el].y, cmax, max_win, maxprod) == 1u))
+#define SX_IN_BAND(el) (s_ent[el].x >= row0 && s_ent[el].x < row1)
+    if (DIRECT) {
+        for (uint32_t e = tid; e < n; e += EM_THREADS) {
+            if (SX_IN_BAND(e) && SX_IS_SHORT(e)) {
+                const uint2 a = s_ent[e];
+                const uint32_t P = SX_NPART(e);
                 u64* row = K + tri_index((u64)a.x, 0);
                 for (uint32_t b = 0; b < P; ++b) {
                     const uint2 pq = SX_PARTNER_OF(e, b);
                     atomicAdd(&row[pq.x], (u64)a.y * pq.y);
                 }
             }
-            continue;
         }
-        for (uint32_t o = tid; o < n_owners; o += EM_THREADS) s_cnt[o] = 0u;
-        __syncthreads();
-        if (mine) {
-            my_o = sx_owner_of(a.x, own_shift);
-            my_pos = atomicAdd(&s_cnt[my_o], P);
+    } else {
+        // ---- short entries. All of the tile's in one pass when their words fit the slot array (the usual
+        // case: ~4 partners per entry), else a quarter of the tile per pass (which always fits).
+        uint32_t words = 0;
+        for (uint32_t e = tid; e < n; e += EM_THREADS)
+            if (SX_IN_BAND(e) && SX_IS_SHORT(e)) words += SX_NPART(e);
+        uint32_t all;
+        (void)block_excl_scan<uint32_t, EM_WAVES>(words, tmp, &all);
+        const uint32_t span = all <= EM_SLOTS ? (uint32_t)SG_TILE : (uint32_t)(SG_TILE / 4);  // entries per pass (uniform)
+        for (uint32_t ea = 0; ea < n; ea += span) {
+            for (uint32_t o = tid; o < n_owners; o += EM_THREADS) s_cnt[o] = 0u;
+            __syncthreads();
+            uint32_t my_pos[EM_PER];
+#pragma unroll
+            for (int q = 0; q < EM_PER; ++q) {
+                const uint32_t e = ea + (uint32_t)q * EM_THREADS + tid;
+                my_pos[q] = 0xffffffffu;
+                if (e < n && e < ea + span && SX_IN_BAND(e) && SX_IS_SHORT(e)) {
+                    const uint32_t o = sx_owner_of(s_ent[e].x, own_shift);
+                    ent_o[e] = (uint16_t)o;
+                    my_pos[q] = atomicAdd(&s_cnt[o], SX_NPART(e));
+                }
+            }
+            __syncthreads();
+            {   // exclusive scan of the owner counts (n_owners <= 512 = one per thread)
+                const uint32_t v = tid < n_owners ? s_cnt[tid] : 0u;
+                uint32_t tot;
+                const uint32_t ex = block_excl_scan<uint32_t, EM_WAVES>(v, tmp, &tot);
+                if (tid < n_owners) s_seg[tid] = ex;
+                if (tid == 0) s_total = tot;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < EM_PER; ++q) {
+                if (my_pos[q] != 0xffffffffu) {
+                    const uint32_t e = ea + (uint32_t)q * EM_THREADS + tid;
+                    const uint32_t o = ent_o[e];
+                    const uint32_t at = s_seg[o] + my_pos[q], P = SX_NPART(e);
+                    ent_at[e] = (uint16_t)at;
+                    ent_cbase[e] = (uint32_t)(tri_index((u64)s_ent[e].x, 0) - tri_index((u64)s_r0[o], 0));
+                    for (uint32_t b = 0; b < P; ++b) slot_ent[at + b] = (uint16_t)e;
+                }
+            }
+            __syncthreads();
+            if (tid < n_owners) s_seg[tid] = s_cur[tid] - s_seg[tid];  // slot -> address in the owner's stream
+            __syncthreads();
+            // one update word per thread and trip, whatever the entries' partner counts: slot i is partner
+            // i - ent_at of its entry; neighbouring slots go to neighbouring addresses of one stream
+            const uint32_t total = s_total;
+            for (uint32_t i = tid; i < total; i += EM_THREADS) {
+                const uint32_t el = slot_ent[i];
+                const uint32_t b = i - ent_at[el];
+                const uint32_t ge = (!SKIP || b < s_T[el]) ? e0 + el - s_P[el] + 1u + b : e0 + el;
+                const uint2 pq = SX_PARTNER(ge);
+                list[s_seg[ent_o[el]] + i] = ((ent_cbase[el] + pq.x) << pb) | (s_ent[el].y * pq.y);
+            }
+            __syncthreads();
+            if (tid < n_owners) s_cur[tid] += s_cnt[tid];
+            // (the barriers of the next pass, or the one below, order this against its readers)
         }
-        __syncthreads();
-        {   // exclusive scan of the owner counts (n_owners <= 512 = one per thread)
-            const uint32_t v = tid < n_owners ? s_cnt[tid] : 0u;
-            uint32_t tot;
-            const uint32_t ex = block_excl_scan<uint32_t, EM_WAVES>(v, tmp, &tot);
-            if (tid < n_owners) s_seg[tid] = ex;
-            if (tid == 0) s_total = tot;
-        }
-        __syncthreads();
-        if (mine) {
-            const uint32_t at = s_seg[my_o] + my_pos;
-            ent_info[tid] = make_uint4(at, (uint32_t)(tri_index((u64)a.x, 0) - tri_index((u64)s_r0[my_o], 0)), s_cur[my_o] - s_seg[my_o],
-                                       e0 + e - s_P[e] + 1u);
-            for (uint32_t b = 0; b < P; ++b) slot_ent[at + b] = (uint16_t)tid;
-        }
-        __syncthreads();
-        // one update word per thread and trip, whatever the entries' partner counts: slot i is partner
-        // i - ent_at of its entry; neighbouring slots go to neighbouring addresses of one stream
-        const uint32_t total = s_total;
-        for (uint32_t i = tid; i < total; i += EM_THREADS) {
-            const uint32_t t = slot_ent[i];
-            const uint32_t el = rb + t;
-            const uint4 inf = ent_info[t];
-            const uint32_t b = i - inf.x;
-            const uint32_t ge = (!SKIP || b < s_T[el]) ? inf.w + b : e0 + el;
-            const uint2 pq = SX_PARTNER(ge);
-            list[inf.z + i] = ((inf.y + pq.x) << pb) | (s_ent[el].y * pq.y);
-        }
-        __syncthreads();
-        if (tid < n_owners) s_cur[tid] += s_cnt[tid];
-        // (the barriers of the next round, or the one below, order this against its readers)
     }
+    __syncthreads();
+    // entries with many partners (or a product that needs several words): listed now that the slot array is free
+    if (tid == 0) s_nlong = 0u;
+    __syncthreads();
+    for (uint32_t e = tid; e < n; e += EM_THREADS)
+        if (SX_IN_BAND(e) && !SX_IS_SHORT(e)) s_long[atomicAdd(&s_nlong, 1u)] = (uint16_t)e;
     __syncthreads();
     // ---- long entries: the lanes of a wave take the partners, the words of an entry are contiguous
     const uint32_t nlong = s_nlong;
@@ -1141,6 +1160,8 @@ __global__ __launch_bounds__(EM_THREADS) void k_sx_emit(const uint2* E, const ui
             }
         }
     }
+#undef SX_IN_BAND
+#undef SX_IS_SHORT
 #undef SX_PARTNER_OF
 #undef SX_NPART
 #undef SX_PARTNER
