@@ -28,7 +28,10 @@ def json_line(path):
 
 
 def main():
-    open(os.path.join(DST, TAG + "_bench100k.json"), "w").write(json_line(os.path.join(SRC, "bench.json")))
+    # (bench_final.json: the same command run again on the box after traffic.json was rebuilt there)
+    final = os.path.join(SRC, "bench_final.json")
+    have_final = os.path.exists(final) and any(l.startswith("{") for l in open(final))
+    open(os.path.join(DST, TAG + "_bench100k.json"), "w").write(json_line(final if have_final else os.path.join(SRC, "bench.json")))
     open(os.path.join(DST, TAG + "_bench100k_under_rocprof.json"), "w").write(json_line(os.path.join(SRC, "bench_under_rocprof.json")))
     shutil.copy(newest(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv")), os.path.join(DST, TAG + "_kernel_stats_bench100k.csv"))
     rows = []

@@ -16,6 +16,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/pmc_$c" -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-also > /dev/null 2> "$O/pmc_$c.err"
 done
+# traffic.json from the two passes above (needs bench.json, stats, pmc_*), then the headline line once more:
+# it now carries the measured HBM traffic of exactly these kernel sources
+(cd "$R" && python3 tools/collect_profiles.py r02 > "$O/collect_on_box.log" 2>&1 && python3 bench.py --steps 2 --warmup 1 > "$O/bench_final.json" 2> "$O/bench_final.err")
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_configs" -- python3 "$R/tools/bench_configs.py" > /dev/null 2> "$O/stats_configs.err"
 cd "$R" && python3 tools/bench_configs.py > "$O/configs.jsonl" 2> "$O/configs.err"
 python3 tools/bench_large_g.py > "$O/large_g.jsonl" 2> "$O/large_g.err"
