@@ -18,9 +18,9 @@ def main(iters=150, seed=0):
         k = int(rng.integers(1, 7 if sigma <= 5 else 4))
         m = int(rng.integers(0, 7))
         g = k + m
-        N = int(rng.choice([1, 2, 63, 64, 65, 127, 129, 300, 700, 1500, 3000]))
+        N = int(rng.choice([1, 2, 63, 64, 65, 127, 129, 300, 700, 1500, 3000, 6500]))  # 6500: an owner band takes two LDS rounds
         lo = g
-        hi = int(rng.choice([g, g + 1, 40, 120, 330, 700]))
+        hi = int(rng.choice([g, g + 1, 40, 120, 330, 700])) if N < 6000 else int(rng.choice([g + 1, 40, 90]))
         hi = max(hi, lo)
         lens = rng.integers(lo, hi + 1, size=N)
         X = [rng.integers(1, sigma + 1, size=int(L)).astype(np.int32) for L in lens]
