@@ -216,9 +216,10 @@ void enumerate_combos(int g, int k, std::vector<uint8_t>& out) {
 
 // host-side helpers of fsk_load_sequences: contiguous ranges of [0, n) on a few threads
 int host_threads_for(int64_t work_items) {
-    if (work_items < ((int64_t)1 << 21)) return 1;
+    if (work_items < ((int64_t)1 << 18)) return 1;
     const unsigned hw = std::thread::hardware_concurrency();
-    return (int)std::max(1u, std::min(8u, hw ? hw : 1u));
+    const unsigned want = work_items < ((int64_t)1 << 21) ? 4u : 8u;  // (a thread start costs ~50 us)
+    return (int)std::max(1u, std::min(want, hw ? hw : 1u));
 }
 template <typename F>
 void parallel_ranges(int64_t n, int nt, F&& fn) {
