@@ -526,21 +526,20 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     { int rcz = materialise_zero(e); if (rcz) return rcz; }
     int rc = ensure_featseq(e);
     if (rc) return rc;
-    if (e->sx_keybits + e->sx_sb > 64)
-        return e->fail(FSK_EUNSUPPORTED, "sparse dataflow: k-mer (%d bits) + sequence id (%d bits) exceed a 64-bit sort record",
-                       e->sx_keybits, e->sx_sb);
     // batch so that the record count stays below the cap ...
     size_t per = SPARSE_MAX_RECORDS / (size_t)std::max<int64_t>(1, e->nfeat);
     int B = (int)std::max<size_t>(1, std::min<size_t>(per, (size_t)n));
     // ... and the owner bands can sum a batch in u32 LDS cells: per cell and combo <= maxW^2
     B = (int)std::max<u64>(1, std::min<u64>((u64)B, 0xffffffffull / std::max<u64>(1, (u64)e->maxW * e->maxW)));
     B = std::min(B, 65535);  // grid.y
-    const bool wide = e->sx_keybits + e->sx_sb > 32;
+    const int recbits = e->sx_keybits + e->sx_sb;  // (<= 62 + 31: a 128-bit record always holds it)
     for (int s = 0; s < n; s += B) {
         const int nb = std::min(B, n - s);
         // (slot triangles are u32 arrays, slot_stride cells apart)
         u64* Kb = slot_stride ? reinterpret_cast<u64*>(reinterpret_cast<uint32_t*>(K) + (u64)s * slot_stride) : K;
-        rc = wide ? sparse_batch<u64>(e, combos + s, nb, Kb, row0, row1, slot_stride) : sparse_batch<uint32_t>(e, combos + s, nb, Kb, row0, row1, slot_stride);
+        rc = recbits <= 32   ? sparse_batch<uint32_t>(e, combos + s, nb, Kb, row0, row1, slot_stride)
+             : recbits <= 64 ? sparse_batch<u64>(e, combos + s, nb, Kb, row0, row1, slot_stride)
+                             : sparse_batch<u128>(e, combos + s, nb, Kb, row0, row1, slot_stride);
         if (rc) return rc;
     }
     return FSK_OK;

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(64) void k_dense_distinct(const uint32_t* C4, const
 // =============================================================================================
 // Per batch of B combos ("slots"):
 //   k_sx_extract   one packed record per (slot, g-mer): rec = (k-mer << sb) | sequence id, u32 when
-//                  that fits 32 bits (every BASELINE config) else u64; slot s owns rec[s*nfeat ..):
+//                  that fits 32 bits (every BASELINE config), else u64, else 128 bits; slot s owns rec[s*nfeat ..):
 //                  the slot is implicit in the position, so B independent sorts run in one launch.
 //   k_sx_hist / k_sx_scan_slot / k_sx_scatter   stable LSD radix sort over the k-mer bits only
 //                  (records are generated in sequence order and every pass is stable), 8-bit digits,
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void k_sx_extract(SeqView S, const uint32_t* f
             const uint32_t wbase = S.wstart[seq];
             u64 key = 0;
             for (int c = 0; c < k; ++c) key = key * sigma + fetch_sym(S.words, wbase, j + pos[c], S.bits);
-            rec[(size_t)slot * nfeat + f] = (RecT)((key << sb) | (u64)seq);
+            rec[(size_t)slot * nfeat + f] = ((RecT)key << sb) | (RecT)seq;
             atomicAdd(&h[(uint32_t)key & dmask], 1u);
         }
     }

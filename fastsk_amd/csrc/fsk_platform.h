@@ -22,3 +22,4 @@
 #include <cstdint>
 
 typedef unsigned long long u64;
+typedef unsigned __int128 u128;  // sort records of the sparse dataflow when k-mer bits + sequence bits exceed 64

@@ -296,6 +296,19 @@ def test_emu_relabelled_and_wide_alphabets(emu_lib, port):
     want, _, _ = port.compute(tok, off, 6, 3, 12, 3, t=1)
     assert np.array_equal(e.get_triangle(), want)
     assert e.stats()["path_used"] == 2
+    e.close()
+    # k = 14 over 20 symbols: 61 k-mer bits + 5 sequence bits = 66 -> 128-bit sort records
+    X = [rng.integers(1, 21, size=int(L)) for L in rng.integers(17, 40, size=20)]
+    for x in X[:9]:
+        x[1:17] = X[12][1:17]
+    X[3][5] = X[3][5] % 20 + 1  # a near copy: shares some gapped 14-mers only
+    tok, off = _native.flatten(X)
+    e = _native.Engine(16, 2, lib=emu_lib)
+    e.compute(tok, off, 14, 6)
+    want, _, _ = port.compute(tok, off, 14, 6, 16, 2, t=1)
+    assert np.array_equal(e.get_triangle(), want)
+    assert e.stats()["path_used"] == 2 and e.stats()["key_space"] == 20 ** 14
+    e.close()
 
 
 def test_emu_mixed_4bit_and_8bit_panels(emu_lib, port):

@@ -163,6 +163,26 @@ def test_mid_size_key_spaces_dense_vs_sparse(native, port, sigma, g, m, L):
         e.close()
 
 
+def test_wide_kmers_128_bit_sort_records(native, port):
+    """k = 14 over 20 symbols (61 k-mer bits) and enough sequences that k-mer + sequence id pass 64 bits:
+    the sparse dataflow sorts 128-bit records (and 64-bit ones for k = 9) — against the oracle."""
+    rng = np.random.default_rng(31)
+    for g, m, n in ((16, 2, 40), (12, 3, 300)):
+        X = [rng.integers(1, 21, size=int(L)).astype(np.int32) for L in rng.integers(g + 1, 60, size=n)]
+        for x in X[: n // 3]:
+            x[1:g + 1] = X[n // 2][1:g + 1]
+        for i in range(0, n // 3, 3):
+            X[i][4] = X[i][4] % 20 + 1
+        tokens, offsets = native.flatten(X)
+        ntr = n - n // 4
+        want, _, _ = port.compute(tokens, offsets, ntr, n - ntr, g, m, t=1)
+        e = native.Engine(g, m)
+        e.compute(tokens, offsets, ntr, n - ntr)
+        assert e.stats()["path_used"] == 2 and e.stats()["key_space"] == 20 ** (g - m)
+        assert np.array_equal(e.get_triangle(), want)
+        e.close()
+
+
 def test_low_complexity_counts_above_255(native, port):
     """A k-mer occurring > 255 times in one sequence does not fit the u8 count panels: the dense
     dataflow must notice and hand that batch to the general one."""
