@@ -14,7 +14,7 @@ OUT = os.path.join(HERE, "libfastsk_emu.so")
 def _current():
     deps = [SRC, os.path.join(HERE, "hip_emu.h"), os.path.join(ROOT, "include", "fastsk_amd.h")]
     deps += [os.path.join(ROOT, "fastsk_amd", "csrc", f)
-             for f in ("fsk_kernels.h", "fsk_tile_kernel.inc", "fsk_tile_kernel_dma.inc", "fsk_platform.h", "fsk_fasta.cpp")]
+             for f in ("fsk_kernels.h", "fsk_tile_kernel.inc", "fsk_tile_kernel_dma.inc", "fsk_sparse_kernels.inc", "fsk_platform.h", "fsk_fasta.cpp")]
     return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps)
 
 
