@@ -369,7 +369,8 @@ def main():
     comm = None
     if use_dist:
         narrow = ncomb * eng.stats()["max_windows"] ** 2 < 2 ** 31
-        nb = args.bands or (8 if (dense and N >= 8192) else 1)
+        tiles = ((N + 127) // 128) * ((N + 127) // 128 + 1) // 2
+        nb = args.bands or ((16 if tiles >= 16 * 16384 else 8) if (dense and N >= 8192) else 1)
         be = distributed.band_edges(N, nb)
         segs = [K[distributed.cell(lo):distributed.cell(hi)] for lo, hi in zip(be[:-1], be[1:])]
         barrier()

@@ -216,7 +216,10 @@ def accumulate_and_reduce(eng, K, combos, group=None, n_bands=None, narrow=None,
         return
     dense = eng.stats()["path_used"] == _native.PATH_DENSE
     if n_bands is None:
-        n_bands = 8 if (dense and N >= 8192) else 1
+        # more, smaller bands leave less of the last band's exchange exposed — as long as a band's tile
+        # launch keeps one workgroup per tile (>= 16384 tiles), the form that stores instead of adding
+        tiles = ((N + TILE - 1) // TILE) * ((N + TILE - 1) // TILE + 1) // 2
+        n_bands = (16 if tiles >= 16 * 16384 else 8) if (dense and N >= 8192) else 1
     if narrow is None:
         total = n_combos_total if n_combos_total is not None else eng.lib.num_combos(eng.g, eng.m)
         narrow = total * eng.stats()["max_windows"] ** 2 < 2 ** 31
