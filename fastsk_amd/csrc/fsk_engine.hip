@@ -155,6 +155,19 @@ struct fsk_engine {
     u64 u_value = 0, u_extra = 0;
     int force_global_pairs = 0;  // FSK_SPARSE_GLOBAL=1: per-pair global atomics (testing)
     u64 sx_max_words = (u64)1 << 31;  // update words per batch beyond which the pairs go to K with atomics (FSK_LIST_MAX_WORDS: testing)
+    // Batches are enqueued without waiting for their word counts once one batch of these sequences has
+    // been sized: the stream buffer keeps headroom over the largest count seen, the kernels leave a
+    // batch that does not fit alone, and the host redoes such a batch (sized exactly) when it reads the
+    // counts back — at the end of an exact accumulate, at the hand-over of a variance-mode batch.
+    unsigned char* h_sx_pos = nullptr;   // pinned: positions of the batches in flight ([SX_DEFER slots][exact call])
+    size_t h_sx_pos_cap = 0;
+    u64* h_sx_stat = nullptr;            // pinned: {pairs, words} of the batches in flight (same layout)
+    size_t h_sx_stat_cap = 0;
+    u64 sx_words_seen = 0;               // largest word count of a batch since the sequences were loaded
+    struct SxDefer { bool active = false; u64 cap = 0; } sx_defer[8];
+    int sx_sync = 0;                     // FSK_SPARSE_SYNC=1: size every batch exactly (testing); also while redoing a batch
+    u64 sx_guard_cap = 0;                // FSK_SPARSE_GUARD_CAP=n: pretend the stream buffer holds n words (testing the redo)
+    u64 sx_redone = 0;                   // batches redone because they did not fit
     int tile_dma = 1;            // FSK_TILE_DMA=0: register-staged tile kernel instead of the direct-to-LDS one (testing)
     int compact_dma = 0;         // FSK_COMPACT_DMA=1: direct-to-LDS k_dense_tile_dma_compact for key-compacted panels (measured slower on
                                  // config 3: its flagged rows take the generic remainder, not k_dense_tile_compact's side-aware one)
@@ -349,8 +362,12 @@ void plan_owner_bands(fsk_engine* e) {
     e->owner_ready = false;
 }
 
+// `pos_pin` / `stat_pin`: pinned staging of this batch (positions in, {pairs, words} out), untouched by
+// anyone else until the batch's counts have been read. `guard_cap` == 0: the call waits for the
+// counts and sizes the streams exactly; else it only enqueues, for streams of at most guard_cap words.
 template <typename RecT>
-int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t row0, int64_t row1, u64 slot_stride = 0) {
+int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t row0, int64_t row1, u64 slot_stride,
+                 unsigned char* pos_pin, u64* stat_pin, u64 guard_cap) {
     const uint32_t nfeat = (uint32_t)e->nfeat;
     const size_t nrec = (size_t)nb * nfeat;
     if (nrec == 0) return FSK_OK;
@@ -400,12 +417,10 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         FSK_HIP(e->d_list_off.reserve((size_t)O + 1));
         FSK_HIP(e->d_part_base.reserve((size_t)O + 1));
     }
-    std::vector<uint8_t> pos((size_t)nb * e->k);
     for (int s = 0; s < nb; ++s)
-        memcpy(&pos[(size_t)s * e->k], &e->all_pos[(size_t)combos[s] * e->k], e->k);
-    FSK_HIP(hipMemcpyAsync(e->d_pos.p, pos.data(), pos.size(), hipMemcpyHostToDevice, e->stream));
+        memcpy(pos_pin + (size_t)s * e->k, &e->all_pos[(size_t)combos[s] * e->k], e->k);
+    FSK_HIP(hipMemcpyAsync(e->d_pos.p, pos_pin, (size_t)nb * e->k, hipMemcpyHostToDevice, e->stream));
     FSK_HIP(hipMemsetAsync(e->d_sxstat.p, 0, 2 * sizeof(u64), e->stream));
-    FSK_HIP(hipStreamSynchronize(e->stream));  // `pos` is a pageable temporary
 
     RecT* rec[2] = {(RecT*)e->d_keys[0].p, (RecT*)e->d_keys[1].p};
 
@@ -453,26 +468,34 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         FSK_LAUNCH(fsk::k_sx_ucol_apply, dim3(nchunks), dim3(256), 0, e->stream, e->d_ucount.p, ntiles, O, (const uint32_t*)e->d_uchunk.p);
         e->st.launches += 4;
     }
-    u64 stat[2] = {0, 0};
-    FSK_HIP(hipMemcpyAsync(stat, e->d_sxstat.p, sizeof stat, hipMemcpyDeviceToHost, e->stream));
-    FSK_HIP(hipStreamSynchronize(e->stream));  // the update streams are sized exactly
+    stat_pin[0] = stat_pin[1] = 0;
+    FSK_HIP(hipMemcpyAsync(stat_pin, e->d_sxstat.p, 2 * sizeof(u64), hipMemcpyDeviceToHost, e->stream));
+    const bool guarded = guard_cap != 0;
+    uint32_t cap_words = 0xffffffffu;
+    if (guarded) {
+        words = lists ? std::max<u64>(1, std::min(e->sx_words_seen, guard_cap)) : 0;  // (sizes the parts; the kernels read the true offsets)
+        cap_words = (uint32_t)std::min<u64>(guard_cap, 0xffffffffu);
+    } else {
+        FSK_HIP(hipStreamSynchronize(e->stream));  // the update streams are sized exactly
+        e->u_extra += stat_pin[0];
+        words = stat_pin[1];
+        e->sx_words_seen = std::max(e->sx_words_seen, words);
+    }
     e->toc(&e->st.ms_segment);
-    e->u_extra += stat[0];
-    words = stat[1];
 
     e->tic();
     const bool use_lists = lists && words < e->sx_max_words;
     if (slot_stride != 0 && !use_lists) return FSK_RETRY_UNGROUPED;  // (nothing of this batch has touched K yet)
     if (use_lists) {
         if (words > 0 || slot_stride != 0) {
-            if ((size_t)words > e->d_ulist.cap)  // (grown with headroom: the batches of a pass differ by a few percent)
+            if (!guarded && (size_t)words > e->d_ulist.cap)  // (grown with headroom: the batches of a pass differ by a few percent)
                 FSK_HIP(e->d_ulist.reserve((size_t)std::max<u64>(1, words + words / 4)));
             // (function pointers: a template-id with a comma cannot pass through the launch macro)
             auto k_emit = skipping ? fsk::k_sx_emit<false, true> : fsk::k_sx_emit<false, false>;
             FSK_LAUNCH(k_emit, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
                        (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)e->d_list_off.p,
                        (const uint32_t*)e->d_ucount.p, e->d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
-                       slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr);
+                       slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr, cap_words);
             const size_t lds = (size_t)e->sx_cap * sizeof(uint32_t);
 #ifndef FSK_EMU
             FSK_HIP(hipFuncSetAttribute((const void*)fsk::k_sx_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -480,16 +503,17 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             // parts of about `target` words: ~1024 workgroups, and never so short that the flush of a
             // part (up to sx_cap cells) outweighs the words it summed
             const uint32_t target = (uint32_t)std::max<u64>((u64)4 * e->sx_cap, (words + 1023) / 1024);
-            const uint32_t max_parts = O + (uint32_t)((words + target - 1) / target);
+            const uint32_t max_parts = O + (uint32_t)(((guarded ? guard_cap : words) + target - 1) / target);
             if (slot_stride != 0) {  // one triangle per slot: a slot's words of a stream are one contiguous piece
                 FSK_LAUNCH(fsk::k_sx_consume, dim3(O, e->sx_rounds, nb), dim3(fsk::CS_THREADS), lds, e->stream, (const uint32_t*)e->d_ulist.p,
                            (const uint32_t*)e->d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)nullptr, O, target,
-                           e->sx_cap, e->sx_pb, K, (const uint32_t*)e->d_ucount.p, tpg, slot_stride);
+                           e->sx_cap, e->sx_pb, K, (const uint32_t*)e->d_ucount.p, tpg, slot_stride, cap_words);
             } else {
-                FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, e->stream, (const uint32_t*)e->d_list_off.p, O, target, e->d_part_base.p);
+                FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, e->stream, (const uint32_t*)e->d_list_off.p, O, target, e->d_part_base.p,
+                           cap_words);
                 FSK_LAUNCH(fsk::k_sx_consume, dim3(max_parts, e->sx_rounds), dim3(fsk::CS_THREADS), lds, e->stream, (const uint32_t*)e->d_ulist.p,
                            (const uint32_t*)e->d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)e->d_part_base.p, O, target,
-                           e->sx_cap, e->sx_pb, K, (const uint32_t*)nullptr, tpg, (u64)0);
+                           e->sx_cap, e->sx_pb, K, (const uint32_t*)nullptr, tpg, (u64)0, cap_words);
                 e->st.launches += 1;
             }
             e->st.launches += 2;
@@ -499,7 +523,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         FSK_LAUNCH(k_emit, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
                    (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)nullptr,
                    (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
-                   slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr);
+                   slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr, 0xffffffffu);
         e->st.launches += 1;
     }
     e->toc(&e->st.ms_pairs);
@@ -520,9 +544,54 @@ int ensure_featseq(fsk_engine* e) {
 
 int materialise_zero(fsk_engine* e);
 
+constexpr int SX_DEFER = 8;          // variance mode: batches whose counts are read at their hand-over
+constexpr int SX_DEFER_COMBOS = 16;  //                combos of such a batch at most
+
+int sx_pinned(fsk_engine* e, size_t pos_bytes, size_t stat_words) {
+    if (pos_bytes > e->h_sx_pos_cap) {
+        if (e->h_sx_pos) (void)hipHostFree(e->h_sx_pos);
+        e->h_sx_pos = nullptr; e->h_sx_pos_cap = 0;
+        FSK_HIP(hipHostMalloc((void**)&e->h_sx_pos, pos_bytes + pos_bytes / 2));
+        e->h_sx_pos_cap = pos_bytes + pos_bytes / 2;
+    }
+    if (stat_words > e->h_sx_stat_cap) {
+        if (e->h_sx_stat) (void)hipHostFree(e->h_sx_stat);
+        e->h_sx_stat = nullptr; e->h_sx_stat_cap = 0;
+        FSK_HIP(hipHostMalloc((void**)&e->h_sx_stat, (stat_words + stat_words / 2) * sizeof(u64)));
+        e->h_sx_stat_cap = stat_words + stat_words / 2;
+    }
+    return FSK_OK;
+}
+
+// how many words a batch may hold when it is enqueued before its count is known (0: size it exactly)
+u64 sx_guard_for(fsk_engine* e) {
+    if (e->sx_sync || e->cfg.profile) return 0;
+    if (!e->sx_lists || e->force_global_pairs) return ~(u64)0;       // no streams: nothing to size
+    if (e->sx_words_seen == 0) return 0;                                // (the first batch of these sequences)
+    if (e->sx_guard_cap) return std::min<u64>(e->sx_guard_cap, (u64)e->d_ulist.cap);
+    const u64 want = e->sx_words_seen + e->sx_words_seen / 2;
+    if (want >= e->sx_max_words) return 0;
+    if ((u64)e->d_ulist.cap < want && e->d_ulist.reserve((size_t)want) != hipSuccess) return 0;
+    return std::min<u64>((u64)e->d_ulist.cap, e->sx_max_words - 1);
+}
+
+// the counts of deferred batch `slot` (its kernels have finished): false when it has to be redone
+bool sx_harvest(fsk_engine* e, int slot) {
+    if (slot < 0 || !e->sx_defer[slot].active) return true;
+    e->sx_defer[slot].active = false;
+    const u64 pairs = e->h_sx_stat[2 * slot], words = e->h_sx_stat[2 * slot + 1];
+    e->sx_words_seen = std::max(e->sx_words_seen, words);
+    if (words > e->sx_defer[slot].cap) { e->sx_redone += 1; return false; }
+    e->u_extra += pairs;
+    return true;
+}
+
 // slot_stride != 0 (variance mode): combo q of the list goes to its own u32 triangle (uint32_t*)K + q * slot_stride,
-// written whole; returns FSK_RETRY_UNGROUPED when that form cannot be used for this batch
-int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0, int64_t row1, u64 slot_stride = 0) {
+// written whole; returns FSK_RETRY_UNGROUPED when that form cannot be used for this batch.
+// defer >= 0 (variance mode): the call returns with the batch enqueued; the caller passes `defer` to
+// sx_harvest() once the batch has finished and redoes the batch (with e->sx_sync set) if that says so.
+int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0, int64_t row1, u64 slot_stride = 0,
+                      int defer = -1) {
     { int rcz = materialise_zero(e); if (rcz) return rcz; }
     int rc = ensure_featseq(e);
     if (rc) return rc;
@@ -533,13 +602,48 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     B = (int)std::max<u64>(1, std::min<u64>((u64)B, 0xffffffffull / std::max<u64>(1, (u64)e->maxW * e->maxW)));
     B = std::min(B, 65535);  // grid.y
     const int recbits = e->sx_keybits + e->sx_sb;  // (<= 62 + 31: a 128-bit record always holds it)
-    for (int s = 0; s < n; s += B) {
-        const int nb = std::min(B, n - s);
+    const int nbatches = (n + B - 1) / B;
+    if (defer >= 0 && (defer >= SX_DEFER || nbatches != 1 || n > SX_DEFER_COMBOS)) defer = -1;
+    const size_t pos_head = (size_t)SX_DEFER * SX_DEFER_COMBOS * e->k, stat_head = (size_t)2 * SX_DEFER;
+    rc = sx_pinned(e, pos_head + (size_t)n * e->k, stat_head + (size_t)2 * nbatches);
+    if (rc) return rc;
+    auto one = [&](int s, int nb, unsigned char* pos_pin, u64* stat_pin, u64 guard) {
         // (slot triangles are u32 arrays, slot_stride cells apart)
         u64* Kb = slot_stride ? reinterpret_cast<u64*>(reinterpret_cast<uint32_t*>(K) + (u64)s * slot_stride) : K;
-        rc = recbits <= 32   ? sparse_batch<uint32_t>(e, combos + s, nb, Kb, row0, row1, slot_stride)
-             : recbits <= 64 ? sparse_batch<u64>(e, combos + s, nb, Kb, row0, row1, slot_stride)
-                             : sparse_batch<u128>(e, combos + s, nb, Kb, row0, row1, slot_stride);
+        return recbits <= 32   ? sparse_batch<uint32_t>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard)
+               : recbits <= 64 ? sparse_batch<u64>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard)
+                               : sparse_batch<u128>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard);
+    };
+    if (defer >= 0) {
+        const u64 guard = sx_guard_for(e);
+        e->sx_defer[defer].active = guard != 0;
+        e->sx_defer[defer].cap = guard;
+        rc = one(0, n, e->h_sx_pos + (size_t)defer * SX_DEFER_COMBOS * e->k, e->h_sx_stat + 2 * defer, guard);
+        if (rc) e->sx_defer[defer].active = false;
+        return rc;
+    }
+    std::vector<u64> caps((size_t)nbatches, 0);  // per batch: the guard it was enqueued under (0: sized exactly)
+    bool waiting = false;
+    for (int s = 0, q = 0; s < n; s += B, ++q) {
+        const int nb = std::min(B, n - s);
+        caps[q] = sx_guard_for(e);
+        waiting |= caps[q] != 0;
+        rc = one(s, nb, e->h_sx_pos + pos_head + (size_t)s * e->k, e->h_sx_stat + stat_head + 2 * q, caps[q]);
+        if (rc) return rc;
+    }
+    if (!waiting) return FSK_OK;
+    FSK_HIP(hipStreamSynchronize(e->stream));
+    for (int s = 0, q = 0; s < n; s += B, ++q) {
+        if (!caps[q]) continue;
+        const u64 pairs = e->h_sx_stat[stat_head + 2 * q], words = e->h_sx_stat[stat_head + 2 * q + 1];
+        e->sx_words_seen = std::max(e->sx_words_seen, words);
+        if (words <= caps[q]) { e->u_extra += pairs; continue; }
+        // the batch did not fit and has left K alone: once more, sized exactly
+        e->sx_redone += 1;
+        const int was = e->sx_sync;
+        e->sx_sync = 1;
+        rc = one(s, std::min(B, n - s), e->h_sx_pos + pos_head + (size_t)s * e->k, e->h_sx_stat + stat_head + 2 * q, 0);
+        e->sx_sync = was;
         if (rc) return rc;
     }
     return FSK_OK;
@@ -847,7 +951,8 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
     return FSK_OK;
 }
 
-int do_accumulate(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0 = 0, int64_t row1 = -1, u64 slot_stride = 0) {
+int do_accumulate(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0 = 0, int64_t row1 = -1, u64 slot_stride = 0,
+                  int defer = -1) {
     if (row1 < 0) row1 = e->N;
     for (int i = 0; i < n; ++i)
         if (combos[i] < 0 || combos[i] >= e->ncomb) return e->fail(FSK_EINVAL, "combo id %d out of range [0,%lld)", combos[i], (long long)e->ncomb);
@@ -857,7 +962,7 @@ int do_accumulate(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t r
         (void)hipEventCreate(&b);
         (void)hipEventRecord(a, e->stream);
     }
-    int rc = e->path == FSK_PATH_DENSE ? accumulate_dense(e, combos, n, K, row0, row1) : accumulate_sparse(e, combos, n, K, row0, row1, slot_stride);
+    int rc = e->path == FSK_PATH_DENSE ? accumulate_dense(e, combos, n, K, row0, row1) : accumulate_sparse(e, combos, n, K, row0, row1, slot_stride, defer);
     if (e->cfg.profile) {
         (void)hipEventRecord(b, e->stream);
         (void)hipEventSynchronize(b);
@@ -994,7 +1099,7 @@ int run_variance_mode(fsk_engine* e, int T) {
         if (grouped) {
             int32_t combos[AHEAD];
             for (int b = 0; b < B.n; ++b) combos[b] = e->order[B.first_item + b * T];
-            int rc = do_accumulate(e, combos, B.n, e->d_Kslots.p, 0, -1, (u64)pairs);
+            int rc = do_accumulate(e, combos, B.n, e->d_Kslots.p, 0, -1, (u64)pairs, B.part);
             if (rc == FSK_RETRY_UNGROUPED) grouped = false;  // too many updates for one stream: from here on one iteration at a time
             else if (rc) return rc;
         }
@@ -1055,6 +1160,22 @@ int run_variance_mode(fsk_engine* e, int T) {
             auto t0 = now();
             FSK_HIP(hipEventSynchronize(ev_done[A.part]));
             t_wait += ms_since(t0);
+            if (!sx_harvest(e, A.part)) {
+                // A was enqueued ahead of its word count and did not fit the update streams: its slot
+                // triangles were not written. Everything issued after it started from A's state: drop
+                // it all and run A again, sized exactly.
+                FSK_HIP(hipStreamSynchronize(e->stream));
+                FSK_HIP(hipStreamSynchronize(e->chain_stream));
+                for (const Batch& B : q) { e->st.combos_done -= B.n; e->sx_defer[B.part].active = false; }
+                q.clear();
+                const int was = e->sx_sync;
+                e->sx_sync = 1;
+                int rc = issue(A);
+                e->sx_sync = was;
+                if (rc) return rc;
+                q.push_back(A);
+                continue;
+            }
             int accepted = 0;
             for (int b = 0; b < A.n && working; ++b) {
                 double v = h_avg[(size_t)A.part * AHEAD + b] / (double)train_pairs;
@@ -1078,6 +1199,7 @@ int run_variance_mode(fsk_engine* e, int T) {
                     FSK_HIP(hipStreamSynchronize(e->stream));
                     FSK_HIP(hipStreamSynchronize(e->chain_stream));
                 }
+                for (const Batch& B : q) (void)sx_harvest(e, B.part);
                 break;
             }
             // (working implies more items and iterations: the queue is not empty)
@@ -1172,6 +1294,8 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     enumerate_combos(cfg->g, e->k, e->all_pos);
     { const char* f = getenv("FSK_COMPACT"); e->force_compact = f ? atoi(f) : -1; }
     { const char* f = getenv("FSK_SPARSE_GLOBAL"); e->force_global_pairs = f ? atoi(f) : 0; }
+    { const char* f = getenv("FSK_SPARSE_SYNC"); if (f) e->sx_sync = atoi(f); }
+    { const char* f = getenv("FSK_SPARSE_GUARD_CAP"); if (f && atoll(f) > 0) e->sx_guard_cap = (u64)atoll(f); }
     { const char* f = getenv("FSK_LIST_MAX_WORDS"); if (f && atoll(f) > 0) e->sx_max_words = std::min<u64>(SX_MAX_LIST_WORDS, (u64)atoll(f)); }
     { const char* f = getenv("FSK_TILE_SPLITS"); e->force_splits = f ? atoi(f) : 0; }
     { const char* f = getenv("FSK_TILE_DMA"); e->tile_dma = f ? atoi(f) : 1; }
@@ -1200,6 +1324,8 @@ void fsk_destroy(fsk_engine* e) {
     e->d_owner_r0.release(); e->d_ucount.release(); e->d_uchunk.release(); e->d_part_base.release(); e->d_tile_stat.release(); e->d_utot.release(); e->d_list_off.release(); e->d_ulist.release();
     e->d_tile_lrh.release(); e->d_tile_rs.release(); e->d_tile_lth.release(); e->d_tile_ts.release(); e->d_Tk.release(); e->d_E.release(); e->d_sxstat.release(); e->d_U.release(); e->d_U2.release();
     if (e->h_prod) (void)hipHostFree(e->h_prod);
+    if (e->h_sx_pos) (void)hipHostFree(e->h_sx_pos);
+    if (e->h_sx_stat) (void)hipHostFree(e->h_sx_stat);
     if (e->ev_order) (void)hipEventDestroy(e->ev_order);
     if (e->chain_stream) { (void)hipStreamSynchronize(e->chain_stream); (void)hipStreamDestroy(e->chain_stream); }
     (void)hipEventDestroy(e->ev0);
@@ -1378,6 +1504,8 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
     e->prep_valid = false; e->tab_n = 0; e->vc_sum = 0; e->vc_n = 0;
     e->lazy_lo = e->lazy_hi = -1;  // (the triangle is filled with zeros below)
     e->u_known = false; e->u_pending = false; e->u_extra = 0; e->u_value = 0;
+    e->sx_words_seen = 0;
+    for (auto& d : e->sx_defer) d.active = false;
     if (e->V > DENSE_MAX_KEYS) e->Vq = 1;  // unused on the sparse path
     {   // sparse dataflow: sort record = (k-mer << sx_sb) | sequence id; owner bands of K
         e->sx_sb = 1;
@@ -1756,6 +1884,7 @@ int fsk_get_stats(fsk_engine* e, fsk_stats* out) {
             hipMemcpy(&U, e->d_U.p, sizeof U, hipMemcpyDeviceToHost) == hipSuccess)
             e->st.cell_updates = U + e->u_extra;
     }
+    e->st.batches_redone = (double)e->sx_redone;
     *out = e->st;
     return FSK_OK;
 }

@@ -101,7 +101,8 @@ typedef struct fsk_stats {
     double max_windows;      /* max over sequences of (length - g + 1): bounds a cell per combo  */
     double count_launches;   /* launches of the segment-count kernel (panel cache misses)        */
     double compact_keys_avg; /* key compaction on: mean keys per combo that really occur (else 0) */
-    double reserved[2];
+    double batches_redone;   /* sparse: batches enqueued ahead of their word count that did not fit */
+    double reserved[1];
 } fsk_stats;
 
 /* ---- lifecycle: replaces FastSK::FastSK (fastsk.cpp:19-28) and ~nothing (the reference leaks) */

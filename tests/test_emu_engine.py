@@ -421,11 +421,36 @@ def test_emu_sparse_pair_accumulation_variants(emu_lib, port, monkeypatch, globa
     assert e.stats()["cell_updates"] == U
 
 
-@pytest.mark.parametrize("env", [{"FSK_SPARSE_GLOBAL": "1"}, {"FSK_LIST_MAX_WORDS": "2000"}, {}])
+@pytest.mark.parametrize("cap", [None, "100"])
+def test_emu_sparse_batches_enqueued_ahead_of_their_size(emu_lib, port, monkeypatch, cap):
+    """Sparse dataflow: after the first batch of a set of sequences, batches are enqueued without
+    waiting for their update-word count; one that does not fit the stream buffer leaves K alone and
+    is redone sized exactly (FSK_SPARSE_GUARD_CAP makes every such batch overflow)."""
+    from fastsk_amd import _native
+    if cap:
+        monkeypatch.setenv("FSK_SPARSE_GUARD_CAP", cap)
+    d = load_golden("f5_prot11_exact")
+    combos = np.arange(0, 210, 15, dtype=np.int32)
+    want, _, U = port.raw_counts(d["tokens"], d["offsets"], d["g"], d["m"], combos)
+    e = _native.Engine(d["g"], d["m"], path=2, lib=emu_lib)
+    e.load_sequences(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+    for part in np.array_split(combos, 4):
+        e.accumulate(part)
+    e.finalize()
+    assert np.array_equal(e.get_counts(), want)
+    st = e.stats()
+    assert st["cell_updates"] == U
+    assert st["batches_redone"] == (3 if cap else 0)
+    e.close()
+
+
+@pytest.mark.parametrize("env", [{"FSK_SPARSE_GLOBAL": "1"}, {"FSK_LIST_MAX_WORDS": "2000"}, {}, {"FSK_SPARSE_SYNC": "1"},
+                                 {"FSK_SPARSE_GUARD_CAP": "100"}])
 def test_emu_variance_mode_sparse_fallbacks(emu_lib, monkeypatch, env):
     """Variance mode on the sparse dataflow: the iterations of a batch share one sparse pass (a u32
     triangle per slot), unless no update streams exist (atomics) or a batch has too many update words
-    for one stream (then: one iteration at a time) — the three forms give the reference's stdevs."""
+    for one stream (then: one iteration at a time) — all forms give the reference's stdevs; so do
+    batches sized exactly (FSK_SPARSE_SYNC) and batches that overflow their guard and are redone."""
     from fastsk_amd import _native
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -435,6 +460,8 @@ def test_emu_variance_mode_sparse_fallbacks(emu_lib, monkeypatch, env):
     e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
     assert np.array_equal(e.get_stdevs(), d["stdevs"])
     assert np.array_equal(e.get_triangle(), d["tri"])
+    if "FSK_SPARSE_GUARD_CAP" in env:
+        assert e.stats()["batches_redone"] > 0
     e.close()
 
 

@@ -705,10 +705,36 @@ def test_sequential_sum_on_the_device(native):
     e.close()
 
 
-@pytest.mark.parametrize("env", [{"FSK_SPARSE_GLOBAL": "1"}, {"FSK_LIST_MAX_WORDS": "200000"}, {}])
+@pytest.mark.parametrize("env", [{}, {"FSK_SPARSE_SYNC": "1"}, {"FSK_SPARSE_GUARD_CAP": "5000"}])
+def test_sparse_batches_enqueued_ahead_of_their_size(native, port, monkeypatch, env):
+    """Sparse dataflow, several accumulate calls: batches after the first are enqueued before their
+    update-word count is known; the same counts and U as batches sized one by one, also when every
+    such batch overflows the (shrunk) guard and is redone."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    tokens, offsets = synthetic_dna(900, 120, seed=21)
+    g, m = 12, 6
+    combos = np.arange(0, port.num_combos(g, m), 5, dtype=np.int32)
+    want, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=8)
+    e = native.Engine(g, m, path=2)
+    e.load_sequences(tokens, offsets, 600, 300)
+    parts = np.array_split(combos, 5)
+    for part in parts:
+        e.accumulate(part)
+    e.finalize()
+    assert np.array_equal(e.get_counts(), want)
+    st = e.stats()
+    assert st["cell_updates"] == U
+    assert st["batches_redone"] == (len(parts) - 1 if "FSK_SPARSE_GUARD_CAP" in env else 0)
+    e.close()
+
+
+@pytest.mark.parametrize("env", [{"FSK_SPARSE_GLOBAL": "1"}, {"FSK_LIST_MAX_WORDS": "200000"}, {}, {"FSK_SPARSE_SYNC": "1"},
+                                 {"FSK_SPARSE_GUARD_CAP": "5000"}])
 def test_variance_mode_sparse_forms(native, monkeypatch, env):
-    """Variance mode through the sparse dataflow in its three forms (grouped batches with a u32 triangle
-    per slot; atomics; ungrouped after a batch too large for one stream): the reference's stdevs and
+    """Variance mode through the sparse dataflow in its forms (grouped batches with a u32 triangle
+    per slot; atomics; ungrouped after a batch too large for one stream; batches sized one by one;
+    batches that overflow their guard and are redone): the reference's stdevs and
     triangle, bit for bit, on the protein slice and on BASELINE config 1 at full size."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
