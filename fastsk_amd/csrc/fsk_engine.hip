@@ -108,7 +108,8 @@ struct fsk_engine {
 
     // combos
     std::vector<uint8_t> all_pos;  // [ncomb][k]
-    DevBuf<uint8_t> d_pos;
+    DevBuf<uint8_t> d_pos, d_allpos;  // positions of the batch at hand; of all combos (sparse dataflow, small batches)
+    bool allpos_ready = false;
     std::vector<int32_t> order;
     bool order_set = false;
     uint64_t seed = 0;
@@ -401,7 +402,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         FSK_HIP(e->d_tile_lth.reserve(ntiles));
         FSK_HIP(e->d_tile_ts.reserve(ntiles));
     }
-    FSK_HIP(e->d_sxstat.reserve(2));
+    FSK_HIP(e->d_sxstat.reserve(3));
     FSK_HIP(e->d_tile_stat.reserve((size_t)2 * ntiles));
     FSK_HIP(e->d_pos.reserve((size_t)nb * e->k));
     if (!e->owner_ready) {
@@ -417,10 +418,22 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         FSK_HIP(e->d_list_off.reserve((size_t)O + 1));
         FSK_HIP(e->d_part_base.reserve((size_t)O + 1));
     }
-    for (int s = 0; s < nb; ++s)
-        memcpy(pos_pin + (size_t)s * e->k, &e->all_pos[(size_t)combos[s] * e->k], e->k);
-    FSK_HIP(hipMemcpyAsync(e->d_pos.p, pos_pin, (size_t)nb * e->k, hipMemcpyHostToDevice, e->stream));
-    FSK_HIP(hipMemsetAsync(e->d_sxstat.p, 0, 2 * sizeof(u64), e->stream));
+    if (nb <= 16) {  // (variance mode: a handful of combos per batch)
+        if (!e->allpos_ready) {
+            FSK_HIP(e->d_allpos.reserve(e->all_pos.size()));
+            FSK_HIP(hipMemcpy(e->d_allpos.p, e->all_pos.data(), e->all_pos.size(), hipMemcpyHostToDevice));
+            e->allpos_ready = true;
+        }
+        fsk::SxIds ids{};
+        for (int s = 0; s < nb; ++s) ids.id[s] = combos[s];
+        FSK_LAUNCH(fsk::k_sx_begin, dim3(1), dim3(256), 0, e->stream, (const uint8_t*)e->d_allpos.p, ids, nb, e->k, e->d_pos.p, e->d_sxstat.p);
+        e->st.launches += 1;
+    } else {
+        for (int s = 0; s < nb; ++s)
+            memcpy(pos_pin + (size_t)s * e->k, &e->all_pos[(size_t)combos[s] * e->k], e->k);
+        FSK_HIP(hipMemcpyAsync(e->d_pos.p, pos_pin, (size_t)nb * e->k, hipMemcpyHostToDevice, e->stream));
+        FSK_HIP(hipMemsetAsync(e->d_sxstat.p, 0, 3 * sizeof(u64), e->stream));
+    }
 
     RecT* rec[2] = {(RecT*)e->d_keys[0].p, (RecT*)e->d_keys[1].p};
 
@@ -458,7 +471,8 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                e->d_ebase.p, e->d_tile_rs.p, e->d_E.p, e->d_Pk.p, e->sx_own_shift, O,
                lists ? e->d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->d_tile_stat.p,
                skip_from, skipping ? (const int*)e->d_tile_ts.p : (const int*)nullptr, skipping ? e->d_Tk.p : (uint32_t*)nullptr);
-    FSK_LAUNCH(fsk::k_sx_stat_sum, dim3(32), dim3(256), 0, e->stream, (const u64*)e->d_tile_stat.p, ntiles, e->d_sxstat.p);
+    stat_pin[0] = stat_pin[1] = 0;
+    FSK_LAUNCH(fsk::k_sx_stat_sum, dim3(32), dim3(256), 0, e->stream, (const u64*)e->d_tile_stat.p, ntiles, e->d_sxstat.p, stat_pin);
     e->st.launches += 4;
     u64 words = 0;
     if (lists) {  // where every (tile, owner) share of the update streams starts
@@ -468,8 +482,6 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         FSK_LAUNCH(fsk::k_sx_ucol_apply, dim3(nchunks), dim3(256), 0, e->stream, e->d_ucount.p, ntiles, O, (const uint32_t*)e->d_uchunk.p);
         e->st.launches += 4;
     }
-    stat_pin[0] = stat_pin[1] = 0;
-    FSK_HIP(hipMemcpyAsync(stat_pin, e->d_sxstat.p, 2 * sizeof(u64), hipMemcpyDeviceToHost, e->stream));
     const bool guarded = guard_cap != 0;
     uint32_t cap_words = 0xffffffffu;
     if (guarded) {
@@ -1048,7 +1060,6 @@ int run_variance_mode(fsk_engine* e, int T) {
     FSK_HIP(e->d_seqblk.reserve(nblk * slots * sizeof(fsk::SeqBlk)));
     FSK_HIP(hipMemsetAsync(e->d_Kf64.p, 0, (size_t)pairs * sizeof(double), e->stream));
     FSK_HIP(hipMemsetAsync(e->d_bsum.p, 0, (nblk * slots + slots) * sizeof(double), e->stream));
-    double* d_avg = e->d_bsum.p + nblk * slots;  // one result per slot, behind the block sums
     if (e->h_prod_cap < slots) {
         if (e->h_prod) (void)hipHostFree(e->h_prod);
         e->h_prod = nullptr; e->h_prod_cap = 0;
@@ -1126,10 +1137,9 @@ int run_variance_mode(fsk_engine* e, int T) {
         // second stream, under the kernels of the batches that follow
         const size_t slot0 = (size_t)B.part * AHEAD;
         int rc = enqueue_sequential_sum(e, e->d_prod.p + slot0 * tp, (u64)train_pairs, e->d_bsum.p + slot0 * nblk,
-                                        reinterpret_cast<fsk::SeqBlk*>(e->d_seqblk.p) + slot0 * nblk, d_avg + slot0, B.n, (u64)tp,
-                                        e->chain_stream, ev_hand[B.part]);
+                                        reinterpret_cast<fsk::SeqBlk*>(e->d_seqblk.p) + slot0 * nblk, h_avg + slot0, B.n, (u64)tp,
+                                        e->chain_stream, ev_hand[B.part]);  // (the sums land in pinned host memory)
         if (rc) return rc;
-        FSK_HIP(hipMemcpyAsync(h_avg + slot0, d_avg + slot0, (size_t)B.n * sizeof(double), hipMemcpyDeviceToHost, e->chain_stream));
         FSK_HIP(hipEventRecord(ev_done[B.part], e->chain_stream));
         return FSK_OK;
     };
@@ -1317,7 +1327,7 @@ void fsk_destroy(fsk_engine* e) {
     DeviceScope on_device(e->cfg.device);
     (void)hipStreamSynchronize(e->stream);
     e->d_words.release(); e->d_wstart.release(); e->d_len.release(); e->d_fstart.release(); e->d_featseq.release();
-    e->d_pos.release(); e->d_bsum.release(); e->d_seqblk.release(); e->K_store.release(); e->d_Kf64.release(); e->d_Khat.release(); e->d_prod.release();
+    e->d_pos.release(); e->d_allpos.release(); e->d_bsum.release(); e->d_seqblk.release(); e->K_store.release(); e->d_Kf64.release(); e->d_Khat.release(); e->d_prod.release();
     e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_Kslots.release(); e->d_cell_idx.release(); e->d_C4.release(); e->d_C4H.release(); e->d_rowmask.release(); e->d_flag.release(); e->d_tiletab.release(); e->d_keybits.release(); e->d_lut.release(); e->d_vc.release();
     for (int b = 0; b < 2; ++b) e->d_keys[b].release();
     e->d_blockhist.release(); e->d_totals.release(); e->d_tile_ent.release(); e->d_ebase.release(); e->d_Pk.release();

@@ -754,7 +754,10 @@ __global__ __launch_bounds__(64) void k_seq_chain(const double* p, u64 n, const 
         }
     }
     if (as_int) s = (double)S * seq_pow2(e - 52);
-    if (lane == 0) out[0] = s;
+    if (lane == 0) {
+        out[0] = s;
+        __threadfence_system();  // (`out` may be pinned host memory: the variance mode reads it after the stream's event)
+    }
     for (uint32_t b = lane; b < nblocks; b += 64) bsum[b] = 0.0;
 }
 

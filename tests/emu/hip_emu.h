@@ -267,6 +267,8 @@ static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
 template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 static inline hipError_t hipFree(void* p) { free(p); return 0; }
+static inline void __threadfence() {}
+static inline void __threadfence_system() {}
 static inline hipError_t hipHostMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
 static inline hipError_t hipHostFree(void* p) { free(p); return 0; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
