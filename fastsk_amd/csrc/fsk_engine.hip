@@ -1084,7 +1084,7 @@ int run_variance_mode(fsk_engine* e, int T) {
     const uint32_t wblocks = (uint32_t)((pairs + 256 * fsk::WF_ITEMS - 1) / (256 * fsk::WF_ITEMS)); // k_welford
     const int n_order = (int)e->order.size();
     auto khat = [&](int i) { return e->d_Khat.p + (size_t)(i % RING) * (size_t)pairs; };
-    struct Batch { int n = 0, first_iter = 0, first_item = 0, base = 0, part = 0; };
+    struct Batch { int n = 0, first_iter = 0, first_item = 0, base = 0, part = 0; bool grouped = false; };
     // how many iterations can still follow (end of the work list, max_iters)
     auto plan = [&](int first_iter, int first_item) {
         int n = AHEAD;
@@ -1105,33 +1105,34 @@ int run_variance_mode(fsk_engine* e, int T) {
     // (u32 triangles written whole by k_sx_consume; without update streams — huge N — pairs go to K with
     // atomics and the iterations run one at a time like the dense ones)
     bool grouped = e->path == FSK_PATH_SPARSE && e->sx_lists && !e->force_global_pairs;
-    if (grouped) FSK_HIP(e->d_Kslots.reserve(((size_t)pairs * AHEAD + 1) / 2));
-    auto issue = [&](const Batch& B) -> int {
+    // (one set of slot triangles per batch in flight: a stop inside a batch runs its Welford prefix again)
+    if (grouped) FSK_HIP(e->d_Kslots.reserve(((size_t)pairs * AHEAD * DEPTH + 1) / 2));
+    auto slots_of = [&](int part) { return reinterpret_cast<uint32_t*>(e->d_Kslots.p) + (size_t)part * AHEAD * (size_t)pairs; };
+    static_assert(AHEAD <= fsk::WF_SLOTS, "k_welford_batch carries a batch's iterations in registers");
+    auto issue = [&](Batch& B) -> int {
         if (grouped) {
             int32_t combos[AHEAD];
             for (int b = 0; b < B.n; ++b) combos[b] = e->order[B.first_item + b * T];
-            int rc = do_accumulate(e, combos, B.n, e->d_Kslots.p, 0, -1, (u64)pairs, B.part);
+            int rc = do_accumulate(e, combos, B.n, reinterpret_cast<u64*>(slots_of(B.part)), 0, -1, (u64)pairs, B.part);
             if (rc == FSK_RETRY_UNGROUPED) grouped = false;  // too many updates for one stream: from here on one iteration at a time
             else if (rc) return rc;
         }
-        for (int b = 0; b < B.n; ++b) {
+        B.grouped = grouped;
+        if (grouped) {  // K_hat through the batch's iterations in one pass; only the state after the batch is written
+            const size_t slot0 = (size_t)B.part * AHEAD;
+            FSK_LAUNCH(fsk::k_welford_batch, dim3(wblocks), dim3(256), 0, e->stream, (const uint32_t*)slots_of(B.part), B.n,
+                       (const double*)khat(B.base), khat(B.base + B.n), e->d_prod.p + slot0 * tp, (u64)tp, (u64)pairs, (u64)train_pairs,
+                       (double)B.first_iter, e->d_bsum.p + slot0 * nblk, (uint32_t)nblk, 1);
+        }
+        for (int b = 0; b < B.n && !grouped; ++b) {
             const size_t slot = (size_t)(B.part * AHEAD + b);
-            const uint32_t* Ks32 = reinterpret_cast<const uint32_t*>(e->d_Kslots.p) + (size_t)b * pairs;
-            if (!grouped) {
-                FSK_HIP(hipMemsetAsync(e->d_K, 0, (size_t)pairs * sizeof(u64), e->stream));
-                int32_t combo = e->order[B.first_item + b * T];
-                int rc = do_accumulate(e, &combo, 1, e->d_K);
-                if (rc) return rc;
-            }
-            double* bsum = e->d_bsum.p + slot * nblk;
-            fsk::SeqBlk* blk = reinterpret_cast<fsk::SeqBlk*>(e->d_seqblk.p) + slot * nblk;
-            if (grouped)
-                FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford<uint32_t>), dim3(wblocks), dim3(256), 0, e->stream, Ks32, (const double*)khat(B.base + b),
-                           khat(B.base + b + 1), e->d_prod.p + slot * tp, (u64)pairs, (u64)train_pairs, (double)(B.first_iter + b), bsum);
-            else
-                FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford<u64>), dim3(wblocks), dim3(256), 0, e->stream, (const u64*)e->d_K, (const double*)khat(B.base + b),
-                           khat(B.base + b + 1), e->d_prod.p + slot * tp, (u64)pairs, (u64)train_pairs, (double)(B.first_iter + b), bsum);
-            (void)blk;
+            FSK_HIP(hipMemsetAsync(e->d_K, 0, (size_t)pairs * sizeof(u64), e->stream));
+            int32_t combo = e->order[B.first_item + b * T];
+            int rc = do_accumulate(e, &combo, 1, e->d_K);
+            if (rc) return rc;
+            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford<u64>), dim3(wblocks), dim3(256), 0, e->stream, (const u64*)e->d_K, (const double*)khat(B.base + b),
+                       khat(B.base + b + 1), e->d_prod.p + slot * tp, (u64)pairs, (u64)train_pairs, (double)(B.first_iter + b),
+                       e->d_bsum.p + slot * nblk);
         }
         // the batch's sums: block totals on all CUs, then one wave per iteration walks its blocks — on a
         // second stream, under the kernels of the batches that follow
@@ -1180,10 +1181,11 @@ int run_variance_mode(fsk_engine* e, int T) {
                 q.clear();
                 const int was = e->sx_sync;
                 e->sx_sync = 1;
-                int rc = issue(A);
+                Batch R = A;
+                int rc = issue(R);
                 e->sx_sync = was;
                 if (rc) return rc;
-                q.push_back(A);
+                q.push_back(R);
                 continue;
             }
             int accepted = 0;
@@ -1210,6 +1212,10 @@ int run_variance_mode(fsk_engine* e, int T) {
                     FSK_HIP(hipStreamSynchronize(e->chain_stream));
                 }
                 for (const Batch& B : q) (void)sx_harvest(e, B.part);
+                if (A.grouped && accepted < A.n)  // the stop fell inside the batch: the state after its accepted prefix
+                    FSK_LAUNCH(fsk::k_welford_batch, dim3(wblocks), dim3(256), 0, e->stream, (const uint32_t*)slots_of(A.part), accepted,
+                               (const double*)khat(A.base), khat(A.base + accepted), (double*)nullptr, (u64)0, (u64)pairs, (u64)train_pairs,
+                               (double)A.first_iter, (double*)nullptr, (uint32_t)0, 0);
                 break;
             }
             // (working implies more items and iterations: the queue is not empty)

@@ -526,6 +526,59 @@ __global__ __launch_bounds__(256) void k_welford(const SrcT* Ks, const double* K
     }
 }
 
+// The same for the `nslots` consecutive iterations of a batch whose counts lie in u32 triangles `pairs`
+// cells apart (sparse dataflow, grouped batches): K_hat is read once, carried through the iterations in
+// a register and written once — the state after the batch; the states in between exist only if the
+// host asks for them by running a prefix of the batch again (it does when its stop test fires inside
+// the batch). Per cell and iteration the same IEEE operations in the same order as k_welford.
+// prod / bsum of slot q: prod + q * prod_stride, bsum + q * nblk; write_prod = 0: only K_hat_out.
+constexpr int WF_SLOTS = 4;
+__global__ __launch_bounds__(256) void k_welford_batch(const uint32_t* Ks, int nslots, const double* K_hat_in, double* K_hat_out, double* prod,
+                                                       u64 prod_stride, u64 pairs, u64 train_pairs, double first_iter, double* bsum,
+                                                       uint32_t nblk, int write_prod) {
+    __shared__ double part[WF_SLOTS][4];
+    const u64 base = (u64)blockIdx.x * (256 * WF_ITEMS);
+    double pr[WF_SLOTS];
+#pragma unroll
+    for (int s = 0; s < WF_SLOTS; ++s) pr[s] = 0.0;
+#pragma unroll
+    for (int q = 0; q < WF_ITEMS; ++q) {
+        const u64 i = base + (u64)q * 256 + threadIdx.x;
+        if (i < pairs) {
+            uint32_t xs[WF_SLOTS];
+#pragma unroll
+            for (int s = 0; s < WF_SLOTS; ++s) xs[s] = s < nslots ? Ks[(u64)s * pairs + i] : 0u;  // (all loads before the dependent chain)
+            double kh = K_hat_in[i];
+#pragma unroll
+            for (int s = 0; s < WF_SLOTS; ++s) {
+                if (s < nslots) {
+                    const double x = (double)xs[s];
+                    const double delta = __dsub_rn(x, kh);
+                    kh = __dadd_rn(kh, __ddiv_rn(delta, first_iter + (double)s));
+                    if (write_prod && i < train_pairs) {
+                        const double v = __dmul_rn(delta, __dsub_rn(x, kh));
+                        prod[(u64)s * prod_stride + i] = v;
+                        pr[s] += v;
+                    }
+                }
+            }
+            K_hat_out[i] = kh;
+        }
+    }
+    if (!write_prod || base >= train_pairs) return;  // (uniform per workgroup)
+#pragma unroll
+    for (int s = 0; s < WF_SLOTS; ++s) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) pr[s] += __shfl_xor(pr[s], d);
+        if ((threadIdx.x & 63) == 0) part[s][threadIdx.x >> 6] = pr[s];
+    }
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)nslots) {
+        const double t = (part[threadIdx.x][0] + part[threadIdx.x][1]) + (part[threadIdx.x][2] + part[threadIdx.x][3]);
+        if (t != 0.0) atomicAdd(&bsum[(size_t)threadIdx.x * nblk + base / SQ_BLOCK], t);
+    }
+}
+
 // ---- exact sequential summation, in parallel ---------------------------------------------------
 // s_i = fl(s_{i-1} + p_i), p_i >= 0, round to nearest even. While the running sum stays inside one
 // binade [2^e, 2^(e+1)) every s_i is a multiple of u = 2^(e-52), so fl(s + p) = s + R(p) with R(p) the

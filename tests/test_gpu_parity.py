@@ -665,10 +665,12 @@ def test_register_staged_tile_kernel_still_agrees(native, port, monkeypatch):
         e.close()
 
 
-def test_variance_mode_stops_anywhere(native, port):
-    """Variance mode runs ahead of its stop test (batches of 4 iterations, two in flight, copy
-    stream, host threads): whatever the chain count, max_iters and delta, stdevs and the kernel are
-    the oracle's, bit for bit."""
+@pytest.mark.parametrize("path", [0, 2])
+def test_variance_mode_stops_anywhere(native, port, path):
+    """Variance mode runs ahead of its stop test (batches of 4 iterations, two in flight, second
+    stream): whatever the chain count, max_iters and delta, stdevs and the kernel are
+    the oracle's, bit for bit — on the dense dataflow (the Welford state of every iteration kept) and
+    on the sparse one (the state written once per batch; a stop inside a batch runs its prefix again)."""
     rng = np.random.default_rng(5)
     X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(12, 40, size=30)]
     tok, off = native.flatten(X)
@@ -679,7 +681,7 @@ def test_variance_mode_stops_anywhere(native, port):
         for max_iters in (-1, 1, 2, 4, 5, 6, 9):
             for delta in (0.025, 0.2, 0.5, 1.0, 3.0):
                 want, sd, _ = port.compute(tok, off, 22, 8, g, m, t=T, approx=True, delta=delta, max_iters=max_iters, order=order)
-                e = native.Engine(g, m, t=T, approx=True, delta=delta, max_iters=max_iters)
+                e = native.Engine(g, m, t=T, approx=True, delta=delta, max_iters=max_iters, path=path)
                 e.set_combo_order(order)
                 e.compute(tok, off, 22, 8)
                 assert np.array_equal(e.get_stdevs(), sd), (T, max_iters, delta)
