@@ -608,13 +608,16 @@ __device__ __forceinline__ double seq_pow2(int e) {  // 2^e, -1022 <= e <= 1023
     DblBits b; b.u = (u64)(e + 1023) << 52;
     return b.d;
 }
-// R(p)/u of one value for scale = 1/u, added to q; limit bounds a single value so that q cannot wrap
+// R(p)/u of one value for scale = 1/u, added to q; limit (<= 2^52) bounds a single value so that q cannot
+// wrap and so that x + 2^52 is x rounded to the nearest integer (ties to even), held in the low 52 bits
 __device__ __forceinline__ void seq_classify(double p, double scale, double limit, u64& q, uint32_t& flags) {
     if (!(p >= 0.0)) { flags |= 1u; return; }  // (-0.0 passes and adds nothing)
     const double x = p * scale;                // exact: a power of two
     if (!(x < limit)) { flags |= 2u; return; }
-    if (x - floor(x) == 0.5) flags |= 4u;
-    q += (u64)rint(x);
+    DblBits y;
+    y.d = __dadd_rn(x, 4503599627370496.0);
+    if (fabs(__dsub_rn(x, __dsub_rn(y.d, 4503599627370496.0))) == 0.5) flags |= 4u;  // (both differences are exact)
+    q += y.u & 0xfffffffffffffull;
 }
 
 // bsum[b] = sum of block b in any order (stand-alone use of the summation; variance mode gets these
@@ -699,6 +702,31 @@ __device__ __forceinline__ double wave_bcast_f64(double x, uint32_t src) {
     return b.d;
 }
 
+// sum of x over the 64 lanes, in every lane. On the critical path of k_seq_chain (one wave, nothing to
+// overlap with), so through the DPP row shifts / broadcasts of the VALU rather than six dependent LDS
+// permutes per 32-bit half: rows of 16 lanes first, then row 0 -> 1 and 2 -> 3, then lane 31 -> rows 2-3.
+__device__ __forceinline__ u64 wave_sum_u64(u64 x) {
+#ifdef FSK_EMU
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+    return x;
+#else
+#define FSK_DPP_ADD64(ctrl, rows)                                                                                   \
+    {                                                                                                               \
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, ctrl, rows, 0xf, true);      \
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), ctrl, rows, 0xf, true); \
+        x += ((u64)hi << 32) | lo;                                                                                  \
+    }
+    FSK_DPP_ADD64(0x111, 0xf)  // row_shr:1
+    FSK_DPP_ADD64(0x112, 0xf)  // row_shr:2
+    FSK_DPP_ADD64(0x114, 0xf)  // row_shr:4
+    FSK_DPP_ADD64(0x118, 0xf)  // row_shr:8  -> lane 15 of every row holds the row's sum
+    FSK_DPP_ADD64(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+    FSK_DPP_ADD64(0x143, 0xc)  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+#undef FSK_DPP_ADD64
+    return wave_bcast_u64(x, 63u);
+#endif
+}
+
 // PER values per lane (held in registers; 0.0 where the range ended) added to s as one integer total,
 // if the conditions hold
 template <int PER>
@@ -711,52 +739,58 @@ __device__ __forceinline__ bool seq_try_regs(const double (&v)[PER], double& s) 
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         if (v[k] != 0.0) nonzero = 1u;
-        seq_classify(v[k], scale, 9007199254740992.0 /* 2^53 */, q, fl);
+        seq_classify(v[k], scale, 4503599627370496.0 /* 2^52 */, q, fl);
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        q += __shfl_xor(q, d);
-        fl |= __shfl_xor(fl, d);
-        nonzero |= __shfl_xor(nonzero, d);
-    }
-    if (!nonzero) return true;  // zeros change no running sum, whatever it is (s starts at +0 and +0 + -0 = +0)
-    if (!usable) return false;
-    const u64 tot = (u64)(s * scale) + q;
-    if (fl != 0u || tot >= ((u64)1 << 53)) return false;
+    if (__ballot(nonzero != 0u) == 0ull) return true;  // zeros change no running sum, whatever it is (s starts at +0 and +0 + -0 = +0)
+    if (!usable || __ballot(fl != 0u) != 0ull) return false;
+    const u64 tot = (u64)(s * scale) + wave_sum_u64(q);
+    if (tot >= ((u64)1 << 53)) return false;
     s = (double)tot * seq_pow2(e - 52);
     return true;
 }
-// The values [lo, hi) added to s: groups of 1024 (16 per lane, value lo + 64 k + lane in register k,
-// the next group's loads in flight meanwhile), then the 16 sub-groups of 64, then plain sequential
-// additions — all from registers — for a group that crosses a binade, holds a tie or a negative value.
-// s and every decision are wave-uniform.
-__device__ __forceinline__ double seq_range(const double* p, u64 lo, u64 hi, double s) {
+// The values [lo, hi) added to s by one wave (a workgroup of its own): SQ_STAGE values at a time go
+// through registers into LDS — the loads of the next stage are in flight while this one is summed — and
+// are taken from there in groups of 1024 (16 per lane, value 64 k + lane in register k), then for a
+// group that crosses a binade, holds a tie or a negative value in its 16 sub-groups of 64, then by plain
+// sequential additions. s and every decision are wave-uniform.
+constexpr int SQ_STAGE = 4096;
+__device__ __forceinline__ double seq_range(const double* p, u64 lo, u64 hi, double s, double* stage) {
     const uint32_t lane = threadIdx.x & 63u;
-    double cur[16], nxt[16];
+    constexpr int PER = SQ_STAGE / 64;
+    double nx[PER];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < PER; ++k) {
         const u64 i = lo + (u64)k * 64 + lane;
-        cur[k] = i < hi ? p[i] : 0.0;
+        nx[k] = i < hi ? p[i] : 0.0;
     }
-    for (u64 a0 = lo; a0 < hi; a0 += 1024) {
+    for (u64 c0 = lo; c0 < hi; c0 += SQ_STAGE) {
+        __syncthreads();  // (one wave: orders the LDS reads of the stage before with these writes)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const u64 i = a0 + 1024 + (u64)k * 64 + lane;
-            nxt[k] = i < hi ? p[i] : 0.0;
+        for (int k = 0; k < PER; ++k) stage[k * 64 + (int)lane] = nx[k];
+        if (c0 + SQ_STAGE < hi) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const u64 i = c0 + SQ_STAGE + (u64)k * 64 + lane;
+                nx[k] = i < hi ? p[i] : 0.0;
+            }
         }
-        if (!seq_try_regs<16>(cur, s)) {
+        __syncthreads();
+        const uint32_t here = hi - c0 < (u64)SQ_STAGE ? (uint32_t)(hi - c0) : (uint32_t)SQ_STAGE;
+        for (uint32_t g0 = 0; g0 < here; g0 += 1024u) {
+            double cur[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const double one[1] = {cur[k]};
+            for (int k = 0; k < 16; ++k) cur[k] = stage[g0 + (uint32_t)k * 64u + lane];  // (0.0 beyond hi)
+            if (seq_try_regs<16>(cur, s)) continue;
+#pragma unroll 1
+            for (uint32_t k = 0; k < 16u; ++k) {  // (rolled: a rare path, kept small)
+                const uint32_t q0 = g0 + k * 64u;
+                const double one[1] = {stage[q0 + lane]};
                 if (!seq_try_regs<1>(one, s)) {
-                    const u64 c0 = a0 + (u64)k * 64;
-                    const uint32_t cn = c0 >= hi ? 0u : (hi - c0 < 64 ? (uint32_t)(hi - c0) : 64u);
-                    for (uint32_t j = 0; j < cn; ++j) s = __dadd_rn(s, wave_bcast_f64(cur[k], j));
+                    const uint32_t cn = q0 >= here ? 0u : (here - q0 < 64u ? here - q0 : 64u);
+                    for (uint32_t j = 0; j < cn; ++j) s = __dadd_rn(s, wave_bcast_f64(one[0], j));
                 }
             }
         }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
     }
     return s;
 }
@@ -765,6 +799,7 @@ __device__ __forceinline__ double seq_range(const double* p, u64 lo, u64 hi, dou
 // (blockIdx.x = one of several independent sums laid out `stride` values / `nblocks` blocks apart)
 __global__ __launch_bounds__(64) void k_seq_chain(const double* p, u64 n, const SeqBlk* blk, uint32_t nblocks, double* bsum, double* out,
                                                   u64 stride) {
+    __shared__ double stage[SQ_STAGE];
     const uint32_t lane = threadIdx.x;
     p += (u64)blockIdx.x * stride;
     blk += (size_t)blockIdx.x * nblocks;
@@ -803,7 +838,7 @@ __global__ __launch_bounds__(64) void k_seq_chain(const double* p, u64 n, const 
                 as_int = false;
             }
             const u64 lo = (u64)(c0 + j) * SQ_BLOCK, hi = lo + SQ_BLOCK < n ? lo + SQ_BLOCK : n;
-            s = seq_range(p, lo, hi, s);
+            s = seq_range(p, lo, hi, s, stage);
         }
     }
     if (as_int) s = (double)S * seq_pow2(e - 52);
