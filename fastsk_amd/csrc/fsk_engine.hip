@@ -141,6 +141,7 @@ struct fsk_engine {
     DevBuf<unsigned char> d_keys[2];      // packed sort records (u32 or u64), double-buffered
     DevBuf<uint32_t> d_blockhist, d_totals, d_tile_ent, d_ebase, d_Pk, d_Tk, d_owner_r0, d_ucount, d_uchunk, d_utot, d_list_off, d_ulist, d_part_base;
     DevBuf<u64> d_tile_stat;
+    DevBuf<uint32_t> d_segc;              // chunk records of the segment scan (batches of many tiles)
     DevBuf<int> d_tile_lrh, d_tile_rs, d_tile_lth, d_tile_ts;
     DevBuf<uint2> d_E;                    // entries: {sequence, multiplicity}
     DevBuf<u64> d_sxstat, d_U;
@@ -166,6 +167,7 @@ struct fsk_engine {
     size_t h_sx_stat_cap = 0;
     u64 sx_words_seen = 0;               // largest word count of a batch since the sequences were loaded
     struct SxDefer { bool active = false; u64 cap = 0; } sx_defer[8];
+    int force_seg_chunks = 0;            // FSK_SEG_SCAN_CHUNKED=1: the three-launch segment scan whatever the tile count (testing)
     int sx_sync = 0;                     // FSK_SPARSE_SYNC=1: size every batch exactly (testing); also while redoing a batch
     u64 sx_guard_cap = 0;                // FSK_SPARSE_GUARD_CAP=n: pretend the stream buffer holds n words (testing the redo)
     u64 sx_redone = 0;                   // batches redone because they did not fit
@@ -465,8 +467,34 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     const uint32_t cmax = maxprod / std::max<uint32_t>(1u, e->maxW);  // multiplicities up to here: one word per pair
     FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_seg_count<RecT>), dim3(tpg, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tpg, sb,
                e->d_tile_ent.p, e->d_tile_lrh.p, skip_from, skipping ? e->d_tile_lth.p : (int*)nullptr);
-    FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(1), dim3(1024), 0, e->stream, e->d_tile_ent.p, e->d_tile_lrh.p, ntiles, e->d_ebase.p,
-               e->d_tile_rs.p, skipping ? (const int*)e->d_tile_lth.p : (const int*)nullptr, skipping ? e->d_tile_ts.p : (int*)nullptr);
+    {
+        const int* lth = skipping ? (const int*)e->d_tile_lth.p : (const int*)nullptr;
+        int* ts = skipping ? e->d_tile_ts.p : (int*)nullptr;
+        if (ntiles <= 4096u && !e->force_seg_chunks) {  // one workgroup walks the tile records
+            FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(1), dim3(1024), 0, e->stream, (const uint32_t*)e->d_tile_ent.p, (const int*)e->d_tile_lrh.p, ntiles,
+                       e->d_ebase.p, e->d_tile_rs.p, lth, ts, (const uint32_t*)nullptr, (const int*)nullptr, (const int*)nullptr,
+                       (uint32_t*)nullptr, (int*)nullptr, (int*)nullptr);
+        } else {  // chunk totals, the same scan over the chunk records, the chunks with their carries
+            const uint32_t nch = (ntiles + 1023u) / 1024u;
+            FSK_HIP(e->d_segc.reserve((size_t)6 * (nch + 1)));
+            uint32_t* c_tot = e->d_segc.p;
+            int* c_lrh = reinterpret_cast<int*>(c_tot + (nch + 1));
+            int* c_lth = c_lrh + (nch + 1);
+            uint32_t* c_ex = reinterpret_cast<uint32_t*>(c_lth + (nch + 1));
+            int* c_h = reinterpret_cast<int*>(c_ex + (nch + 1));
+            int* c_t = c_h + (nch + 1);
+            FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(nch), dim3(1024), 0, e->stream, (const uint32_t*)e->d_tile_ent.p, (const int*)e->d_tile_lrh.p, ntiles,
+                       (uint32_t*)nullptr, (int*)nullptr, lth, (int*)nullptr, (const uint32_t*)nullptr, (const int*)nullptr, (const int*)nullptr,
+                       c_tot, c_lrh, c_lth);
+            FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(1), dim3(1024), 0, e->stream, (const uint32_t*)c_tot, (const int*)c_lrh, nch, c_ex, c_h,
+                       skipping ? (const int*)c_lth : (const int*)nullptr, skipping ? c_t : (int*)nullptr, (const uint32_t*)nullptr,
+                       (const int*)nullptr, (const int*)nullptr, (uint32_t*)nullptr, (int*)nullptr, (int*)nullptr);
+            FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(nch), dim3(1024), 0, e->stream, (const uint32_t*)e->d_tile_ent.p, (const int*)e->d_tile_lrh.p, ntiles,
+                       e->d_ebase.p, e->d_tile_rs.p, lth, ts, (const uint32_t*)c_ex, (const int*)c_h, (const int*)c_t, (uint32_t*)nullptr,
+                       (int*)nullptr, (int*)nullptr);
+            e->st.launches += 2;
+        }
+    }
     FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_seg_write<RecT>), dim3(tpg, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tpg, sb,
                e->d_ebase.p, e->d_tile_rs.p, e->d_E.p, e->d_Pk.p, e->sx_own_shift, O,
                lists ? e->d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->d_tile_stat.p,
@@ -1310,6 +1338,7 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     enumerate_combos(cfg->g, e->k, e->all_pos);
     { const char* f = getenv("FSK_COMPACT"); e->force_compact = f ? atoi(f) : -1; }
     { const char* f = getenv("FSK_SPARSE_GLOBAL"); e->force_global_pairs = f ? atoi(f) : 0; }
+    { const char* f = getenv("FSK_SEG_SCAN_CHUNKED"); if (f) e->force_seg_chunks = atoi(f); }
     { const char* f = getenv("FSK_SPARSE_SYNC"); if (f) e->sx_sync = atoi(f); }
     { const char* f = getenv("FSK_SPARSE_GUARD_CAP"); if (f && atoll(f) > 0) e->sx_guard_cap = (u64)atoll(f); }
     { const char* f = getenv("FSK_LIST_MAX_WORDS"); if (f && atoll(f) > 0) e->sx_max_words = std::min<u64>(SX_MAX_LIST_WORDS, (u64)atoll(f)); }
@@ -1338,7 +1367,7 @@ void fsk_destroy(fsk_engine* e) {
     for (int b = 0; b < 2; ++b) e->d_keys[b].release();
     e->d_blockhist.release(); e->d_totals.release(); e->d_tile_ent.release(); e->d_ebase.release(); e->d_Pk.release();
     e->d_owner_r0.release(); e->d_ucount.release(); e->d_uchunk.release(); e->d_part_base.release(); e->d_tile_stat.release(); e->d_utot.release(); e->d_list_off.release(); e->d_ulist.release();
-    e->d_tile_lrh.release(); e->d_tile_rs.release(); e->d_tile_lth.release(); e->d_tile_ts.release(); e->d_Tk.release(); e->d_E.release(); e->d_sxstat.release(); e->d_U.release(); e->d_U2.release();
+    e->d_tile_lrh.release(); e->d_tile_rs.release(); e->d_tile_lth.release(); e->d_tile_ts.release(); e->d_Tk.release(); e->d_E.release(); e->d_sxstat.release(); e->d_segc.release(); e->d_U.release(); e->d_U2.release();
     if (e->h_prod) (void)hipHostFree(e->h_prod);
     if (e->h_sx_pos) (void)hipHostFree(e->h_sx_pos);
     if (e->h_sx_stat) (void)hipHostFree(e->h_sx_stat);

@@ -423,6 +423,29 @@ def test_emu_sparse_pair_accumulation_variants(emu_lib, port, monkeypatch, globa
     assert e.stats()["cell_updates"] == U
 
 
+def test_emu_segment_scan_in_chunks(emu_lib, port, monkeypatch):
+    """Sparse dataflow: the tile records of a batch (entries per tile, last run start) are scanned by
+    one workgroup, or — batches of many tiles — as chunk totals, a scan over the chunks and the chunks
+    with their carries; forced here on a small batch, with and without skip_test_block."""
+    from fastsk_amd import _native
+    monkeypatch.setenv("FSK_SEG_SCAN_CHUNKED", "1")
+    d = load_golden("f5_prot11_exact")
+    combos = np.arange(0, 210, 40, dtype=np.int32)
+    want, _, U = port.raw_counts(d["tokens"], d["offsets"], d["g"], d["m"], combos)
+    N, ntr = d["n_train"] + d["n_test"], d["n_train"]
+    for skip in (False, True):
+        e = _native.Engine(d["g"], d["m"], path=2, skip_test_block=skip, lib=emu_lib)
+        e.load_sequences(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+        e.accumulate(combos)
+        e.finalize()
+        ref = want.copy()
+        if skip:
+            i, j = np.tril_indices(N)
+            ref[(j >= ntr) & (i != j)] = 0
+        assert np.array_equal(e.get_counts(), ref), skip
+        e.close()
+
+
 @pytest.mark.parametrize("cap", [None, "100"])
 def test_emu_sparse_batches_enqueued_ahead_of_their_size(emu_lib, port, monkeypatch, cap):
     """Sparse dataflow: after the first batch of a set of sequences, batches are enqueued without

@@ -819,6 +819,36 @@ def test_skip_test_block_sparse(native, port, monkeypatch, global_pairs):
         e.close()
 
 
+@pytest.mark.parametrize("forced", ["0", "1"])
+def test_sparse_segment_scan_in_chunks(native, port, monkeypatch, forced):
+    """A sparse batch of more than 4096 entry tiles scans its tile records in three launches (chunk
+    totals, the chunks, the tiles with their carries); forced=1 takes that form for the small batches of
+    the row bands too. Counts against the oracle, with and without skip_test_block."""
+    monkeypatch.setenv("FSK_SEG_SCAN_CHUNKED", forced)
+    X = protein_like(2600, 60, 260, seed=33)
+    N, ntr, g, m = len(X), 1700, 8, 4
+    tokens, offsets = native.flatten(X)
+    combos = np.arange(0, 70, 2, dtype=np.int32)   # 35 combos x ~200 tiles each: one batch of ~7000 tiles
+    raw, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=8)
+    i, j = np.tril_indices(N)
+    for skip in (False, True):
+        e = native.Engine(g, m, path=2, skip_test_block=skip)
+        e.load_sequences(tokens, offsets, ntr, N - ntr)
+        if forced == "1":
+            for lo, hi in ((0, 1024), (1024, N)):
+                e.accumulate_rows(combos, lo, hi)
+        else:
+            e.accumulate(combos)
+        e.finalize()
+        ref = raw.copy()
+        if skip:
+            ref[(j >= ntr) & (i != j)] = 0
+        assert np.array_equal(e.get_counts(), ref), skip
+        if not skip:
+            assert e.stats()["cell_updates"] == U
+        e.close()
+
+
 def test_device_resident_block_getter(native):
     """fsk_get_block_device: the normalised block straight into a torch tensor on the GPU."""
     d = load_golden("f4_ep300_exact")
