@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Variance mode on the GPU against the CPU oracle, many random cases: chain count, max_iters, delta,
+alphabet, ragged lengths; both dataflows; sparse batches sized exactly, enqueued ahead of their size, and
+under a guard that overflows (redo). stdevs and the kernel must match bit for bit every time.
+Not part of the pytest suite; run it after touching run_variance_mode or the Welford / sum kernels."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fastsk_amd import _native
+from oracle import loader
+
+
+def main(iters=200, seed=0):
+    rng = np.random.default_rng(seed)
+    port = loader.port()
+    t0 = time.time()
+    stops = set()
+    for it in range(iters):
+        sigma = int(rng.choice([3, 4, 5, 20]))
+        k = int(rng.integers(2, 6 if sigma <= 5 else 4))
+        m = int(rng.integers(1, 5))
+        g = k + m
+        N = int(rng.choice([8, 40, 130, 300]))
+        hi = int(rng.choice([g + 2, 30, 80]))
+        X = [rng.integers(1, sigma + 1, size=int(L)).astype(np.int32) for L in rng.integers(g, max(hi, g) + 1, size=N)]
+        if rng.random() < 0.3:
+            X[int(rng.integers(N))][:] = 1  # a low-complexity row
+        tokens, offsets = _native.flatten(X)
+        ntr = int(rng.integers(2, N + 1))
+        nc = port.num_combos(g, m)
+        order = rng.permutation(nc).astype(np.int32)
+        T = int(rng.choice([1, 1, 2, 3, 5]))
+        max_iters = int(rng.choice([-1, 1, 2, 3, 5, 7, 12]))
+        delta = float(rng.choice([0.01, 0.05, 0.2, 0.6, 2.0]))
+        want, sd, _ = port.compute(tokens, offsets, ntr, N - ntr, g, m, t=T, approx=True, delta=delta, max_iters=max_iters, order=order)
+        stops.add(len(sd))
+        for path in (1, 2):
+            if path == 1 and sigma ** k > 4096:
+                continue
+            for var in ("FSK_SPARSE_SYNC", "FSK_SPARSE_GUARD_CAP", "FSK_LIST_MAX_WORDS"):
+                os.environ.pop(var, None)
+            mode = "default"
+            if path == 2:
+                mode = str(rng.choice(["default", "sync", "overflow", "ungrouped"]))
+                if mode == "sync": os.environ["FSK_SPARSE_SYNC"] = "1"
+                if mode == "overflow": os.environ["FSK_SPARSE_GUARD_CAP"] = str(int(rng.choice([1, 50, 2000])))
+                if mode == "ungrouped": os.environ["FSK_LIST_MAX_WORDS"] = str(int(rng.choice([10, 1000])))
+            e = _native.Engine(g, m, t=T, approx=True, delta=delta, max_iters=max_iters, path=path)
+            e.set_combo_order(order)
+            e.compute(tokens, offsets, ntr, N - ntr)
+            what = (it, path, mode, sigma, g, m, N, T, max_iters, delta)
+            assert np.array_equal(e.get_stdevs(), sd), what
+            assert np.array_equal(e.get_triangle(), want), what
+            e.close()
+        if it % 20 == 0:
+            print("iter %d ok (%.0fs) sigma=%d g=%d m=%d N=%d T=%d max_iters=%d delta=%g stop=%d" % (it, time.time() - t0, sigma, g, m, N, T, max_iters, delta, len(sd)), flush=True)
+    print("variance stress OK: %d random cases, %d distinct stopping iterations" % (iters, len(stops)))
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
