@@ -511,10 +511,10 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         e->st.launches += 4;
     }
     const bool guarded = guard_cap != 0;
-    uint32_t cap_words = 0xffffffffu;
+    u64 cap_words = ~(u64)0;
     if (guarded) {
         words = lists ? std::max<u64>(1, std::min(e->sx_words_seen, guard_cap)) : 0;  // (sizes the parts; the kernels read the true offsets)
-        cap_words = (uint32_t)std::min<u64>(guard_cap, 0xffffffffu);
+        cap_words = guard_cap;
     } else {
         FSK_HIP(hipStreamSynchronize(e->stream));  // the update streams are sized exactly
         e->u_extra += stat_pin[0];
@@ -535,7 +535,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             FSK_LAUNCH(k_emit, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
                        (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)e->d_list_off.p,
                        (const uint32_t*)e->d_ucount.p, e->d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
-                       slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr, cap_words);
+                       slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr, (const u64*)e->d_sxstat.p, cap_words);
             const size_t lds = (size_t)e->sx_cap * sizeof(uint32_t);
 #ifndef FSK_EMU
             FSK_HIP(hipFuncSetAttribute((const void*)fsk::k_sx_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -547,13 +547,13 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             if (slot_stride != 0) {  // one triangle per slot: a slot's words of a stream are one contiguous piece
                 FSK_LAUNCH(fsk::k_sx_consume, dim3(O, e->sx_rounds, nb), dim3(fsk::CS_THREADS), lds, e->stream, (const uint32_t*)e->d_ulist.p,
                            (const uint32_t*)e->d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)nullptr, O, target,
-                           e->sx_cap, e->sx_pb, K, (const uint32_t*)e->d_ucount.p, tpg, slot_stride, cap_words);
+                           e->sx_cap, e->sx_pb, K, (const uint32_t*)e->d_ucount.p, tpg, slot_stride, (const u64*)e->d_sxstat.p, cap_words);
             } else {
                 FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, e->stream, (const uint32_t*)e->d_list_off.p, O, target, e->d_part_base.p,
-                           cap_words);
+                           (const u64*)e->d_sxstat.p, cap_words);
                 FSK_LAUNCH(fsk::k_sx_consume, dim3(max_parts, e->sx_rounds), dim3(fsk::CS_THREADS), lds, e->stream, (const uint32_t*)e->d_ulist.p,
                            (const uint32_t*)e->d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)e->d_part_base.p, O, target,
-                           e->sx_cap, e->sx_pb, K, (const uint32_t*)nullptr, tpg, (u64)0, cap_words);
+                           e->sx_cap, e->sx_pb, K, (const uint32_t*)nullptr, tpg, (u64)0, (const u64*)e->d_sxstat.p, cap_words);
                 e->st.launches += 1;
             }
             e->st.launches += 2;
@@ -563,7 +563,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         FSK_LAUNCH(k_emit, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
                    (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)nullptr,
                    (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
-                   slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr, 0xffffffffu);
+                   slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr, (const u64*)nullptr, ~(u64)0);
         e->st.launches += 1;
     }
     e->toc(&e->st.ms_pairs);

@@ -293,10 +293,14 @@ def test_emu_relabelled_and_wide_alphabets(emu_lib, port):
     for x in X[:4]:
         x[3:15] = X[5][3:15]  # shared 12-mers so that off-diagonals are non-trivial
     tok, off = _native.flatten(X)
+    combos = np.arange(0, port.num_combos(12, 3), 5, dtype=np.int32)  # (a subset: the emulator pays per workgroup)
     e = _native.Engine(12, 3, lib=emu_lib)
-    e.compute(tok, off, 6, 3)
-    want, _, _ = port.compute(tok, off, 6, 3, 12, 3, t=1)
-    assert np.array_equal(e.get_triangle(), want)
+    e.load_sequences(tok, off, 6, 3)
+    e.accumulate(combos)
+    e.finalize()
+    want, _, _ = port.raw_counts(tok, off, 12, 3, combos)
+    assert np.array_equal(e.get_counts(), want) and want[1] > 0
+    assert np.array_equal(e.get_triangle(), port.normalise(want.astype(np.float64), 9))
     assert e.stats()["path_used"] == 2
     e.close()
     # k = 14 over 20 symbols: 61 k-mer bits + 5 sequence bits = 66 -> 128-bit sort records
@@ -305,10 +309,14 @@ def test_emu_relabelled_and_wide_alphabets(emu_lib, port):
         x[1:17] = X[12][1:17]
     X[3][5] = X[3][5] % 20 + 1  # a near copy: shares some gapped 14-mers only
     tok, off = _native.flatten(X)
+    combos = np.arange(0, port.num_combos(16, 2), 4, dtype=np.int32)
     e = _native.Engine(16, 2, lib=emu_lib)
-    e.compute(tok, off, 14, 6)
-    want, _, _ = port.compute(tok, off, 14, 6, 16, 2, t=1)
-    assert np.array_equal(e.get_triangle(), want)
+    e.load_sequences(tok, off, 14, 6)
+    e.accumulate(combos)
+    e.finalize()
+    want, _, _ = port.raw_counts(tok, off, 16, 2, combos)
+    assert np.array_equal(e.get_counts(), want)
+    assert np.array_equal(e.get_triangle(), port.normalise(want.astype(np.float64), 20))
     assert e.stats()["path_used"] == 2 and e.stats()["key_space"] == 20 ** 14
     e.close()
 

@@ -819,6 +819,33 @@ def test_skip_test_block_sparse(native, port, monkeypatch, global_pairs):
         e.close()
 
 
+def test_sparse_guarded_batch_beyond_32_bit_word_total(native):
+    """A sparse batch enqueued ahead of its size whose update words pass 2^32 (long runs: 729 keys, 3000
+    ragged sequences): the 32-bit stream offsets wrap, so the kernels must judge the batch by the 64-bit
+    total — it does not fit its guard, is left alone and redone with atomics. Checked against the dense
+    dataflow (this shape found the 32-bit comparison as a GPU memory fault in tools/stress_parity.py)."""
+    rng = np.random.default_rng(1)
+    g, m, N = 11, 5, 3000
+    X = [rng.integers(1, 4, size=int(L)).astype(np.int32) for L in rng.integers(g, 701, size=N)]
+    tokens, offsets = native.flatten(X)
+    combos = np.array([81, 203, 210, 230, 290, 311, 318, 321, 339, 348, 358], dtype=np.int32)
+    d = native.Engine(g, m, path=1)
+    d.load_sequences(tokens, offsets, N, 0)
+    d.accumulate(combos)
+    d.finalize()
+    want = d.get_counts()
+    d.close()
+    e = native.Engine(g, m, path=2)
+    e.load_sequences(tokens, offsets, N, 0)
+    e.accumulate_rows(combos, 0, 768)     # sized exactly: ~0.3 G words, the guard of the next batch is 1.5x that
+    e.accumulate_rows(combos, 768, N)     # ~4.3 G words
+    e.finalize()
+    st = e.stats()
+    assert st["cell_updates"] > 2 ** 32 + 2 ** 28 and st["batches_redone"] == 1
+    assert np.array_equal(e.get_counts(), want)
+    e.close()
+
+
 @pytest.mark.parametrize("forced", ["0", "1"])
 def test_sparse_segment_scan_in_chunks(native, port, monkeypatch, forced):
     """A sparse batch of more than 4096 entry tiles scans its tile records in three launches (chunk

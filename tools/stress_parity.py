@@ -31,6 +31,8 @@ def main(iters=150, seed=0):
         nc = _native.library().num_combos(g, m)
         combos = np.unique(rng.integers(0, nc, size=int(rng.integers(1, 24)))).astype(np.int32)
         ntr = int(rng.integers(1, N + 1))
+        if os.environ.get("FSK_STRESS_VERBOSE"):  # (a crash loses the buffered line: say what is about to run)
+            print("iter %d: sigma=%d g=%d m=%d N=%d Lmax=%d ntr=%d combos=%s" % (it, sigma, g, m, N, hi, ntr, combos.tolist()), flush=True)
         res = {}
         for name, path, env in (("dense", 1, "0"), ("dense_compact", 1, "1"), ("sparse", 2, "0"), ("sparse_global", 2, "1")):
             if path == 1 and (sigma ** k > 16384 or k > 16):
@@ -42,6 +44,8 @@ def main(iters=150, seed=0):
             os.environ.pop("FSK_SPARSE_GUARD_CAP", None)
             if name == "sparse" and rng.random() < 0.3:
                 os.environ["FSK_SPARSE_GUARD_CAP"] = str(int(rng.choice([1, 64, 5000])))
+            if os.environ.get("FSK_STRESS_VERBOSE"):
+                print("   %s guard=%s" % (name, os.environ.get("FSK_SPARSE_GUARD_CAP")), flush=True)
             e = _native.Engine(g, m, path=path)
             e.load_sequences(tokens, offsets, ntr, N - ntr)
             if rng.random() < 0.5 or N < 256:
