@@ -16,6 +16,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <array>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -90,6 +92,9 @@ struct fsk_engine {
     // them (dense dataflow, one workgroup per tile): rows [lazy_lo, lazy_hi) are zero by contract
     // but not in memory until a tile launch stores them or materialise_zero() fills them.
     int64_t lazy_lo = -1, lazy_hi = -1;
+    uint32_t* h_stage = nullptr;         // pinned: the packed sequences on their way to the device (fsk_load_sequences)
+    size_t h_stage_cap = 0;
+    bool stage_in_flight = false;
     double* h_prod = nullptr;            // pinned: one sequential sum per iteration in flight (kept across calls)
     size_t h_prod_cap = 0;
 
@@ -242,6 +247,28 @@ void parallel_ranges(int64_t n, int nt, F&& fn) {
     if (nt <= 1) { fn(0, (int64_t)0, n); return; }
     std::vector<std::thread> th;
     for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { fn(t, n * t / nt, n * (t + 1) / nt); });
+    for (auto& x : th) x.join();
+}
+
+// two phases over the same thread team with `between` run by one thread in the middle (one thread start
+// per call instead of two; a spinning barrier: the team is a handful of threads for a fraction of a millisecond)
+template <typename F1, typename FM, typename F2>
+void parallel_two_phase(int nt, F1&& phase1, FM&& between, F2&& phase2) {
+    if (nt <= 1) { phase1(0); between(); phase2(0); return; }
+    std::atomic<int> arrived{0}, go{0};
+    auto body = [&](int t) {
+        phase1(t);
+        if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == nt) {
+            between();
+            go.store(1, std::memory_order_release);
+        } else {
+            while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+        }
+        phase2(t);
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(body, t);
+    body(0);
     for (auto& x : th) x.join();
 }
 
@@ -1371,6 +1398,7 @@ void fsk_destroy(fsk_engine* e) {
     if (e->h_prod) (void)hipHostFree(e->h_prod);
     if (e->h_sx_pos) (void)hipHostFree(e->h_sx_pos);
     if (e->h_sx_stat) (void)hipHostFree(e->h_sx_stat);
+    if (e->h_stage) (void)hipHostFree(e->h_stage);
     if (e->ev_order) (void)hipEventDestroy(e->ev_order);
     if (e->chain_stream) { (void)hipStreamSynchronize(e->chain_stream); (void)hipStreamDestroy(e->chain_stream); }
     (void)hipEventDestroy(e->ev0);
@@ -1407,6 +1435,10 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
     if (N >= ((int64_t)1 << 31)) return e->fail(FSK_EUNSUPPORTED, "more than 2^31 sequences");
     if (offsets[0] < 0) return e->fail(FSK_EINVAL, "offsets[0] must be >= 0");
     if (offsets[N] > offsets[0] && !tokens) return e->fail(FSK_EINVAL, "null tokens");
+    if (e->stage_in_flight) {  // the previous call's upload reads the pinned staging this call is about to refill
+        FSK_HIP(hipStreamSynchronize(e->stream));
+        e->stage_in_flight = false;
+    }
     // only tokens[offsets[0] .. offsets[N]) belong to the call: everything below works on that window
     tokens = tokens ? tokens + offsets[0] : tokens;
     const int64_t off0 = offsets[0];
@@ -1426,74 +1458,154 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
         return e->fail(FSK_ESHORT, "g cannot be longer than the shortest sequence in a dataset. g = %d, but shortest test sequence has length %lld", g, (long long)shortest_test);
     if (nfeat >= ((int64_t)1 << 31) || longest >= ((int64_t)1 << 24)) return e->fail(FSK_EUNSUPPORTED, "input too large (g-mers >= 2^31 or a sequence >= 2^24)");
     // ---- alphabet: rank-remap the tokens that occur (equality preserving; the reference's
-    // dict_size = |{0} U tokens|, fastsk.cpp:70-85, only serves as its counting-sort radix)
+    // dict_size = |{0} U tokens|, fastsk.cpp:70-85, only serves as its counting-sort radix), then pack,
+    // every sequence word-aligned.
     const int64_t total = offsets[N] - off0;
     std::vector<int32_t> distinct;
-    std::vector<int64_t> tok_hist;  // occurrences per token value when every token lies in [0, 65536): one pass
+    std::vector<int64_t> sym_freq(256, 0);
+    uint32_t sigma = 1;
+    int bits = 2;
+    u64 V = 1;
+    std::vector<uint32_t> len32((size_t)N), fstart((size_t)N + 1);
+    std::vector<uint32_t> wstart_v, words_v;           // general path only
+    const uint32_t *p_words = nullptr, *p_wstart = nullptr;
+    size_t n_words_alloc = 0;
+    bool staged = false;                               // packed into the engine's pinned staging: asynchronous upload
     {
-        tok_hist.assign(65536, 0);
-        bool small = true;
-        {   // (a few host threads: at 100k x 300 tokens this scan and the packing below are the load time)
-            const int nt = host_threads_for(total);
-            std::vector<std::vector<int64_t>> part((size_t)nt);
-            std::vector<char> ok((size_t)nt, 1);
-            parallel_ranges(total, nt, [&](int t, int64_t lo, int64_t hi) {
-                std::vector<int64_t>& h = part[(size_t)t];
-                h.assign(65536, 0);
+        uint32_t fcount = 0;
+        for (int64_t i = 0; i < N; ++i) {
+            const int64_t len = offsets[i + 1] - offsets[i];
+            len32[i] = (uint32_t)len;
+            fstart[i] = fcount;
+            fcount += (uint32_t)(len - g + 1);
+        }
+        fstart[N] = fcount;
+    }
+    // sigma, bits, V from `distinct`; where every sequence's words start
+    auto plan_words = [&](uint32_t* wstart, uint64_t* nwords_out) -> int {
+        if (distinct.size() > 256) return e->fail(FSK_EUNSUPPORTED, "alphabet of %zu symbols (> 256)", distinct.size());
+        sigma = (uint32_t)std::max<size_t>(1, distinct.size());
+        bits = sigma <= 4 ? 2 : sigma <= 16 ? 4 : 8;
+        V = 1;
+        for (int c = 0; c < e->k; ++c) {
+            if (V > (((u64)1 << 62) / sigma)) return e->fail(FSK_EUNSUPPORTED, "alphabet^(g-m) does not fit in 62 bits");
+            V *= sigma;
+        }
+        uint64_t nwords = 0;
+        for (int64_t i = 0; i < N; ++i) {
+            wstart[i] = (uint32_t)nwords;
+            nwords += ((uint64_t)len32[i] * bits + 31) / 32;
+            if (nwords >= ((uint64_t)1 << 32)) return e->fail(FSK_EUNSUPPORTED, "packed sequences exceed 2^32 words");
+        }
+        *nwords_out = nwords;
+        return FSK_OK;
+    };
+    {
+        // Fast path — token ids below 256, every vocabulary in practice: ONE team of host threads counts the
+        // tokens of its share of the sequences (256 counters each), one of them turns the counts into the
+        // rank table and lays out the words in the engine's pinned staging, the team packs its sequences
+        // there; the upload is asynchronous. (At 100k x 300 tokens this is the load time.)
+        const int nt = host_threads_for(total);
+        std::vector<int64_t> bound((size_t)nt + 1, N);  // sequence ranges with about equal token counts
+        bound[0] = 0;
+        for (int t = 1; t < nt; ++t)
+            bound[(size_t)t] = std::lower_bound(offsets, offsets + N, off0 + total * t / nt) - offsets;
+        std::vector<std::array<int64_t, 256>> hist((size_t)nt);
+        std::vector<char> small((size_t)nt, 1);
+        uint8_t lut[256] = {0};
+        int rc_mid = FSK_OK;
+        bool all_small = true;
+        uint32_t* st_words = nullptr;
+        uint32_t* st_wstart = nullptr;
+        parallel_two_phase(
+            nt,
+            [&](int t) {
+                std::array<int64_t, 256>& h = hist[(size_t)t];
+                h.fill(0);
+                const int64_t lo = offsets[bound[(size_t)t]] - off0, hi = offsets[bound[(size_t)t + 1]] - off0;
                 for (int64_t i = lo; i < hi; ++i) {
                     const uint32_t v = (uint32_t)tokens[i];
-                    if (v < 65536u) h[v]++;
-                    else { ok[(size_t)t] = 0; break; }
+                    if (v < 256u) h[v]++;
+                    else { small[(size_t)t] = 0; break; }
+                }
+            },
+            [&] {
+                for (int t = 0; t < nt; ++t) all_small = all_small && small[(size_t)t];
+                if (!all_small) return;
+                for (int v = 0; v < 256; ++v) {
+                    int64_t c = 0;
+                    for (int t = 0; t < nt; ++t) c += hist[(size_t)t][(size_t)v];
+                    if (c) { lut[v] = (uint8_t)distinct.size(); sym_freq[distinct.size()] = c; distinct.push_back(v); }
+                }
+                // staging: [words + 4][wstart N][len N][fstart N + 1]
+                std::vector<uint32_t> ws((size_t)N);
+                uint64_t nwords = 0;
+                rc_mid = plan_words(ws.data(), &nwords);
+                if (rc_mid) return;
+                const size_t need = (size_t)nwords + 4 + 3 * (size_t)N + 1;
+                if (need > e->h_stage_cap) {
+                    if (e->h_stage) (void)hipHostFree(e->h_stage);
+                    e->h_stage = nullptr; e->h_stage_cap = 0;
+                    if (hipHostMalloc((void**)&e->h_stage, (need + need / 4) * sizeof(uint32_t)) != hipSuccess) {
+                        rc_mid = e->fail(FSK_ENOMEM, "cannot allocate %zu bytes of pinned staging", need * sizeof(uint32_t));
+                        return;
+                    }
+                    e->h_stage_cap = need + need / 4;
+                }
+                st_words = e->h_stage;
+                st_wstart = e->h_stage + (size_t)nwords + 4;
+                memcpy(st_wstart, ws.data(), (size_t)N * sizeof(uint32_t));
+                memcpy(st_wstart + N, len32.data(), (size_t)N * sizeof(uint32_t));
+                memcpy(st_wstart + 2 * N, fstart.data(), ((size_t)N + 1) * sizeof(uint32_t));
+                memset(st_words + nwords, 0, 4 * sizeof(uint32_t));
+                n_words_alloc = (size_t)nwords + 4;
+            },
+            [&](int t) {
+                if (!all_small || rc_mid) return;
+                const uint32_t per_word = 32u / (uint32_t)bits;
+                for (int64_t i = bound[(size_t)t]; i < bound[(size_t)t + 1]; ++i) {  // a sequence's words are its own
+                    const int32_t* sq = tokens + (offsets[i] - off0);
+                    uint32_t* w = st_words + st_wstart[i];
+                    const uint32_t len = len32[i];
+                    uint32_t p = 0;
+                    for (; p + per_word <= len; p += per_word) {
+                        uint32_t word = 0;
+                        for (uint32_t q = 0; q < per_word; ++q) word |= (uint32_t)lut[sq[p + q]] << (q * (uint32_t)bits);
+                        *w++ = word;
+                    }
+                    if (p < len) {
+                        uint32_t word = 0;
+                        for (uint32_t q = 0; p + q < len; ++q) word |= (uint32_t)lut[sq[p + q]] << (q * (uint32_t)bits);
+                        *w = word;
+                    }
                 }
             });
-            for (int t = 0; t < nt; ++t) {
-                if (!ok[(size_t)t]) small = false;
-                for (int v = 0; v < 65536; ++v) tok_hist[(size_t)v] += part[(size_t)t][(size_t)v];
-            }
+        if (rc_mid) return rc_mid;
+        if (all_small) {
+            staged = true;
+            p_words = st_words;
+            p_wstart = st_wstart;
         }
-        if (small) {
-            for (int32_t v = 0; v < 65536; ++v)
-                if (tok_hist[v]) distinct.push_back(v);
+    }
+    if (!staged) {
+        // General path (token values anywhere in int32): distinct values by sort or by a seen-table, ranks by
+        // table or binary search, one thread.
+        int32_t lo = INT32_MAX, hi = INT32_MIN;
+        for (int64_t i = 0; i < total; ++i) { lo = std::min(lo, tokens[i]); hi = std::max(hi, tokens[i]); }
+        if (total > 0 && lo >= 0 && hi < (1 << 20)) {
+            std::vector<char> seen((size_t)hi + 1, 0);
+            for (int64_t i = 0; i < total; ++i) seen[tokens[i]] = 1;
+            for (int32_t v = 0; v <= hi; ++v) if (seen[v]) distinct.push_back(v);
         } else {
-            tok_hist.clear();
-            int32_t lo = INT32_MAX, hi = INT32_MIN;
-            for (int64_t i = 0; i < total; ++i) { lo = std::min(lo, tokens[i]); hi = std::max(hi, tokens[i]); }
-            if (total > 0 && lo >= 0 && hi < (1 << 20)) {
-                std::vector<char> seen((size_t)hi + 1, 0);
-                for (int64_t i = 0; i < total; ++i) seen[tokens[i]] = 1;
-                for (int32_t v = 0; v <= hi; ++v) if (seen[v]) distinct.push_back(v);
-            } else {
-                distinct.assign(tokens, tokens + total);
-                std::sort(distinct.begin(), distinct.end());
-                distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
-            }
+            distinct.assign(tokens, tokens + total);
+            std::sort(distinct.begin(), distinct.end());
+            distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
         }
-    }
-    if (distinct.size() > 256) return e->fail(FSK_EUNSUPPORTED, "alphabet of %zu symbols (> 256)", distinct.size());
-    const uint32_t sigma = (uint32_t)std::max<size_t>(1, distinct.size());
-    const int bits = sigma <= 4 ? 2 : sigma <= 16 ? 4 : 8;
-    u64 V = 1;
-    for (int c = 0; c < e->k; ++c) {
-        if (V > (((u64)1 << 62) / sigma)) return e->fail(FSK_EUNSUPPORTED, "alphabet^(g-m) does not fit in 62 bits");
-        V *= sigma;
-    }
-    // ---- pack, every sequence word-aligned
-    std::vector<uint32_t> wstart((size_t)N), len32((size_t)N), fstart((size_t)N + 1);
-    uint64_t nwords = 0;
-    uint32_t fcount = 0;
-    for (int64_t i = 0; i < N; ++i) {
-        const int64_t len = offsets[i + 1] - offsets[i];
-        wstart[i] = (uint32_t)nwords;
-        len32[i] = (uint32_t)len;
-        fstart[i] = fcount;
-        fcount += (uint32_t)(len - g + 1);
-        nwords += ((uint64_t)len * bits + 31) / 32;
-        if (nwords >= ((uint64_t)1 << 32)) return e->fail(FSK_EUNSUPPORTED, "packed sequences exceed 2^32 words");
-    }
-    fstart[N] = fcount;
-    std::vector<uint32_t> words((size_t)nwords + 4, 0u);
-    std::vector<int64_t> sym_freq(256, 0);
-    {
+        wstart_v.resize((size_t)N);
+        uint64_t nwords = 0;
+        int rc_plan = plan_words(wstart_v.data(), &nwords);
+        if (rc_plan) return rc_plan;
+        words_v.assign((size_t)nwords + 4, 0u);
         const int32_t base = distinct.empty() ? 0 : distinct.front();
         const bool direct = !distinct.empty() && (int64_t)distinct.back() - base < (1 << 20);
         std::vector<uint8_t> lut;
@@ -1501,42 +1613,20 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
             lut.assign((size_t)(distinct.back() - base) + 1, 0);
             for (size_t r = 0; r < distinct.size(); ++r) lut[(size_t)(distinct[r] - base)] = (uint8_t)r;
         }
-        if (direct && !tok_hist.empty()) {
-            // frequencies are known from the histogram: the packing loop builds whole words
-            for (size_t r = 0; r < distinct.size(); ++r) sym_freq[r] = tok_hist[(size_t)distinct[r]];
-            const uint32_t per_word = 32u / (uint32_t)bits;
-            const uint8_t* lt = lut.data();
-            parallel_ranges(N, host_threads_for(total), [&](int, int64_t s_lo, int64_t s_hi) {  // a sequence's words are its own
-                for (int64_t i = s_lo; i < s_hi; ++i) {
-                    const int32_t* sq = tokens + (offsets[i] - off0);
-                    uint32_t* w = words.data() + wstart[i];
-                    const uint32_t len = len32[i];
-                    uint32_t p = 0;
-                    for (; p + per_word <= len; p += per_word) {
-                        uint32_t word = 0;
-                        for (uint32_t q = 0; q < per_word; ++q) word |= (uint32_t)lt[sq[p + q] - base] << (q * (uint32_t)bits);
-                        *w++ = word;
-                    }
-                    if (p < len) {
-                        uint32_t word = 0;
-                        for (uint32_t q = 0; p + q < len; ++q) word |= (uint32_t)lt[sq[p + q] - base] << (q * (uint32_t)bits);
-                        *w = word;
-                    }
-                }
-            });
-        } else {
-            for (int64_t i = 0; i < N; ++i) {
-                const int32_t* sq = tokens + (offsets[i] - off0);
-                uint32_t* w = words.data() + wstart[i];
-                for (uint32_t p = 0; p < len32[i]; ++p) {
-                    uint32_t r = direct ? lut[(size_t)(sq[p] - base)]
-                                        : (uint32_t)(std::lower_bound(distinct.begin(), distinct.end(), sq[p]) - distinct.begin());
-                    const uint32_t bitpos = p * (uint32_t)bits;
-                    w[bitpos >> 5] |= r << (bitpos & 31u);
-                    sym_freq[r]++;
-                }
+        for (int64_t i = 0; i < N; ++i) {
+            const int32_t* sq = tokens + (offsets[i] - off0);
+            uint32_t* w = words_v.data() + wstart_v[i];
+            for (uint32_t p = 0; p < len32[i]; ++p) {
+                uint32_t r = direct ? lut[(size_t)(sq[p] - base)]
+                                    : (uint32_t)(std::lower_bound(distinct.begin(), distinct.end(), sq[p]) - distinct.begin());
+                const uint32_t bitpos = p * (uint32_t)bits;
+                w[bitpos >> 5] |= r << (bitpos & 31u);
+                sym_freq[r]++;
             }
         }
+        p_words = words_v.data();
+        p_wstart = wstart_v.data();
+        n_words_alloc = words_v.size();
     }
     // ---- commit
     e->N = N; e->n_train = n_train; e->n_test = n_test; e->nfeat = nfeat;
@@ -1547,7 +1637,7 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
     e->n_panels = (uint32_t)((N + fsk::PANEL - 1) / fsk::PANEL);
     e->h_len = len32; e->h_fstart = fstart; e->featseq_ready = false;
     e->prep_valid = false; e->tab_n = 0; e->vc_sum = 0; e->vc_n = 0;
-    e->lazy_lo = e->lazy_hi = -1;  // (the triangle is filled with zeros below)
+    e->lazy_lo = e->lazy_hi = -1;  // (the triangle is zeroed, or promised to be, below)
     e->u_known = false; e->u_pending = false; e->u_extra = 0; e->u_value = 0;
     e->sx_words_seen = 0;
     for (auto& d : e->sx_defer) d.active = false;
@@ -1568,14 +1658,22 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
         e->compact = sigma >= 3 && V >= 64 && V <= 4096 && rarest * 50 < total;
         if (e->force_compact >= 0) e->compact = e->force_compact != 0 && V <= 4096;
     }
-    FSK_HIP(e->d_words.reserve(words.size()));
+    FSK_HIP(e->d_words.reserve(n_words_alloc));
     FSK_HIP(e->d_wstart.reserve((size_t)N));
     FSK_HIP(e->d_len.reserve((size_t)N));
     FSK_HIP(e->d_fstart.reserve((size_t)N + 1));
-    FSK_HIP(hipMemcpy(e->d_words.p, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    FSK_HIP(hipMemcpy(e->d_wstart.p, wstart.data(), (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice));
-    FSK_HIP(hipMemcpy(e->d_len.p, len32.data(), (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice));
-    FSK_HIP(hipMemcpy(e->d_fstart.p, fstart.data(), ((size_t)N + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (staged) {  // everything sits in pinned memory: four copies on the stream, nothing to wait for
+        FSK_HIP(hipMemcpyAsync(e->d_words.p, p_words, n_words_alloc * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        FSK_HIP(hipMemcpyAsync(e->d_wstart.p, p_wstart, (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        FSK_HIP(hipMemcpyAsync(e->d_len.p, p_wstart + N, (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        FSK_HIP(hipMemcpyAsync(e->d_fstart.p, p_wstart + 2 * N, ((size_t)N + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        e->stage_in_flight = true;
+    } else {
+        FSK_HIP(hipMemcpy(e->d_words.p, p_words, n_words_alloc * sizeof(uint32_t), hipMemcpyHostToDevice));
+        FSK_HIP(hipMemcpy(e->d_wstart.p, p_wstart, (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice));
+        FSK_HIP(hipMemcpy(e->d_len.p, e->h_len.data(), (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice));
+        FSK_HIP(hipMemcpy(e->d_fstart.p, e->h_fstart.data(), ((size_t)N + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     if (e->d_K && !e->K_owned) {
         if (e->bound_cells != e->pairs) return e->fail(FSK_EINVAL, "bound counts buffer holds %lld cells, need %lld", (long long)e->bound_cells, (long long)e->pairs);
     } else {
@@ -1584,7 +1682,11 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
         e->d_K = e->K_store.p;
         e->K_owned = true;
     }
-    FSK_HIP(hipMemsetAsync(e->d_K, 0, (size_t)e->pairs * sizeof(u64), e->stream));
+    if (lazy_zero_possible(e)) {  // (as after fsk_reset_counts: the first tile launch stores its sums)
+        e->lazy_lo = 0; e->lazy_hi = N;
+    } else {
+        FSK_HIP(hipMemsetAsync(e->d_K, 0, (size_t)e->pairs * sizeof(u64), e->stream));
+    }
     FSK_HIP(e->d_U.reserve(1));
     FSK_HIP(hipMemsetAsync(e->d_U.p, 0, sizeof(u64), e->stream));
     e->loaded = true; e->finalized = false; e->result_f64 = false;
