@@ -54,7 +54,8 @@ SYMBOLS = ["fsk_create", "fsk_destroy", "fsk_last_error", "fsk_abi_version", "fs
            "fsk_counts_device_ptr", "fsk_reset_counts", "fsk_reset_counts_rows", "fsk_accumulate", "fsk_accumulate_rows", "fsk_synchronize", "fsk_finalize",
            "fsk_get_block", "fsk_get_block_device", "fsk_get_train", "fsk_get_test", "fsk_get_triangle", "fsk_get_counts",
            "fsk_get_counts_block", "fsk_get_counts_cells", "fsk_get_stdevs", "fsk_save_kernel", "fsk_get_stats", "fsk_num_combos",
-           "fsk_combo_positions", "fsk_stream_wait_engine", "fsk_engine_wait_stream", "fsk_read_fasta", "fsk_sequential_sum"]
+           "fsk_combo_positions", "fsk_stream_wait_engine", "fsk_engine_wait_stream", "fsk_read_fasta", "fsk_sequential_sum",
+           "fsk_run_chains", "fsk_get_kernel_sum_device", "fsk_set_kernel_sum_device"]
 
 
 _hip_shared = False
@@ -162,6 +163,9 @@ class Library:
             "fsk_engine_wait_stream": ([vp, vp], C.c_int),
             "fsk_read_fasta": ([C.c_char_p, vp, C.POINTER(i32), vp, i64, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.c_char_p, i32], C.c_int),
             "fsk_sequential_sum": ([vp, vp, i64, C.POINTER(C.c_double)], C.c_int),
+            "fsk_run_chains": ([vp, i32, i32], C.c_int),
+            "fsk_get_kernel_sum_device": ([vp, vp], C.c_int),
+            "fsk_set_kernel_sum_device": ([vp, vp], C.c_int),
             "fsk_get_stdevs": ([vp, vp, i32, C.POINTER(i32)], C.c_int),
             "fsk_save_kernel": ([vp, C.c_char_p], C.c_int),
             "fsk_get_stats": ([vp, C.POINTER(Stats)], C.c_int),
@@ -368,6 +372,18 @@ class Engine:
         out = C.c_double(0.0)
         self._ck(self.lib.L.fsk_sequential_sum(self.h, values.ctypes.data, len(values), C.byref(out)))
         return out.value
+
+    # ---- variance mode over several engines: the Welford chains are the units
+    def run_chains(self, first, step):
+        """Chains ``first, first + step, ...`` of the ``t`` Welford chains (after ``load_sequences``)."""
+        self._ck(self.lib.L.fsk_run_chains(self.h, first, step))
+
+    def get_kernel_sum_device(self, device_ptr):
+        """The fp64 sum of the chains' K_hat into ``pairs`` doubles at ``device_ptr`` (device memory)."""
+        self._ck(self.lib.L.fsk_get_kernel_sum_device(self.h, C.c_void_p(device_ptr)))
+
+    def set_kernel_sum_device(self, device_ptr):
+        self._ck(self.lib.L.fsk_set_kernel_sum_device(self.h, C.c_void_p(device_ptr)))
 
     def get_stdevs(self):
         n = C.c_int32(0)

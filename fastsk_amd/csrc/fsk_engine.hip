@@ -1085,7 +1085,8 @@ int enqueue_sequential_sum(fsk_engine* e, const double* d_vals, u64 n, double* b
 }
 
 // variance mode: T sequential Welford chains (fastsk_kernel.cpp:188-262, 286-315)
-int run_variance_mode(fsk_engine* e, int T) {
+// chains tid = chain_first, chain_first + chain_step, ... < T (all of them: 0, 1); stdevs are chain 0's
+int run_variance_mode(fsk_engine* e, int T, int chain_first = 0, int chain_step = 1) {
     { int rcz = materialise_zero(e); if (rcz) return rcz; }
     const int64_t pairs = e->pairs;
     const int64_t train_pairs = (int64_t)((e->n_train / (double)2) * (e->n_train + 1));
@@ -1200,7 +1201,7 @@ int run_variance_mode(fsk_engine* e, int T) {
         return FSK_OK;
     };
     e->stdevs.clear();
-    for (int tid = 0; tid < T; ++tid) {
+    for (int tid = chain_first; tid < T; tid += chain_step) {
         int cur = 0;  // ring position of the state after the last accepted iteration
         FSK_HIP(hipMemsetAsync(khat(cur), 0, (size_t)pairs * sizeof(double), e->stream));
         int iter = 1, item = tid;
@@ -1851,6 +1852,41 @@ int fsk_compute(fsk_engine* e, const int32_t* tokens, const int64_t* offsets, in
     rc = run_variance_mode(e, T);
     if (rc) return rc;
     return make_diag(e);
+}
+
+int fsk_run_chains(fsk_engine* e, int32_t first, int32_t step) {
+    if (!e) return FSK_EINVAL;
+    if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
+    const fsk_config& c = e->cfg;
+    if (!c.approx || c.skip_variance) return e->fail(FSK_ESTATE, "fsk_run_chains is the variance mode (approx=1, skip_variance=0)");
+    if (first < 0 || step < 1) return e->fail(FSK_EINVAL, "need first >= 0 and step >= 1");
+    FSK_ON_DEVICE(e);
+    if (!e->order_set) default_order(e);
+    int T = c.t == -1 ? 20 : c.t;  // fastsk_kernel.cpp:54-61
+    T = std::max(1, std::min<int>(T, (int)e->order.size()));
+    e->finalized = false;
+    return run_variance_mode(e, T, first, step);
+}
+
+int fsk_get_kernel_sum_device(fsk_engine* e, double* device_out) {
+    if (!e) return FSK_EINVAL;
+    if (!e->loaded || !e->result_f64) return e->fail(FSK_ESTATE, "no Welford chains have run");
+    if (!device_out) return e->fail(FSK_EINVAL, "null output");
+    FSK_ON_DEVICE(e);
+    FSK_HIP(hipMemcpyAsync(device_out, e->d_Kf64.p, (size_t)e->pairs * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    FSK_HIP(hipStreamSynchronize(e->stream));
+    return FSK_OK;
+}
+
+int fsk_set_kernel_sum_device(fsk_engine* e, const double* device_in) {
+    if (!e) return FSK_EINVAL;
+    if (!e->loaded || !e->result_f64) return e->fail(FSK_ESTATE, "no Welford chains have run");
+    if (!device_in) return e->fail(FSK_EINVAL, "null input");
+    FSK_ON_DEVICE(e);
+    FSK_HIP(hipMemcpyAsync(e->d_Kf64.p, device_in, (size_t)e->pairs * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    FSK_HIP(hipStreamSynchronize(e->stream));
+    e->finalized = false;
+    return FSK_OK;
 }
 
 int fsk_get_block(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1, double* out) {

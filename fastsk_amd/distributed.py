@@ -300,3 +300,49 @@ def compute_sharded(tokens, offsets, n_train, n_test, g, m, combos=None, group=N
                               n_combos_total=len(combos))
     eng.finalize()
     return eng, K
+
+
+def compute_variance_sharded(tokens, offsets, n_train, n_test, g, m, t, delta=0.025, max_iters=-1, order=None, seed=None,
+                             group=None, device=None, lib=None, path=_native.PATH_AUTO):
+    """Variance (convergence) mode over the ranks of ``group``: the ``t`` Welford chains of the
+    reference's worker threads (``fastsk_kernel.cpp:188-281``) are the units — chain c runs on rank
+    ``c mod R`` — and their K_hat are summed in fp64 with ONE all-reduce (``fastsk_kernel.cpp:286-315``
+    adds them under locks, in whatever order the threads arrive; here the order is the collective's).
+    Every rank needs the same combo order: pass ``order`` or ``seed``.
+
+    Returns ``(engine, stdevs)``: the finalized engine of this rank (every rank holds the whole
+    kernel) and chain 0's convergence trace, broadcast from the rank that ran it. With ``t <= R`` some
+    ranks have no chain and only take part in the sum."""
+    import torch
+    import torch.distributed as dist
+
+    distributed_run = dist.is_initialized()
+    world = dist.get_world_size(group) if distributed_run else 1
+    rank = dist.get_rank(group) if distributed_run else 0
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    eng = _native.Engine(g, m, t=t, approx=True, delta=delta, max_iters=max_iters,
+                         device=(device.index or 0) if device.type == "cuda" else 0, path=path, lib=lib)
+    if order is not None:
+        eng.set_combo_order(order)
+    elif seed is not None:
+        eng.set_seed(seed)
+    elif world > 1:
+        raise ValueError("every rank needs the same combo order: pass order= or seed=")
+    eng.load_sequences(tokens, offsets, n_train, n_test)
+    eng.run_chains(rank, world)
+    if world > 1:
+        N = n_train + n_test
+        total = torch.empty(N * (N + 1) // 2, dtype=torch.float64, device=device)
+        eng.get_kernel_sum_device(total.data_ptr())
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        eng.set_kernel_sum_device(total.data_ptr())
+    eng.finalize()
+    sd = [eng.get_stdevs() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(sd, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return eng, np.asarray(sd[0], dtype=np.float64)
+

@@ -186,6 +186,16 @@ int fsk_get_counts_cells(fsk_engine* e, const int64_t* rows, const int64_t* cols
  * approx mode depends on it). `values` is a host array. Exposed so that the summation can be verified
  * on its own. */
 int fsk_sequential_sum(fsk_engine* e, const double* values, int64_t n, double* out);
+/* Variance mode over several GPUs (the T Welford chains are the units): after
+ * fsk_load_sequences, run the chains first, first + step, ... < T of this engine — one worker thread's
+ * share of fastsk_kernel.cpp:188-281 — leaving the sum of their K_hat (fastsk_kernel.cpp:286-315) in the
+ * engine's fp64 triangle; chain 0's engine holds get_stdevs(). The caller sums the triangles of all
+ * engines (fsk_get_kernel_sum_device -> e.g. an RCCL all-reduce -> fsk_set_kernel_sum_device; device
+ * buffers of N(N+1)/2 doubles) and calls fsk_finalize. With T > 1 the fp64 sum over chains depends on
+ * its order, as it does between the reference's threads. */
+int fsk_run_chains(fsk_engine* e, int32_t first, int32_t step);
+int fsk_get_kernel_sum_device(fsk_engine* e, double* device_out);
+int fsk_set_kernel_sum_device(fsk_engine* e, const double* device_in);
 /* approx/variance mode: thread 0's convergence trace, get_stdevs() (fastsk.cpp:219-221) */
 int fsk_get_stdevs(fsk_engine* e, double* out, int32_t cap, int32_t* n);
 /* "%d:%e " text dump, one row per line, 1-based column ids: save_kernel (fastsk.cpp:223-237) */

@@ -135,3 +135,44 @@ def test_four_ranks(tmp_path, port, shard_by):
         assert np.array_equal(z["full"][il], tri)
         if shard_by == "combos":
             assert np.array_equal(z["counts"], want)
+
+
+def run_variance_world(tmp_path, fixture, port_no, world, device="cpu"):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_no), WORLD_SIZE=str(world))
+    procs = []
+    for rank in range(world):
+        e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_variance_worker.py"), fixture,
+                                       str(tmp_path), device], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    return [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+
+
+def variance_case(tmp_path, port, T):
+    """Small ragged DNA set, variance mode with T chains, and the oracle's result (chains summed in order)."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(17)
+    X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(12, 40, size=30)]
+    tok, off = _native.flatten(X)
+    g, m, delta, max_iters = 7, 3, 0.3, 9
+    order = rng.permutation(port.num_combos(g, m)).astype(np.int32)
+    want, sd, _ = port.compute(tok, off, 22, 8, g, m, t=T, approx=True, delta=delta, max_iters=max_iters, order=order)
+    fixture = str(tmp_path / "variance_case.npz")
+    np.savez(fixture, tokens=tok, offsets=off, n_train=22, n_test=8, g=g, m=m, t=T, delta=delta, max_iters=max_iters, order=order)
+    return fixture, want, sd
+
+
+@pytest.mark.parametrize("T,world", [(2, 2), (5, 2), (3, 4)])
+def test_variance_mode_chains_over_ranks(tmp_path, port, T, world):
+    """SURVEY 8e, approx variance mode: chain c on rank c mod R, one fp64 all-reduce of the K_hat sums.
+    stdevs are chain 0's, bit for bit; the kernel is the oracle's to the bit when the sum has two terms
+    (fp64 addition commutes) and to rounding otherwise (the reference's own threads add in arrival order)."""
+    fixture, want, sd = variance_case(tmp_path, port, T)
+    for z in run_variance_world(tmp_path, fixture, 29650 + T, world):
+        assert np.array_equal(z["stdevs"], sd)
+        if T == 2:
+            assert np.array_equal(z["tri"], want)
+        else:
+            assert np.allclose(z["tri"], want, rtol=1e-14, atol=0)
+

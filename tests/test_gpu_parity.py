@@ -981,6 +981,37 @@ def test_two_ranks_sharing_the_gpu_row_sharded(native, port, tmp_path, replicate
             assert np.array_equal(z["counts"], want)
 
 
+@pytest.mark.parametrize("T", [2, 4])
+def test_two_ranks_sharing_the_gpu_variance_chains(native, port, tmp_path, T):
+    """Variance mode over ranks with the REAL engine (two processes on cuda:0, gloo): chain c on rank
+    c mod 2, one fp64 all-reduce of the K_hat sums, stdevs from chain 0's rank — protein-like input
+    through the sparse dataflow. Two terms add up the same in either order: bit-identical to the oracle
+    for T = 2; to rounding for T = 4 (as between the reference's own threads)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    X = protein_like(400, 30, 120, seed=5)
+    tokens, offsets = native.flatten(X)
+    g, m, delta, max_iters = 8, 4, 0.05, 11
+    order = np.random.default_rng(3).permutation(port.num_combos(g, m)).astype(np.int32)
+    want, sd, _ = port.compute(tokens, offsets, 300, 100, g, m, t=T, approx=True, delta=delta, max_iters=max_iters, order=order)
+    fx = tmp_path / "in.npz"
+    np.savez(fx, tokens=tokens, offsets=offsets, n_train=300, n_test=100, g=g, m=m, t=T, delta=delta, max_iters=max_iters, order=order)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29720 + T), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_variance_worker.py"), str(fx), str(tmp_path),
+                               "cuda:0"], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    for r in range(2):
+        z = np.load(tmp_path / ("rank%d.npz" % r))
+        assert np.array_equal(z["stdevs"], sd)
+        if T == 2:
+            assert np.array_equal(z["tri"], want)
+        else:
+            assert np.allclose(z["tri"], want, rtol=1e-14, atol=0)
+
+
 @pytest.mark.parametrize("global_pairs", ["0", "1"])
 def test_sparse_pair_accumulation_variants(native, port, monkeypatch, global_pairs):
     """Protein-like input through the sparse dataflow with owner-slice LDS accumulation and with
