@@ -431,6 +431,26 @@ def test_emu_sparse_pair_accumulation_variants(emu_lib, port, monkeypatch, globa
     assert e.stats()["cell_updates"] == U
 
 
+def test_emu_emit_quarter_tile_passes(emu_lib, port):
+    """Sparse dataflow, k_sx_emit: 16 long sequences over 4^5 keys give every k-mer run ~16 entries of up to
+    16 partners — short entries only, ~17 k update words per 2048-entry tile, more than the 12,288 LDS
+    slots: the tile is binned a quarter at a time (every other input bins a tile in one pass)."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(44)
+    X = rng.integers(1, 5, size=(16, 2500), dtype=np.int32)
+    tok, off = _native.flatten(X)
+    g, m = 8, 3
+    combos = np.array([0, 17, 55], dtype=np.int32)
+    want, _, U = port.raw_counts(tok, off, g, m, combos)
+    e = _native.Engine(g, m, path=2, lib=emu_lib)
+    e.load_sequences(tok, off, 12, 4)
+    e.accumulate(combos)
+    e.finalize()
+    assert np.array_equal(e.get_counts(), want)
+    assert e.stats()["cell_updates"] == U and U > 3 * 12288 * 8
+    e.close()
+
+
 def test_emu_segment_scan_in_chunks(emu_lib, port, monkeypatch):
     """Sparse dataflow: the tile records of a batch (entries per tile, last run start) are scanned by
     one workgroup, or — batches of many tiles — as chunk totals, a scan over the chunks and the chunks
