@@ -822,21 +822,18 @@ def test_skip_test_block_sparse(native, port, monkeypatch, global_pairs):
 def test_sparse_emit_quarter_tile_passes(native, port):
     """k_sx_emit bins a tile's short entries a quarter at a time when their update words exceed the LDS
     slots: 16 long sequences over 4^5 keys make every run ~16 entries of up to 16 partners (~17 k words per
-    2048-entry tile). Whole and in row bands, streams and atomics, against the oracle."""
+    2048-entry tile). In one call and in two (the second enqueued ahead of its size), against the oracle."""
     rng = np.random.default_rng(44)
     X = rng.integers(1, 5, size=(16, 6000), dtype=np.int32)
     tokens, offsets = native.flatten(X)
     g, m = 8, 3
     combos = np.arange(0, 56, 5, dtype=np.int32)
     want, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=8)
-    for rows in (None, ((0, 9), (9, 16))):
+    for parts in (1, 2):
         e = native.Engine(g, m, path=2)
         e.load_sequences(tokens, offsets, 12, 4)
-        if rows:
-            for lo, hi in rows:
-                e.accumulate_rows(combos, lo, hi)
-        else:
-            e.accumulate(combos)
+        for part in np.array_split(combos, parts):
+            e.accumulate(part)
         e.finalize()
         assert np.array_equal(e.get_counts(), want)
         assert e.stats()["cell_updates"] == U
