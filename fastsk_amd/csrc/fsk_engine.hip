@@ -447,16 +447,15 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         FSK_HIP(e->d_list_off.reserve((size_t)O + 1));
         FSK_HIP(e->d_part_base.reserve((size_t)O + 1));
     }
-    if (nb <= 16) {  // (variance mode: a handful of combos per batch)
+    fsk::SxIds ids{};
+    const bool by_id = nb <= 16;  // (variance mode: a handful of combos per batch) positions from the resident table
+    if (by_id) {
         if (!e->allpos_ready) {
             FSK_HIP(e->d_allpos.reserve(e->all_pos.size()));
             FSK_HIP(hipMemcpy(e->d_allpos.p, e->all_pos.data(), e->all_pos.size(), hipMemcpyHostToDevice));
             e->allpos_ready = true;
         }
-        fsk::SxIds ids{};
         for (int s = 0; s < nb; ++s) ids.id[s] = combos[s];
-        FSK_LAUNCH(fsk::k_sx_begin, dim3(1), dim3(256), 0, e->stream, (const uint8_t*)e->d_allpos.p, ids, nb, e->k, e->d_pos.p, e->d_sxstat.p);
-        e->st.launches += 1;
     } else {
         for (int s = 0; s < nb; ++s)
             memcpy(pos_pin + (size_t)s * e->k, &e->all_pos[(size_t)combos[s] * e->k], e->k);
@@ -468,7 +467,8 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
 
     e->tic();
     FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_extract<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, e->view(), e->d_featseq.p,
-               e->d_fstart.p, nfeat, tps, e->k, e->sigma, sb, e->d_pos.p, rec[0], e->d_blockhist.p, dmask);
+               e->d_fstart.p, nfeat, tps, e->k, e->sigma, sb, by_id ? (const uint8_t*)e->d_allpos.p : (const uint8_t*)e->d_pos.p, rec[0],
+               e->d_blockhist.p, dmask, ids, by_id ? e->d_sxstat.p : (u64*)nullptr);
     e->toc(&e->st.ms_extract);
     e->st.launches += 1;
 
@@ -527,15 +527,18 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                lists ? e->d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->d_tile_stat.p,
                skip_from, skipping ? (const int*)e->d_tile_ts.p : (const int*)nullptr, skipping ? e->d_Tk.p : (uint32_t*)nullptr);
     stat_pin[0] = stat_pin[1] = 0;
-    FSK_LAUNCH(fsk::k_sx_stat_sum, dim3(32), dim3(256), 0, e->stream, (const u64*)e->d_tile_stat.p, ntiles, e->d_sxstat.p, stat_pin);
-    e->st.launches += 4;
+    e->st.launches += 3;
     u64 words = 0;
-    if (lists) {  // where every (tile, owner) share of the update streams starts
-        FSK_LAUNCH(fsk::k_sx_ucol_sum, dim3(nchunks), dim3(256), 0, e->stream, (const uint32_t*)e->d_ucount.p, ntiles, O, e->d_uchunk.p);
+    if (lists) {  // where every (tile, owner) share of the update streams starts (+ the batch's pair and word totals)
+        FSK_LAUNCH(fsk::k_sx_ucol_sum, dim3(nchunks), dim3(256), 0, e->stream, (const uint32_t*)e->d_ucount.p, ntiles, O, e->d_uchunk.p,
+                   (const u64*)e->d_tile_stat.p, e->d_sxstat.p, stat_pin);
         FSK_LAUNCH(fsk::k_sx_ucol_scan, dim3(O), dim3(256), 0, e->stream, e->d_uchunk.p, nchunks, O, e->d_utot.p);
-        FSK_LAUNCH(fsk::k_scan_totals, dim3(1), dim3(256), 0, e->stream, (const uint32_t*)e->d_utot.p, O, e->d_list_off.p);
-        FSK_LAUNCH(fsk::k_sx_ucol_apply, dim3(nchunks), dim3(256), 0, e->stream, e->d_ucount.p, ntiles, O, (const uint32_t*)e->d_uchunk.p);
-        e->st.launches += 4;
+        FSK_LAUNCH(fsk::k_sx_ucol_apply, dim3(nchunks), dim3(256), 0, e->stream, e->d_ucount.p, ntiles, O, (const uint32_t*)e->d_uchunk.p,
+                   (const uint32_t*)e->d_utot.p, e->d_list_off.p);
+        e->st.launches += 3;
+    } else {
+        FSK_LAUNCH(fsk::k_sx_stat_sum, dim3(32), dim3(256), 0, e->stream, (const u64*)e->d_tile_stat.p, ntiles, e->d_sxstat.p, stat_pin);
+        e->st.launches += 1;
     }
     const bool guarded = guard_cap != 0;
     u64 cap_words = ~(u64)0;
