@@ -67,8 +67,12 @@ def git_blob_hash(path):
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
-def kernel_hashes():
-    return {f: git_blob_hash(os.path.join(ROOT, f)) for f in KERNEL_FILES}
+def kernel_hashes(files=KERNEL_FILES):
+    return {f: git_blob_hash(os.path.join(ROOT, f)) for f in files}
+
+
+# the sources of the sparse pipeline (kernels + the host code that batches and sizes them)
+SPARSE_FILES = ("fastsk_amd/csrc/fsk_sparse_kernels.inc", "fastsk_amd/csrc/fsk_kernels.h", "fastsk_amd/csrc/fsk_engine.hip")
 
 
 def host_cpus():
@@ -468,10 +472,27 @@ def main():
             gpu_ms = (d("ms_extract") + d("ms_sort") + d("ms_segment") + d("ms_pairs")) / args.steps
             alg_gbs = alg_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0
             fam = {"extract": d("ms_extract"), "sort": d("ms_sort"), "segment": d("ms_segment"), "pairs": d("ms_pairs")}
+            # measured HBM bytes of one config-4 pass: the sum over the pipeline's kernels of the rocprofv3 --pmc passes in
+            # profiles/ (FETCH_SIZE x2 + WRITE_SIZE), accepted only for this workload and these sources
+            traffic, traffic_note = None, "not collected in this run (profiles/ holds the rocprofv3 --pmc passes of the sparse kernels)"
+            tpath = os.path.join(ROOT, "profiles", "traffic_config4.json")
+            if args.config == 4 and world == 1 and os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    if tj.get("combos") != len(mine):
+                        traffic_note = "profiles/traffic_config4.json describes another combo count"
+                    elif tj.get("kernel_files") != kernel_hashes(SPARSE_FILES):
+                        traffic_note = "profiles/traffic_config4.json was measured on other sources (blob hashes differ): refused"
+                    else:
+                        traffic = tj.get("hbm_bytes_per_step")
+                        traffic_note = "profiles/traffic_config4.json (sum over the pipeline's kernels of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, NOT this run), commit %s" % tj.get("commit", "?")
+                except Exception as exc:
+                    traffic_note = "profiles/traffic_config4.json unreadable: %r" % exc
             roofline = {
                 "bound": "hbm", "kernel": "sparse pipeline (k_sx_extract, k_sx_hist/scan_slot/scatter, k_sx_seg_*, k_sx_emit + k_sx_consume); largest family: %s" % max(fam, key=fam.get),
-                "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS, "traffic": None,
-                "traffic_source": "not collected in this run (profiles/ holds the rocprofv3 --pmc passes of the sparse kernels)",
+                "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": traffic_note,
+                "hbm_measured_frac": (traffic / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and gpu_ms > 0) else None,
                 "algorithmic_bytes_per_step": alg_bytes, "cell_updates_per_step": U, "gpu_ms_per_step": gpu_ms,
                 "sort_passes_priced": P, "sort_passes_run": s1["sort_passes"],
                 "note": "algorithmic bytes = 16*U + 16*P*nfeat + input per combo (SURVEY 8d) over the HIP-event time of the pipeline's kernels",

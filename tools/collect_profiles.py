@@ -84,6 +84,17 @@ def main():
         src = os.path.join(ROOT, "gpurun_out", "pmc", tag, "summary.json")
         if os.path.exists(src):
             shutil.copy(src, os.path.join(DST, dst))
+    # measured HBM bytes of one config-4 pass (what `bench.py --config 4` reports as roofline.traffic)
+    c4 = os.path.join(DST, TAG + "_pmc_sparse_config4.json")
+    if os.path.exists(c4):
+        from bench import SPARSE_FILES
+        ks = json.load(open(c4))["kernels"]
+        total = sum(v.get("hbm_bytes") or 0.0 for v in ks.values())
+        json.dump({"workload": "config4: protein 2.19, g=14 m=10, exact", "combos": 1001, "hbm_bytes_per_step": total,
+                   "kernel_files": kernel_hashes(SPARSE_FILES), "commit": commit + ("+uncommitted csrc changes" if dirty else ""),
+                   "source": "profiles/%s_pmc_sparse_config4.json: sum over the pipeline's kernels of FETCH_SIZE KiB x1024 x2 (gfx950 "
+                             "correction) + WRITE_SIZE KiB x1024, one fsk_compute of all 1001 combos" % TAG},
+                  open(os.path.join(DST, "traffic_config4.json"), "w"), indent=1)
     if os.path.exists(os.path.join(SRC, "ubench_mfma_i8.txt")):
         shutil.copy(os.path.join(SRC, "ubench_mfma_i8.txt"), os.path.join(DST, TAG + "_ubench_mfma_i8_vs_dot8.txt"))
     print("profiles/ refreshed from", SRC)
