@@ -221,6 +221,30 @@ def test_emu_error_convention(emu_lib):
     e.finalize()
     assert e.get_test().shape == (0, 2)
     assert e.get_train()[0, 0] == 1.0
+    # the chain entry points belong to the variance mode
+    with pytest.raises(_native.FskError) as ei:
+        e.run_chains(0, 1)
+    assert ei.value.code == -3 and "variance mode" in str(ei.value)
+    buf = np.zeros(3, dtype=np.float64)
+    with pytest.raises(_native.FskError) as ei:
+        e.get_kernel_sum_device(buf.ctypes.data)
+    assert ei.value.code == -3
+    v = _native.Engine(6, 2, t=2, approx=True, max_iters=3, lib=emu_lib)
+    with pytest.raises(_native.FskError) as ei:
+        v.run_chains(0, 1)           # nothing loaded
+    assert ei.value.code == -3
+    v.load_sequences(tok, off, 2, 0)
+    with pytest.raises(_native.FskError) as ei:
+        v.run_chains(-1, 1)
+    assert ei.value.code == -1
+    with pytest.raises(_native.FskError) as ei:
+        v.set_kernel_sum_device(buf.ctypes.data)   # no chains have run yet
+    assert ei.value.code == -3
+    v.run_chains(1, 2)               # chain 1 only: no stdevs on this engine
+    v.get_kernel_sum_device(buf.ctypes.data)
+    v.set_kernel_sum_device(buf.ctypes.data)
+    v.finalize()
+    assert len(v.get_stdevs()) == 0 and v.get_train()[1, 1] == 1.0
 
 
 def test_emu_edge_cases(emu_lib, port):
