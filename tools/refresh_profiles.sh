@@ -9,20 +9,21 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
 rm -rf "$O"; mkdir -p "$O"
 cd "$R" && python3 bench.py --steps 2 --warmup 1 > "$O/bench.json" 2> "$O/bench.err"
-python3 bench.py --config 4 --steps 5 --warmup 2 --no-cpu-baseline --no-also > "$O/bench_config4.json" 2> "$O/bench_config4.err"
 FSK_BENCH_FORCE_DIST=1 MASTER_PORT=29777 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also > "$O/bench_rccl_world1.json" 2> "$O/bench_rccl_world1.err"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-also > "$O/bench_under_rocprof.json" 2> "$O/stats.err"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/pmc_$c" -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-also > /dev/null 2> "$O/pmc_$c.err"
 done
-# traffic.json from the two passes above (needs bench.json, stats, pmc_*), then the headline line once more:
-# it now carries the measured HBM traffic of exactly these kernel sources
-(cd "$R" && python3 tools/collect_profiles.py r02 > "$O/collect_on_box.log" 2>&1 && python3 bench.py --steps 2 --warmup 1 > "$O/bench_final.json" 2> "$O/bench_final.err")
+# the sparse pipeline's counter passes at config 4 (traffic_config4.json is built from them)
+(cd "$R" && tools/pmc_passes.sh r02_cfg4 "$R/tools/profile_one.py" f7_cfg4_prot219_exact > "$O/pmc_cfg4.log" 2>&1)
+# traffic.json / traffic_config4.json from the passes above (needs bench.json, stats, pmc_*), then the headline
+# line once more and the config-4 line: they now carry the measured HBM traffic of exactly these sources
+(cd "$R" && python3 tools/collect_profiles.py r02 > "$O/collect_on_box.log" 2>&1 && python3 bench.py --steps 2 --warmup 1 > "$O/bench_final.json" 2> "$O/bench_final.err";
+ python3 bench.py --config 4 --steps 5 --warmup 2 --no-cpu-baseline --no-also > "$O/bench_config4.json" 2> "$O/bench_config4.err")
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_configs" -- python3 "$R/tools/bench_configs.py" > /dev/null 2> "$O/stats_configs.err"
 cd "$R" && python3 tools/bench_configs.py > "$O/configs.jsonl" 2> "$O/configs.err"
 python3 tools/bench_large_g.py > "$O/large_g.jsonl" 2> "$O/large_g.err"
-tools/pmc_passes.sh r02_cfg4 "$R/tools/profile_one.py" f7_cfg4_prot219_exact > "$O/pmc_cfg4.log" 2>&1
 tools/pmc_passes.sh r02_cfg1 "$R/tools/profile_one.py" f7_cfg1_prot11_approx_t1 > "$O/pmc_cfg1.log" 2>&1
 tools/bench_n_series.sh > /dev/null 2>&1; cp "$R/gpurun_out/n_series.jsonl" "$O/n_series.jsonl"
 [ -x tools/ubench_mfma_i8 ] && tools/ubench_mfma_i8 > "$O/ubench_mfma_i8.txt" 2>&1
