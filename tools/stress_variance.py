@@ -21,16 +21,16 @@ def main(iters=200, seed=0):
         k = int(rng.integers(2, 6 if sigma <= 5 else 4))
         m = int(rng.integers(1, 5))
         g = k + m
-        N = int(rng.choice([8, 40, 130, 300]))
+        N = int(rng.choice([1, 2, 3, 8, 40, 130, 300]))
         hi = int(rng.choice([g + 2, 30, 80]))
         X = [rng.integers(1, sigma + 1, size=int(L)).astype(np.int32) for L in rng.integers(g, max(hi, g) + 1, size=N)]
         if rng.random() < 0.3:
             X[int(rng.integers(N))][:] = 1  # a low-complexity row
         tokens, offsets = _native.flatten(X)
-        ntr = int(rng.integers(2, N + 1))
+        ntr = int(rng.integers(1, N + 1))
         nc = port.num_combos(g, m)
         order = rng.permutation(nc).astype(np.int32)
-        T = int(rng.choice([1, 1, 2, 3, 5]))
+        T = int(rng.choice([1, 1, 2, 3, 5, 25]))  # (25: more chains than some (g, m) have combos)
         max_iters = int(rng.choice([-1, 1, 2, 3, 5, 7, 12]))
         delta = float(rng.choice([0.01, 0.05, 0.2, 0.6, 2.0]))
         want, sd, _ = port.compute(tokens, offsets, ntr, N - ntr, g, m, t=T, approx=True, delta=delta, max_iters=max_iters, order=order)
