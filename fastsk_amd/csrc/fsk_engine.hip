@@ -1073,8 +1073,9 @@ void default_order(fsk_engine* e) {
 // (zero on entry, zero again on exit), result to out[0]
 // `count` independent sums laid out `stride` values apart (their block sums / block records / results
 // follow each other); the chains run on `chain_stream`
-int enqueue_sequential_sum(fsk_engine* e, const double* d_vals, u64 n, double* bsum, fsk::SeqBlk* blk, double* out, int count = 1,
-                           u64 stride = 0, hipStream_t chain_stream = nullptr, hipEvent_t handoff = nullptr) {
+// grp: 2 * SQ_GROUPS group records per block, laid out like blk
+int enqueue_sequential_sum(fsk_engine* e, const double* d_vals, u64 n, double* bsum, fsk::SeqBlk* blk, fsk::SeqGrp* grp, double* out,
+                           int count = 1, u64 stride = 0, hipStream_t chain_stream = nullptr, hipEvent_t handoff = nullptr) {
     const uint32_t nblocks = (uint32_t)((n + fsk::SQ_BLOCK - 1) / fsk::SQ_BLOCK);
     if (nblocks > 0)
         FSK_LAUNCH(fsk::k_seq_prep, dim3(nblocks, count), dim3(256), 0, e->stream, d_vals, n, (const double*)bsum, blk, stride, nblocks);
@@ -1083,7 +1084,10 @@ int enqueue_sequential_sum(fsk_engine* e, const double* d_vals, u64 n, double* b
         FSK_HIP(hipEventRecord(handoff, e->stream));
         FSK_HIP(hipStreamWaitEvent(chain_stream, handoff, 0));
     }
-    FSK_LAUNCH(fsk::k_seq_chain, dim3(count), dim3(64), 0, cs, d_vals, n, (const fsk::SeqBlk*)blk, nblocks, bsum, out, stride);
+    if (nblocks > 0)  // (the few blocks that need group records: on the chains' stream, beside the next batch's kernels)
+        FSK_LAUNCH(fsk::k_seq_prep_groups, dim3(nblocks, count), dim3(256), 0, cs, d_vals, n, (const fsk::SeqBlk*)blk, stride, nblocks, grp);
+    FSK_LAUNCH(fsk::k_seq_chain, dim3(count), dim3(64), 0, cs, d_vals, n, (const fsk::SeqBlk*)blk, nblocks, bsum, out, stride,
+               (const fsk::SeqGrp*)grp);
     return FSK_OK;
 }
 
@@ -1116,7 +1120,8 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first = 0, int chain_step 
     FSK_HIP(e->d_Khat.reserve((size_t)pairs * RING));
     FSK_HIP(e->d_prod.reserve(tp * slots));
     FSK_HIP(e->d_bsum.reserve(nblk * slots + slots));
-    FSK_HIP(e->d_seqblk.reserve(nblk * slots * sizeof(fsk::SeqBlk)));
+    FSK_HIP(e->d_seqblk.reserve(nblk * slots * (sizeof(fsk::SeqBlk) + 2 * fsk::SQ_GROUPS * sizeof(fsk::SeqGrp))));
+    fsk::SeqGrp* const seq_grp = reinterpret_cast<fsk::SeqGrp*>(e->d_seqblk.p + nblk * slots * sizeof(fsk::SeqBlk));
     FSK_HIP(hipMemsetAsync(e->d_Kf64.p, 0, (size_t)pairs * sizeof(double), e->stream));
     FSK_HIP(hipMemsetAsync(e->d_bsum.p, 0, (nblk * slots + slots) * sizeof(double), e->stream));
     if (e->h_prod_cap < slots) {
@@ -1197,7 +1202,8 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first = 0, int chain_step 
         // second stream, under the kernels of the batches that follow
         const size_t slot0 = (size_t)B.part * AHEAD;
         int rc = enqueue_sequential_sum(e, e->d_prod.p + slot0 * tp, (u64)train_pairs, e->d_bsum.p + slot0 * nblk,
-                                        reinterpret_cast<fsk::SeqBlk*>(e->d_seqblk.p) + slot0 * nblk, h_avg + slot0, B.n, (u64)tp,
+                                        reinterpret_cast<fsk::SeqBlk*>(e->d_seqblk.p) + slot0 * nblk,
+                                        seq_grp + slot0 * nblk * (2 * fsk::SQ_GROUPS), h_avg + slot0, B.n, (u64)tp,
                                         e->chain_stream, ev_hand[B.part]);  // (the sums land in pinned host memory)
         if (rc) return rc;
         FSK_HIP(hipEventRecord(ev_done[B.part], e->chain_stream));
@@ -2025,12 +2031,13 @@ int fsk_sequential_sum(fsk_engine* e, const double* values, int64_t n, double* o
     struct Free { DevBuf<double>&a, &b; DevBuf<unsigned char>& c; ~Free() { a.release(); b.release(); c.release(); } } guard{vals, bsum, blk};
     FSK_HIP(vals.reserve((size_t)std::max<int64_t>(1, n)));
     FSK_HIP(bsum.reserve(nblk + 1));
-    FSK_HIP(blk.reserve((nblk + 1) * sizeof(fsk::SeqBlk)));
+    FSK_HIP(blk.reserve((nblk + 1) * (sizeof(fsk::SeqBlk) + 2 * fsk::SQ_GROUPS * sizeof(fsk::SeqGrp))));
     FSK_HIP(hipMemcpyAsync(vals.p, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, e->stream));
     FSK_HIP(hipMemsetAsync(bsum.p, 0, (nblk + 1) * sizeof(double), e->stream));
     if (n > 0)  // approximate block sums (what k_welford accumulates on the way in variance mode)
         FSK_LAUNCH(fsk::k_block_sums, dim3((uint32_t)nblk), dim3(256), 0, e->stream, (const double*)vals.p, (u64)n, bsum.p);
-    int rc = enqueue_sequential_sum(e, vals.p, (u64)n, bsum.p, reinterpret_cast<fsk::SeqBlk*>(blk.p), bsum.p + nblk);
+    int rc = enqueue_sequential_sum(e, vals.p, (u64)n, bsum.p, reinterpret_cast<fsk::SeqBlk*>(blk.p),
+                                    reinterpret_cast<fsk::SeqGrp*>(blk.p + (nblk + 1) * sizeof(fsk::SeqBlk)), bsum.p + nblk);
     if (rc) return rc;
     FSK_HIP(hipMemcpyAsync(out, bsum.p + nblk, sizeof(double), hipMemcpyDeviceToHost, e->stream));
     FSK_HIP(hipStreamSynchronize(e->stream));

@@ -593,8 +593,19 @@ __global__ __launch_bounds__(256) void k_welford_batch(const uint32_t* Ks, int n
 struct SeqBlk {
     int e;            // binade the block's integer total was computed for
     uint32_t flags;   // 1: negative or NaN value, 2: value too large for the integer total, 4: tie, 8: no prediction,
-                      // 16: every value of the block is zero (the block changes no running sum)
+                      // 16: every value of the block is zero (the block changes no running sum),
+                      // 32: the block has group records (below)
     u64 Q;            // sum of R(p) / u over the block
+};
+// A block that will not go through as one integer total — it holds a tie or an outsized value, or the
+// approximate sums say the running sum crosses into the next binade inside it — also gets one record per
+// group of SQ_GROUP values, for the predicted binade e (records 0..7) and for e + 1 (records 8..15): the
+// chain then redoes only the group where the crossing / the tie actually is, not the block.
+constexpr int SQ_GROUP = 1024, SQ_GROUPS = 8192 / SQ_GROUP;
+struct SeqGrp {
+    u64 Q;            // sum of R(p) / u over the group
+    uint32_t flags;   // 1, 2, 4, 16 as above
+    uint32_t pad;
 };
 union DblBits { double d; u64 u; };
 // unbiased exponent of a normal positive double within +-900, else INT32_MIN (zero, subnormal, huge, NaN)
@@ -679,9 +690,64 @@ __global__ __launch_bounds__(256) void k_seq_prep(const double* p, u64 n, const 
     __syncthreads();
     if (tid == 0) {
         const uint32_t all = s_f[0] | s_f[1] | s_f[2] | s_f[3];
+        const bool zero = (all >> 8) == 0u;
+        // group records when the block cannot be one integer total (a tie, an outsized or negative value)
+        // or is predicted to end in another binade than it starts in
+        const bool need = e != INT32_MIN && !zero && ((all & 7u) != 0u || seq_exponent(pre + bsum[b]) != e);
         blk[b].e = e == INT32_MIN ? 0 : e;
-        blk[b].flags = (all & 0xffu) | ((all >> 8) ? 0u : 16u);
+        blk[b].flags = (all & 0xffu) | (zero ? 16u : 0u) | (need ? 32u : 0u);
         blk[b].Q = s_q[0] + s_q[1] + s_q[2] + s_q[3];
+    }
+}
+
+// the group records of the blocks k_seq_prep marked (a few per sum): same grid; a kernel of its own so
+// that the common path above stays lean
+__global__ __launch_bounds__(256) void k_seq_prep_groups(const double* p, u64 n, const SeqBlk* blk, u64 stride, uint32_t nblk, SeqGrp* grp) {
+    static_assert(SQ_GROUP * SQ_GROUPS == SQ_BLOCK && SQ_GROUP % 256 == 0, "groups of a block");
+    const uint32_t tid = threadIdx.x, b = blockIdx.x;
+    blk += (size_t)blockIdx.y * nblk;
+    if (!(blk[b].flags & 32u)) return;  // (uniform)
+    __shared__ u64 s_gq[4][2 * SQ_GROUPS];
+    __shared__ uint32_t s_gf[4][2 * SQ_GROUPS];
+    p += (u64)blockIdx.y * stride;
+    grp += ((size_t)blockIdx.y * nblk + b) * (2 * SQ_GROUPS);
+    const u64 lo = (u64)b * SQ_BLOCK;
+    // thread tid holds values lo + 256 j + tid: j / (SQ_GROUP / 256) is the group
+    const double scale = seq_pow2(52 - blk[b].e), scale1 = scale * 0.5;  // binades e and e + 1
+    for (int g = 0; g < SQ_GROUPS; ++g) {
+        u64 q0 = 0, q1 = 0;
+        uint32_t f0 = 0, f1 = 0, nz = 0;
+#pragma unroll
+        for (int jj = 0; jj < SQ_GROUP / 256; ++jj) {
+            const u64 i = lo + (u64)(g * (SQ_GROUP / 256) + jj) * 256 + tid;
+            if (i < n) {
+                const double v = p[i];
+                if (v != 0.0) nz = 1u;
+                seq_classify(v, scale, 1125899906842624.0 /* 2^50 */, q0, f0);
+                seq_classify(v, scale1, 1125899906842624.0, q1, f1);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            q0 += __shfl_xor(q0, d);
+            q1 += __shfl_xor(q1, d);
+            f0 |= __shfl_xor(f0, d);
+            f1 |= __shfl_xor(f1, d);
+            nz |= __shfl_xor(nz, d);
+        }
+        if ((tid & 63u) == 0) {
+            s_gq[tid >> 6][g] = q0; s_gq[tid >> 6][SQ_GROUPS + g] = q1;
+            s_gf[tid >> 6][g] = f0 | (nz << 8); s_gf[tid >> 6][SQ_GROUPS + g] = f1 | (nz << 8);
+        }
+    }
+    __syncthreads();
+    if (tid < 2u * SQ_GROUPS) {
+        const uint32_t all = s_gf[0][tid] | s_gf[1][tid] | s_gf[2][tid] | s_gf[3][tid];
+        SeqGrp r;
+        r.Q = s_gq[0][tid] + s_gq[1][tid] + s_gq[2][tid] + s_gq[3][tid];
+        r.flags = (all & 7u) | ((all >> 8) ? 0u : 16u);
+        r.pad = 0u;
+        grp[tid] = r;
     }
 }
 
@@ -798,11 +864,12 @@ __device__ __forceinline__ double seq_range(const double* p, u64 lo, u64 hi, dou
 // one wave: out[0] = the sequential sum of p[0..n); zeroes bsum for the slot's next use
 // (blockIdx.x = one of several independent sums laid out `stride` values / `nblocks` blocks apart)
 __global__ __launch_bounds__(64) void k_seq_chain(const double* p, u64 n, const SeqBlk* blk, uint32_t nblocks, double* bsum, double* out,
-                                                  u64 stride) {
+                                                  u64 stride, const SeqGrp* grp) {
     __shared__ double stage[SQ_STAGE];
     const uint32_t lane = threadIdx.x;
     p += (u64)blockIdx.x * stride;
     blk += (size_t)blockIdx.x * nblocks;
+    grp += (size_t)blockIdx.x * nblocks * (2 * SQ_GROUPS);
     bsum += (size_t)blockIdx.x * nblocks;
     out += blockIdx.x;
     // the running sum is kept either as a double s, or — between accepted blocks of one binade — as the
@@ -833,11 +900,44 @@ __global__ __launch_bounds__(64) void k_seq_chain(const double* p, u64 n, const 
                     continue;
                 }
             }
+            const u64 lo = (u64)(c0 + j) * SQ_BLOCK, hi = lo + SQ_BLOCK < n ? lo + SQ_BLOCK : n;
+            if (kf & 32u) {
+                // group records: the groups before and after the crossing / the tie go through as integer
+                // totals of their binade; only the group in between is redone
+                const int ke = (int)wave_bcast_u32((uint32_t)mine.e, j);
+                SeqGrp mg;
+                mg.Q = 0; mg.flags = 1u; mg.pad = 0u;
+                if (lane < 2u * SQ_GROUPS) mg = grp[(size_t)(c0 + j) * (2 * SQ_GROUPS) + lane];
+                for (uint32_t g = 0; g < (uint32_t)SQ_GROUPS; ++g) {
+                    const u64 glo = lo + (u64)g * SQ_GROUP;
+                    if (glo >= hi) break;
+                    if (wave_bcast_u32(mg.flags, g) & 16u) continue;  // all zeros
+                    if (!as_int && s > 0.0 && seq_exponent(s) != INT32_MIN) {
+                        e = seq_exponent(s);
+                        S = (u64)(s * seq_pow2(52 - e));
+                        as_int = true;
+                    }
+                    if (as_int && (e == ke || e == ke + 1)) {
+                        const uint32_t r = (e == ke ? 0u : (uint32_t)SQ_GROUPS) + g;
+                        const u64 gq = wave_bcast_u64(mg.Q, r);
+                        if (wave_bcast_u32(mg.flags, r) == 0u && S + gq < ((u64)1 << 53)) {
+                            S += gq;
+                            continue;
+                        }
+                    }
+                    if (as_int) {
+                        s = (double)S * seq_pow2(e - 52);
+                        as_int = false;
+                    }
+                    const u64 ghi = glo + SQ_GROUP < hi ? glo + SQ_GROUP : hi;
+                    s = seq_range(p, glo, ghi, s, stage);
+                }
+                continue;
+            }
             if (as_int) {
                 s = (double)S * seq_pow2(e - 52);
                 as_int = false;
             }
-            const u64 lo = (u64)(c0 + j) * SQ_BLOCK, hi = lo + SQ_BLOCK < n ? lo + SQ_BLOCK : n;
             s = seq_range(p, lo, hi, s, stage);
         }
     }
