@@ -32,9 +32,11 @@ def main():
             if d["approx"]:
                 e.set_combo_order(d["order"])
             e.compute(tokens, offsets, ntr, nte)  # warm-up (allocations)
-            t0 = time.perf_counter()
-            e.compute(tokens, offsets, ntr, nte)
-            dt = time.perf_counter() - t0
+            dt = float("inf")
+            for _ in range(1 if profile else 3):  # (best of three whole calls: a single call now and then catches a hiccup of the box)
+                t0 = time.perf_counter()
+                e.compute(tokens, offsets, ntr, nte)
+                dt = min(dt, time.perf_counter() - t0)
             st = e.stats()
             e.close()
             if not profile:
