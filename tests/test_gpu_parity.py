@@ -665,6 +665,32 @@ def test_register_staged_tile_kernel_still_agrees(native, port, monkeypatch):
         e.close()
 
 
+def test_sequential_sum_random_inputs(native):
+    """The device's left-to-right fp64 sum on 300 random vectors of five kinds (wide magnitude ranges,
+    squares scaled by 1 - 1/i as the Welford products are, dyadic values that tie at every addition, mostly
+    zeros, one huge value among small ones; 1 to 60,000 values: whole blocks, group records, tails) — bit
+    for bit against the host loop."""
+    from test_sequential_sum import sequential
+    e = native.Engine(4, 2)
+    rng = np.random.default_rng(9)
+    for t in range(300):
+        n = int(rng.integers(1, 60000))
+        kind = t % 5
+        if kind == 0:
+            x = rng.random(n) * 10.0 ** rng.integers(-8, 8)
+        elif kind == 1:
+            x = (rng.integers(0, 40, n) ** 2) * (1.0 - 1.0 / rng.integers(2, 60))
+        elif kind == 2:
+            x = np.ldexp(rng.integers(1, 1 << 20, n).astype(np.float64), rng.integers(-30, 30, n))
+        elif kind == 3:
+            x = np.where(rng.random(n) < 0.7, 0.0, rng.random(n))
+        else:
+            x = np.full(n, 0.5 * 2.0 ** rng.integers(-5, 5))
+            x[rng.integers(0, n)] = 2.0 ** 40
+        assert np.float64(e.sequential_sum(x)).tobytes() == np.float64(sequential(x)).tobytes(), (t, kind, n)
+    e.close()
+
+
 @pytest.mark.parametrize("path", [0, 2])
 def test_variance_mode_stops_anywhere(native, port, path):
     """Variance mode runs ahead of its stop test (batches of 4 iterations, two in flight, second
