@@ -53,3 +53,24 @@ def test_sequential_sum_is_the_left_to_right_sum(emu_engine, name):
     got = emu_engine.sequential_sum(x)
     want = sequential(x)
     assert np.float64(got).tobytes() == np.float64(want).tobytes(), (name, got, want)
+
+
+def test_sequential_sum_random_vectors(emu_engine):
+    """Random vectors spanning several blocks (group records, tails, ties in dyadic data, mostly-zero
+    data) — the same five kinds tests/test_gpu_parity.py runs at larger sizes on the GPU."""
+    rng = np.random.default_rng(19)
+    for t in range(25):
+        n = int(rng.integers(1, 30000))
+        kind = t % 5
+        if kind == 0:
+            x = rng.random(n) * 10.0 ** rng.integers(-8, 8)
+        elif kind == 1:
+            x = (rng.integers(0, 40, n) ** 2) * (1.0 - 1.0 / rng.integers(2, 60))
+        elif kind == 2:
+            x = np.ldexp(rng.integers(1, 1 << 20, n).astype(np.float64), rng.integers(-30, 30, n))
+        elif kind == 3:
+            x = np.where(rng.random(n) < 0.7, 0.0, rng.random(n))
+        else:
+            x = np.full(n, 0.5 * 2.0 ** rng.integers(-5, 5))
+            x[rng.integers(0, n)] = 2.0 ** 40
+        assert np.float64(emu_engine.sequential_sum(x)).tobytes() == np.float64(sequential(x)).tobytes(), (t, kind, n)
