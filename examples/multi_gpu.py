@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
-"""Multi-GPU exact kernel: one process per GPU, row-band (or combo) sharded over RCCL.
+"""Multi-GPU kernel: one process per GPU over RCCL — exact mode sharded by row bands (or combos), or
+the approximate (variance / convergence) mode with its Welford chains dealt over the GPUs.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
         examples/multi_gpu.py --n-seq 100000 --seq-len 300 -g 12 -m 8
 
 --shard rows (default): every rank runs all combos over its own band of rows, the kernel stays
 distributed and blocks are assembled on demand; --shard combos: combos dealt round-robin and the
-triangle all-reduced. Rank 0 prints a corner of the normalised kernel. See fastsk_amd/distributed.py.
+triangle all-reduced. --approx T: variance mode with T chains (chain c on GPU c mod R, one fp64
+all-reduce of their sums, stdevs from chain 0). Rank 0 prints a corner of the normalised kernel.
+See fastsk_amd/distributed.py.
 """
 import argparse
 import os
@@ -30,6 +33,8 @@ def main():
     ap.add_argument("-g", type=int, default=12)
     ap.add_argument("-m", type=int, default=8)
     ap.add_argument("--shard", choices=["rows", "combos"], default="rows")
+    ap.add_argument("--approx", type=int, default=0, metavar="T", help="variance mode with T chains instead of the exact kernel")
+    ap.add_argument("--delta", type=float, default=0.025)
     args = ap.parse_args()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
@@ -38,6 +43,18 @@ def main():
     rng = np.random.Generator(np.random.PCG64(20201214))
     X = rng.integers(1, 5, size=(args.n_seq, args.seq_len), dtype=np.int32)
     tokens, offsets = X.reshape(-1), np.arange(args.n_seq + 1, dtype=np.int64) * args.seq_len
+    if args.approx:
+        t0 = time.time()
+        eng, sd = distributed.compute_variance_sharded(tokens, offsets, args.n_seq, 0, args.g, args.m, args.approx, delta=args.delta,
+                                                       seed=20201214)  # (every rank must draw the same combo order)
+        dt = time.time() - t0
+        if not dist.is_initialized() or dist.get_rank() == 0:
+            print("approximate gkm kernel, %d sequences, %d chains, %d GPUs: %.2f s, chain 0 ran %d iterations (last stdev %.4g)"
+                  % (args.n_seq, args.approx, dist.get_world_size() if dist.is_initialized() else 1, dt, len(sd), sd[-1]))
+            print(eng.get_block(0, 4, 0, 4))
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
     t0 = time.time()
     eng, K = distributed.compute_sharded(tokens, offsets, args.n_seq, 0, args.g, args.m, shard_by=args.shard,
                                          replicate=False)
