@@ -92,6 +92,8 @@ struct fsk_engine {
     // them (dense dataflow, one workgroup per tile): rows [lazy_lo, lazy_hi) are zero by contract
     // but not in memory until a tile launch stores them or materialise_zero() fills them.
     int64_t lazy_lo = -1, lazy_hi = -1;
+    int variance_dense_slots = 1;  // FSK_VARIANCE_DENSE_SLOTS=0: zero fill + k_welford per iteration instead (testing)
+    bool store_next = false;  // variance mode, dense dataflow: the next (one-combo, whole-triangle) tile launch stores into the K it is given
     uint32_t* h_stage = nullptr;         // pinned: the packed sequences on their way to the device (fsk_load_sequences)
     size_t h_stage_cap = 0;
     bool stage_in_flight = false;
@@ -981,7 +983,11 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
         // Store instead of add? Only the first launch over rows that are still "zero by contract",
         // starting at their lower edge, with one workgroup per tile and the engine's own triangle.
         int store = 0;
-        if (e->lazy_lo >= 0) {
+        if (e->store_next) {
+            if (!(e->tile_dma && !compact && n_splits == 1 && first_test_tile == 0xffffffffu && row0 == 0 && row1 >= e->N))
+                return e->fail(FSK_ESTATE, "internal: a storing tile launch was asked for where none is possible");
+            store = 1;
+        } else if (e->lazy_lo >= 0) {
             if (K == e->d_K && e->tile_dma && !compact && n_splits == 1 && first_test_tile == 0xffffffffu && row0 == e->lazy_lo &&
                 row1 <= e->lazy_hi) {
                 store = 1;
@@ -1169,9 +1175,17 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first = 0, int chain_step 
     // (u32 triangles written whole by k_sx_consume; without update streams — huge N — pairs go to K with
     // atomics and the iterations run one at a time like the dense ones)
     bool grouped = e->path == FSK_PATH_SPARSE && e->sx_lists && !e->force_global_pairs;
+    // Dense dataflow with a tile kernel that can STORE (one workgroup per tile, the direct-to-LDS kernel, no
+    // key compaction, no test-block filter): every iteration's tile launch stores its counts into a u64
+    // triangle of its own — no zero fill — and the batch's Welford updates run as one pass like the sparse
+    // batches' (while the slot triangles stay a modest share of the memory).
+    const bool dense_slots = e->path == FSK_PATH_DENSE && e->tile_dma && !e->compact && !(e->cfg.skip_test_block && e->n_test > 0) &&
+                             (u64)pairs * AHEAD * DEPTH * sizeof(u64) <= ((u64)8 << 30) && e->variance_dense_slots;
     // (one set of slot triangles per batch in flight: a stop inside a batch runs its Welford prefix again)
     if (grouped) FSK_HIP(e->d_Kslots.reserve(((size_t)pairs * AHEAD * DEPTH + 1) / 2));
+    if (dense_slots) FSK_HIP(e->d_Kslots.reserve((size_t)pairs * AHEAD * DEPTH));
     auto slots_of = [&](int part) { return reinterpret_cast<uint32_t*>(e->d_Kslots.p) + (size_t)part * AHEAD * (size_t)pairs; };
+    auto slots64_of = [&](int part) { return e->d_Kslots.p + (size_t)part * AHEAD * (size_t)pairs; };
     static_assert(AHEAD <= fsk::WF_SLOTS, "k_welford_batch carries a batch's iterations in registers");
     auto issue = [&](Batch& B) -> int {
         if (grouped) {
@@ -1181,14 +1195,26 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first = 0, int chain_step 
             if (rc == FSK_RETRY_UNGROUPED) grouped = false;  // too many updates for one stream: from here on one iteration at a time
             else if (rc) return rc;
         }
-        B.grouped = grouped;
+        B.grouped = grouped || dense_slots;  // (the batch's counts sit in slot triangles, its Welford update is one pass)
         if (grouped) {  // K_hat through the batch's iterations in one pass; only the state after the batch is written
             const size_t slot0 = (size_t)B.part * AHEAD;
-            FSK_LAUNCH(fsk::k_welford_batch, dim3(wblocks), dim3(256), 0, e->stream, (const uint32_t*)slots_of(B.part), B.n,
+            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<uint32_t>), dim3(wblocks), dim3(256), 0, e->stream, (const uint32_t*)slots_of(B.part), B.n,
+                       (const double*)khat(B.base), khat(B.base + B.n), e->d_prod.p + slot0 * tp, (u64)tp, (u64)pairs, (u64)train_pairs,
+                       (double)B.first_iter, e->d_bsum.p + slot0 * nblk, (uint32_t)nblk, 1);
+        } else if (dense_slots) {
+            for (int b = 0; b < B.n; ++b) {
+                int32_t combo = e->order[B.first_item + b * T];
+                e->store_next = true;
+                int rc = do_accumulate(e, &combo, 1, slots64_of(B.part) + (size_t)b * pairs);
+                e->store_next = false;
+                if (rc) return rc;
+            }
+            const size_t slot0 = (size_t)B.part * AHEAD;
+            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<u64>), dim3(wblocks), dim3(256), 0, e->stream, (const u64*)slots64_of(B.part), B.n,
                        (const double*)khat(B.base), khat(B.base + B.n), e->d_prod.p + slot0 * tp, (u64)tp, (u64)pairs, (u64)train_pairs,
                        (double)B.first_iter, e->d_bsum.p + slot0 * nblk, (uint32_t)nblk, 1);
         }
-        for (int b = 0; b < B.n && !grouped; ++b) {
+        for (int b = 0; b < B.n && !B.grouped; ++b) {
             const size_t slot = (size_t)(B.part * AHEAD + b);
             FSK_HIP(hipMemsetAsync(e->d_K, 0, (size_t)pairs * sizeof(u64), e->stream));
             int32_t combo = e->order[B.first_item + b * T];
@@ -1277,10 +1303,16 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first = 0, int chain_step 
                     FSK_HIP(hipStreamSynchronize(e->chain_stream));
                 }
                 for (const Batch& B : q) (void)sx_harvest(e, B.part);
-                if (A.grouped && accepted < A.n)  // the stop fell inside the batch: the state after its accepted prefix
-                    FSK_LAUNCH(fsk::k_welford_batch, dim3(wblocks), dim3(256), 0, e->stream, (const uint32_t*)slots_of(A.part), accepted,
-                               (const double*)khat(A.base), khat(A.base + accepted), (double*)nullptr, (u64)0, (u64)pairs, (u64)train_pairs,
-                               (double)A.first_iter, (double*)nullptr, (uint32_t)0, 0);
+                if (A.grouped && accepted < A.n) {  // the stop fell inside the batch: the state after its accepted prefix
+                    if (dense_slots)
+                        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<u64>), dim3(wblocks), dim3(256), 0, e->stream, (const u64*)slots64_of(A.part),
+                                   accepted, (const double*)khat(A.base), khat(A.base + accepted), (double*)nullptr, (u64)0, (u64)pairs,
+                                   (u64)train_pairs, (double)A.first_iter, (double*)nullptr, (uint32_t)0, 0);
+                    else
+                        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<uint32_t>), dim3(wblocks), dim3(256), 0, e->stream,
+                                   (const uint32_t*)slots_of(A.part), accepted, (const double*)khat(A.base), khat(A.base + accepted),
+                                   (double*)nullptr, (u64)0, (u64)pairs, (u64)train_pairs, (double)A.first_iter, (double*)nullptr, (uint32_t)0, 0);
+                }
                 break;
             }
             // (working implies more items and iterations: the queue is not empty)
@@ -1375,6 +1407,7 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     enumerate_combos(cfg->g, e->k, e->all_pos);
     { const char* f = getenv("FSK_COMPACT"); e->force_compact = f ? atoi(f) : -1; }
     { const char* f = getenv("FSK_SPARSE_GLOBAL"); e->force_global_pairs = f ? atoi(f) : 0; }
+    { const char* f = getenv("FSK_VARIANCE_DENSE_SLOTS"); if (f) e->variance_dense_slots = atoi(f); }
     { const char* f = getenv("FSK_SEG_SCAN_CHUNKED"); if (f) e->force_seg_chunks = atoi(f); }
     { const char* f = getenv("FSK_SPARSE_SYNC"); if (f) e->sx_sync = atoi(f); }
     { const char* f = getenv("FSK_SPARSE_GUARD_CAP"); if (f && atoll(f) > 0) e->sx_guard_cap = (u64)atoll(f); }

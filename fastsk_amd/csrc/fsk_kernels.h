@@ -526,14 +526,15 @@ __global__ __launch_bounds__(256) void k_welford(const SrcT* Ks, const double* K
     }
 }
 
-// The same for the `nslots` consecutive iterations of a batch whose counts lie in u32 triangles `pairs`
-// cells apart (sparse dataflow, grouped batches): K_hat is read once, carried through the iterations in
+// The same for the `nslots` consecutive iterations of a batch whose counts lie in triangles `pairs`
+// cells apart (u32: sparse dataflow, grouped batches; u64: dense dataflow, one storing tile launch per iteration): K_hat is read once, carried through the iterations in
 // a register and written once — the state after the batch; the states in between exist only if the
 // host asks for them by running a prefix of the batch again (it does when its stop test fires inside
 // the batch). Per cell and iteration the same IEEE operations in the same order as k_welford.
 // prod / bsum of slot q: prod + q * prod_stride, bsum + q * nblk; write_prod = 0: only K_hat_out.
 constexpr int WF_SLOTS = 4;
-__global__ __launch_bounds__(256) void k_welford_batch(const uint32_t* Ks, int nslots, const double* K_hat_in, double* K_hat_out, double* prod,
+template <typename SrcT>
+__global__ __launch_bounds__(256) void k_welford_batch(const SrcT* Ks, int nslots, const double* K_hat_in, double* K_hat_out, double* prod,
                                                        u64 prod_stride, u64 pairs, u64 train_pairs, double first_iter, double* bsum,
                                                        uint32_t nblk, int write_prod) {
     __shared__ double part[WF_SLOTS][4];
@@ -545,9 +546,9 @@ __global__ __launch_bounds__(256) void k_welford_batch(const uint32_t* Ks, int n
     for (int q = 0; q < WF_ITEMS; ++q) {
         const u64 i = base + (u64)q * 256 + threadIdx.x;
         if (i < pairs) {
-            uint32_t xs[WF_SLOTS];
+            SrcT xs[WF_SLOTS];
 #pragma unroll
-            for (int s = 0; s < WF_SLOTS; ++s) xs[s] = s < nslots ? Ks[(u64)s * pairs + i] : 0u;  // (all loads before the dependent chain)
+            for (int s = 0; s < WF_SLOTS; ++s) xs[s] = s < nslots ? Ks[(u64)s * pairs + i] : (SrcT)0;  // (all loads before the dependent chain)
             double kh = K_hat_in[i];
 #pragma unroll
             for (int s = 0; s < WF_SLOTS; ++s) {

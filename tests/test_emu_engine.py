@@ -100,22 +100,30 @@ def test_emu_approx_modes(emu_lib, name):
         assert np.array_equal(e.get_counts(), d["counts"])
 
 
-@pytest.mark.parametrize("path", [0, 2])
-def test_emu_variance_mode_stops_anywhere(emu_lib, port, path):
+@pytest.mark.parametrize("path", [0, 2, -1])
+def test_emu_variance_mode_stops_anywhere(emu_lib, port, path, monkeypatch):
     """Variance mode runs ahead of its stop test (batches of 4 iterations, two in flight): whatever
     the chain count, max_iters and delta, the stop must land on the reference's iteration and the
     state of the dropped iterations must not leak into the result. (Sparse dataflow: the Welford
-    state is written once per batch; a stop inside a batch runs the accepted prefix again.)"""
+    state is written once per batch; a stop inside a batch runs the accepted prefix again. So it is on
+    the dense dataflow, where every iteration's tile launch stores into a triangle of its own; path -1 =
+    the dense dataflow with that switched off: zero fill and one Welford kernel per iteration.)"""
     from fastsk_amd import _native
+    if path == -1:
+        monkeypatch.setenv("FSK_VARIANCE_DENSE_SLOTS", "0")
+        path = 1
+    elif path == 0:
+        path = 1
     rng = np.random.default_rng(5)
     X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(12, 40, size=30)]
     tok, off = _native.flatten(X)
     g, m = 7, 3
     order = rng.permutation(port.num_combos(g, m)).astype(np.int32)
     lengths = set()
-    for T in (1, 2, 3) if path == 0 else (1, 2):
-        for max_iters in (-1, 1, 2, 4, 5, 6, 9) if path == 0 else (-1, 3, 6):
-            for delta in (0.025, 0.2, 0.5, 1.0, 3.0) if path == 0 else (0.2, 0.5, 1.0, 3.0):
+    full = path == 1 and os.environ.get("FSK_VARIANCE_DENSE_SLOTS") != "0"
+    for T in (1, 2, 3) if full else (1, 2):
+        for max_iters in (-1, 1, 2, 4, 5, 6, 9) if full else (-1, 3, 6):
+            for delta in (0.025, 0.2, 0.5, 1.0, 3.0) if full else (0.2, 0.5, 1.0, 3.0):
                 want, sd, _ = port.compute(tok, off, 22, 8, g, m, t=T, approx=True, delta=delta, max_iters=max_iters, order=order)
                 e = _native.Engine(g, m, t=T, approx=True, delta=delta, max_iters=max_iters, path=path, lib=emu_lib)
                 e.set_combo_order(order)
@@ -124,7 +132,7 @@ def test_emu_variance_mode_stops_anywhere(emu_lib, port, path):
                 assert np.array_equal(e.get_triangle(), want), (T, max_iters, delta)
                 lengths.add(len(sd))
                 e.close()
-    assert len(lengths) >= (6 if path == 0 else 4)  # stops landed at many different places inside the batches
+    assert len(lengths) >= (6 if full else 4)  # stops landed at many different places inside the batches
 
 
 def test_emu_reset_then_storing_launch(emu_lib, port, monkeypatch):

@@ -691,12 +691,16 @@ def test_sequential_sum_random_inputs(native):
     e.close()
 
 
-@pytest.mark.parametrize("path", [0, 2])
-def test_variance_mode_stops_anywhere(native, port, path):
+@pytest.mark.parametrize("path", [0, 2, -1])
+def test_variance_mode_stops_anywhere(native, port, path, monkeypatch):
     """Variance mode runs ahead of its stop test (batches of 4 iterations, two in flight, second
     stream): whatever the chain count, max_iters and delta, stdevs and the kernel are
-    the oracle's, bit for bit — on the dense dataflow (the Welford state of every iteration kept) and
-    on the sparse one (the state written once per batch; a stop inside a batch runs its prefix again)."""
+    the oracle's, bit for bit — on both dataflows the counts of a batch's iterations sit in triangles of
+    their own and the Welford state is written once per batch (a stop inside a batch runs its prefix again);
+    path -1: the dense dataflow with its per-iteration triangles switched off."""
+    if path == -1:
+        monkeypatch.setenv("FSK_VARIANCE_DENSE_SLOTS", "0")
+        path = 1
     rng = np.random.default_rng(5)
     X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(12, 40, size=30)]
     tok, off = native.flatten(X)
