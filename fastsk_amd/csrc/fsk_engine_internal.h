@@ -1,0 +1,249 @@
+// fsk_engine_internal.h — the engine object behind the opaque `fsk_engine` handle of include/fastsk_amd.h,
+// shared by the translation units of libfastsk_amd.so (fsk_engine.hip: one device; fsk_multi.hip: a group
+// of engines on several devices of one process). Not installed, not part of the ABI.
+#pragma once
+#include "fsk_common.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <array>
+#include <atomic>
+#include <thread>
+#include <vector>
+
+#include <cstdint>
+#include <climits>
+
+#include "../../include/fastsk_amd.h"
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+
+struct fsk_group;  // fsk_multi.hip: the engines of fsk_create_multi (this one leads them), their worker threads and collective
+
+namespace fsk_detail {
+
+#define FSK_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (call);                                                                \
+        if (_e != hipSuccess) return e->fail(FSK_EDEVICE, "%s failed: %s", #call, hipGetErrorString(_e)); \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t r = hipMalloc((void**)&p, n * sizeof(T));
+        if (r == hipSuccess) cap = n;
+        return r;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// Every entry point runs on the engine's device and puts the calling thread's current device back
+// afterwards: the engine shares one HIP runtime with torch, whose current device must not move
+// under it (e.g. when an Engine on another GPU is garbage-collected).
+struct DeviceScope {
+    int prev = -1, dev;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev);
+    }
+    ~DeviceScope() {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+#define FSK_ON_DEVICE(e)                                                                      \
+    DeviceScope fsk_on_device_((e)->cfg.device);                                             \
+    if (fsk_on_device_.err != hipSuccess)                                                    \
+        return (e)->fail(FSK_EDEVICE, "hipSetDevice(%d) failed: %s", (e)->cfg.device, hipGetErrorString(fsk_on_device_.err))
+
+}  // namespace fsk_detail
+
+using fsk_detail::DevBuf;
+
+struct fsk_engine {
+    fsk_config cfg{};
+    std::string err;
+    int k = 0;
+    int64_t ncomb = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_order = nullptr;       // fsk_stream_wait_engine / fsk_engine_wait_stream
+    hipStream_t chain_stream = nullptr;  // variance mode: the sequential sums of a batch, under the next batches' kernels
+    // fsk_reset_counts does not fill K when the next accumulate can STORE its sums instead of adding
+    // them (dense dataflow, one workgroup per tile): rows [lazy_lo, lazy_hi) are zero by contract
+    // but not in memory until a tile launch stores them or materialise_zero() fills them.
+    int64_t lazy_lo = -1, lazy_hi = -1;
+    int variance_dense_slots = 1;  // FSK_VARIANCE_DENSE_SLOTS=0: zero fill + k_welford per iteration instead (testing)
+    bool store_next = false;  // variance mode, dense dataflow: the next (one-combo, whole-triangle) tile launch stores into the K it is given
+    uint32_t* h_stage = nullptr;         // pinned: the packed sequences on their way to the device (fsk_load_sequences)
+    size_t h_stage_cap = 0;
+    bool stage_in_flight = false;
+    double* h_prod = nullptr;            // pinned: one sequential sum per iteration in flight (kept across calls)
+    size_t h_prod_cap = 0;
+
+    // sequences
+    bool loaded = false, finalized = false, result_f64 = false;
+    int64_t N = 0, n_train = 0, n_test = 0, nfeat = 0, pairs = 0;
+    uint32_t sigma = 0, Lmax = 0, Lmin = 0, maxW = 0, Vq = 0, n_panels = 0;
+    int bits = 0;
+    u64 V = 0;
+    int path = 0;
+    DevBuf<uint32_t> d_words, d_wstart, d_len, d_fstart, d_featseq;
+    std::vector<uint32_t> h_len, h_fstart;
+    bool featseq_ready = false;
+    int force_splits = 0;      // FSK_TILE_SPLITS=n: combo splits per tile (tuning)
+    uint32_t force_chunk = 0;  // FSK_DENSE_CHUNK=n: cap the count kernel's staging chunk (testing)
+
+    // combos
+    std::vector<uint8_t> all_pos;  // [ncomb][k]
+    DevBuf<uint8_t> d_pos, d_allpos;  // positions of the batch at hand; of all combos (sparse dataflow, small batches)
+    bool allpos_ready = false;
+    std::vector<int32_t> order;
+    bool order_set = false;
+    uint64_t seed = 0;
+    std::vector<double> stdevs;
+
+    // counts / results
+    u64* d_K = nullptr;
+    bool K_owned = false;
+    int64_t bound_cells = 0;
+    DevBuf<u64> K_store;
+    DevBuf<double> d_Kf64, d_Khat, d_prod, d_diag, d_stage, d_bsum;
+    DevBuf<unsigned char> d_seqblk;
+    DevBuf<u64> d_stage_u64, d_Kslots;
+    DevBuf<int64_t> d_cell_idx;
+
+    // dense scratch
+    DevBuf<uint32_t> d_C4, d_C4H, d_rowmask, d_flag;  // lo / hi nibble planes, per-row hi masks
+    DevBuf<uint32_t> d_keybits;   // key compaction: per-combo bitmap of the keys that occur
+    DevBuf<uint16_t> d_lut, d_vc; //                  rank table and key count per combo
+    bool compact = false;         // decided at load: the alphabet has a rare symbol
+    std::vector<uint16_t> h_vc_cache;
+    double vc_sum = 0, vc_n = 0;
+    int force_compact = -1;       // FSK_COMPACT=0/1 overrides (testing)
+    DevBuf<uint32_t> d_tiletab;
+    uint32_t tab_t0 = 0, tab_t1 = 0, tab_n = 0;   // tile-row range the table on the device covers
+    std::vector<int32_t> prep_combos;              // combos whose count panels are resident
+    bool prep_valid = false, prep_overflow = false;
+    // sparse scratch
+    DevBuf<unsigned char> d_keys[2];      // packed sort records (u32 or u64), double-buffered
+    DevBuf<uint32_t> d_blockhist, d_totals, d_tile_ent, d_ebase, d_Pk, d_Tk, d_owner_r0, d_ucount, d_uchunk, d_utot, d_list_off, d_ulist, d_part_base;
+    DevBuf<u64> d_tile_stat;
+    DevBuf<uint32_t> d_segc;              // chunk records of the segment scan (batches of many tiles)
+    DevBuf<int> d_tile_lrh, d_tile_rs, d_tile_lth, d_tile_ts;
+    DevBuf<uint2> d_E;                    // entries: {sequence, multiplicity}
+    DevBuf<u64> d_sxstat, d_U;
+    std::vector<uint32_t> h_owner_r0;     // owner bands of K: rows [r0[o], r0[o+1])
+    uint32_t n_owners = 0, sx_rounds = 1, sx_cap = 0;
+    int sx_pb = 16, sx_sb = 1, sx_keybits = 1, sx_own_shift = 13;
+    bool sx_lists = false, owner_ready = false;
+    // profile mode, dense dataflow: U of the last single-chunk combo list is kept, so that repeating
+    // the same pass (bench steps, row bands of later passes) does not re-read every count panel
+    DevBuf<u64> d_U2;
+    std::vector<int32_t> u_combos;
+    bool u_known = false, u_pending = false;
+    u64 u_value = 0, u_extra = 0;
+    int force_global_pairs = 0;  // FSK_SPARSE_GLOBAL=1: per-pair global atomics (testing)
+    u64 sx_max_words = (u64)1 << 31;  // update words per batch beyond which the pairs go to K with atomics (FSK_LIST_MAX_WORDS: testing)
+    // Batches are enqueued without waiting for their word counts once one batch of these sequences has
+    // been sized: the stream buffer keeps headroom over the largest count seen, the kernels leave a
+    // batch that does not fit alone, and the host redoes such a batch (sized exactly) when it reads the
+    // counts back — at the end of an exact accumulate, at the hand-over of a variance-mode batch.
+    unsigned char* h_sx_pos = nullptr;   // pinned: positions of the batches in flight ([SX_DEFER slots][exact call])
+    size_t h_sx_pos_cap = 0;
+    u64* h_sx_stat = nullptr;            // pinned: {pairs, words} of the batches in flight (same layout)
+    size_t h_sx_stat_cap = 0;
+    u64 sx_words_seen = 0;               // largest word count of a batch since the sequences were loaded
+    struct SxDefer { bool active = false; u64 cap = 0; } sx_defer[8];
+    int force_seg_chunks = 0;            // FSK_SEG_SCAN_CHUNKED=1: the three-launch segment scan whatever the tile count (testing)
+    int sx_sync = 0;                     // FSK_SPARSE_SYNC=1: size every batch exactly (testing); also while redoing a batch
+    u64 sx_guard_cap = 0;                // FSK_SPARSE_GUARD_CAP=n: pretend the stream buffer holds n words (testing the redo)
+    u64 sx_redone = 0;                   // batches redone because they did not fit
+    int tile_dma = 1;            // FSK_TILE_DMA=0: register-staged tile kernel instead of the direct-to-LDS one (testing)
+    int compact_dma = 0;         // FSK_COMPACT_DMA=1: direct-to-LDS k_dense_tile_dma_compact for key-compacted panels (measured slower on
+                                 // config 3: its flagged rows take the generic remainder, not k_dense_tile_compact's side-aware one)
+
+    fsk_stats st{};
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+    fsk::SeqView view() const {
+        return fsk::SeqView{d_words.p, d_wstart.p, d_len.p, (uint32_t)N, bits};
+    }
+    void tic() {
+        if (cfg.profile) (void)hipEventRecord(ev0, stream);
+    }
+    void toc(double* acc) {
+        if (!cfg.profile) return;
+        (void)hipEventRecord(ev1, stream);
+        (void)hipEventSynchronize(ev1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ev0, ev1);
+        *acc += ms;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// What the translation units of the library call in each other (all on the engine's device, which
+// the C-ABI entry point has made current).
+namespace fsk_detail {
+
+constexpr size_t LDS_BUDGET = 150 * 1024;       // of 160 KiB per CU
+constexpr u64 DENSE_MAX_KEYS = 16384;           // count panels: alphabet^k <= this (DNA up to k = 7)
+constexpr size_t SPARSE_MAX_RECORDS = 1u << 25; // records per sort batch
+constexpr u64 SX_MAX_LIST_WORDS = (u64)1 << 31;  // update words of one sparse batch beyond which its pairs go to K with atomics
+constexpr int FSK_RETRY_UNGROUPED = 1;  // internal: a per-slot sparse batch has to be redone one combo at a time
+
+// fsk_engine.hip
+int64_t n_choose_k(int n, int k);
+int materialise_zero(fsk_engine* e);
+bool lazy_zero_possible(const fsk_engine* e);
+int do_accumulate(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0 = 0, int64_t row1 = -1, u64 slot_stride = 0,
+                  int defer = -1);
+int make_diag(fsk_engine* e);
+void default_order(fsk_engine* e);
+
+// fsk_engine_dense.hip
+struct DensePlan { uint32_t CH = 0, Vcq = 0; size_t lds = 0; };
+DensePlan dense_plan(uint32_t maxW, int g, uint32_t Vq, size_t extra = 0);
+int fetch_pending_u(fsk_engine* e);
+int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0, int64_t row1);
+
+// fsk_engine_sparse.hip
+void plan_owner_bands(fsk_engine* e);
+bool sx_harvest(fsk_engine* e, int slot);
+int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0, int64_t row1, u64 slot_stride = 0,
+                      int defer = -1);
+
+// fsk_engine_variance.hip
+int run_variance_mode(fsk_engine* e, int T, int chain_first = 0, int chain_step = 1);
+
+}  // namespace fsk_detail

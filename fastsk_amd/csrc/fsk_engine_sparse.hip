@@ -1,0 +1,373 @@
+// fsk_engine_sparse.hip — host side of the SPARSE dataflow (configs 1, 4; the fallback for everything): the
+// reference's own pipeline per combo — gather, cntsrtna, permute, countAndUpdateTri (fastsk_kernel.cpp:224-241,
+// shared.cpp:156-191, 268-333) — as batched streams: extract -> LSD radix sort -> segments -> update streams ->
+// owner bands.
+#include "fsk_engine_internal.h"
+#include "fsk_kernels_sparse.h"
+
+using namespace fsk_detail;
+
+namespace fsk_detail {
+
+// ---------------------------------------------------------------------------------------------
+// sparse dataflow: owner bands of K. The update stream of a band is summed in LDS by one workgroup,
+// so a band is a range of whole rows with about 8192 cells (the LDS budget of k_sx_consume bounds
+// it: SX_CAP cells per round, at most SX_MAX_ROUNDS rounds over the band's stream).
+constexpr uint32_t SX_CAP = 16384;        // u32 cells of K one k_sx_consume workgroup holds in LDS (64 KiB)
+constexpr uint32_t SX_MAX_ROUNDS = 16;
+
+void plan_owner_bands(fsk_engine* e) {
+    // band o = the rows whose first cell index lies in [o << t, (o + 1) << t): a row's band is a shift
+    // of its triangular index, bands hold about 2^t cells (2^t + N at most: the last row of a band is
+    // kept whole) and can be empty when a single row is longer than 2^t cells.
+    const u64 N = (u64)e->N, cells = N * (N + 1) / 2;
+    int t = 13;
+    while ((((cells + (((u64)1) << t) - 1) >> t)) > (u64)fsk::SX_MAX_OWNERS) ++t;
+    e->sx_own_shift = t;
+    e->n_owners = (uint32_t)((cells + (((u64)1) << t) - 1) >> t);
+    e->h_owner_r0.assign((size_t)e->n_owners + 1, (uint32_t)N);
+    u64 largest = 0;
+    {
+        uint32_t o = 0;  // r0[o] = first row whose triangular index reaches o << t
+        for (u64 i = 0; i < N && o <= e->n_owners; ++i)
+            while (o <= e->n_owners && (i * (i + 1) / 2) >= ((u64)o << t)) e->h_owner_r0[o++] = (uint32_t)i;
+        for (uint32_t q = 0; q < e->n_owners; ++q) {
+            const u64 a = e->h_owner_r0[q], b = e->h_owner_r0[q + 1];
+            largest = std::max(largest, b * (b + 1) / 2 - a * (a + 1) / 2);
+        }
+    }
+    int L = 1;
+    while (((u64)1 << L) < largest) ++L;
+    e->sx_pb = 32 - L;
+    e->sx_rounds = (uint32_t)std::max<u64>(1, (largest + SX_CAP - 1) / SX_CAP);
+    e->sx_cap = (uint32_t)std::max<u64>(1, std::min<u64>(SX_CAP, largest));
+    e->sx_lists = e->n_owners <= (uint32_t)fsk::SX_MAX_OWNERS && e->sx_rounds <= SX_MAX_ROUNDS && e->sx_pb >= 8;
+    e->owner_ready = false;
+}
+
+// `pos_pin` / `stat_pin`: pinned staging of this batch (positions in, {pairs, words} out), untouched by
+// anyone else until the batch's counts have been read. `guard_cap` == 0: the call waits for the
+// counts and sizes the streams exactly; else it only enqueues, for streams of at most guard_cap words.
+template <typename RecT>
+int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t row0, int64_t row1, u64 slot_stride,
+                 unsigned char* pos_pin, u64* stat_pin, u64 guard_cap) {
+    const uint32_t nfeat = (uint32_t)e->nfeat;
+    const size_t nrec = (size_t)nb * nfeat;
+    if (nrec == 0) return FSK_OK;
+    // Only the k-mer bits are sorted: the records of a slot are generated in sequence order and every
+    // LSD pass is stable, so equal k-mers end up contiguous with their sequence ids ascending.
+    int keybits = 1;
+    while (keybits < 62 && ((u64)1 << keybits) < (u64)e->V) ++keybits;
+    const int sb = e->sx_sb;
+    const int passes = (keybits + 7) / 8;
+    const int nbits = (keybits + passes - 1) / passes;  // the k-mer bits split evenly: 19 bits sort as 7 + 6 + 6, not 8 + 8 + 3
+    const uint32_t dmask = (1u << nbits) - 1u;
+    const uint32_t tps = (nfeat + fsk::SX_TILE - 1) / fsk::SX_TILE;   // sort tiles per slot
+    const uint32_t tpg = (nfeat + fsk::SG_TILE - 1) / fsk::SG_TILE;   // segment tiles per slot
+    const uint32_t ntiles = tpg * (uint32_t)nb;
+    const bool lists = e->sx_lists && !e->force_global_pairs;
+    const uint32_t O = e->n_owners;
+    for (int b = 0; b < 2; ++b) FSK_HIP(e->d_keys[b].reserve(nrec * sizeof(RecT)));
+    FSK_HIP(e->d_blockhist.reserve((size_t)256 * tps * nb));
+    FSK_HIP(e->d_totals.reserve((size_t)256 * nb));
+    FSK_HIP(e->d_tile_ent.reserve(ntiles));
+    FSK_HIP(e->d_tile_lrh.reserve(ntiles));
+    FSK_HIP(e->d_tile_rs.reserve(ntiles));
+    FSK_HIP(e->d_ebase.reserve((size_t)ntiles + 1));
+    FSK_HIP(e->d_E.reserve(nrec));
+    FSK_HIP(e->d_Pk.reserve(nrec));
+    // skip_test_block: test rows pair only with the train entries of their runs (and themselves)
+    const uint32_t skip_from = e->cfg.skip_test_block && e->n_test > 0 ? (uint32_t)e->n_train : 0xffffffffu;
+    const bool skipping = skip_from != 0xffffffffu;
+    if (skipping) {
+        FSK_HIP(e->d_Tk.reserve(nrec));
+        FSK_HIP(e->d_tile_lth.reserve(ntiles));
+        FSK_HIP(e->d_tile_ts.reserve(ntiles));
+    }
+    FSK_HIP(e->d_sxstat.reserve(3));
+    FSK_HIP(e->d_tile_stat.reserve((size_t)2 * ntiles));
+    FSK_HIP(e->d_pos.reserve((size_t)nb * e->k));
+    if (!e->owner_ready) {
+        FSK_HIP(e->d_owner_r0.reserve(e->h_owner_r0.size()));
+        FSK_HIP(hipMemcpyAsync(e->d_owner_r0.p, e->h_owner_r0.data(), e->h_owner_r0.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        e->owner_ready = true;  // (h_owner_r0 lives as long as the engine: no wait needed)
+    }
+    const uint32_t nchunks = (ntiles + fsk::UC_CHUNK - 1) / fsk::UC_CHUNK;
+    if (lists) {
+        FSK_HIP(e->d_ucount.reserve((size_t)O * ntiles));
+        FSK_HIP(e->d_uchunk.reserve((size_t)O * nchunks));
+        FSK_HIP(e->d_utot.reserve(O));
+        FSK_HIP(e->d_list_off.reserve((size_t)O + 1));
+        FSK_HIP(e->d_part_base.reserve((size_t)O + 1));
+    }
+    fsk::SxIds ids{};
+    const bool by_id = nb <= 16;  // (variance mode: a handful of combos per batch) positions from the resident table
+    if (by_id) {
+        if (!e->allpos_ready) {
+            FSK_HIP(e->d_allpos.reserve(e->all_pos.size()));
+            FSK_HIP(hipMemcpy(e->d_allpos.p, e->all_pos.data(), e->all_pos.size(), hipMemcpyHostToDevice));
+            e->allpos_ready = true;
+        }
+        for (int s = 0; s < nb; ++s) ids.id[s] = combos[s];
+    } else {
+        for (int s = 0; s < nb; ++s)
+            memcpy(pos_pin + (size_t)s * e->k, &e->all_pos[(size_t)combos[s] * e->k], e->k);
+        FSK_HIP(hipMemcpyAsync(e->d_pos.p, pos_pin, (size_t)nb * e->k, hipMemcpyHostToDevice, e->stream));
+        FSK_HIP(hipMemsetAsync(e->d_sxstat.p, 0, 3 * sizeof(u64), e->stream));
+    }
+
+    RecT* rec[2] = {(RecT*)e->d_keys[0].p, (RecT*)e->d_keys[1].p};
+
+    e->tic();
+    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_extract<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, e->view(), e->d_featseq.p,
+               e->d_fstart.p, nfeat, tps, e->k, e->sigma, sb, by_id ? (const uint8_t*)e->d_allpos.p : (const uint8_t*)e->d_pos.p, rec[0],
+               e->d_blockhist.p, dmask, ids, by_id ? e->d_sxstat.p : (u64*)nullptr);
+    e->toc(&e->st.ms_extract);
+    e->st.launches += 1;
+
+    e->tic();
+    int cur = 0;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = sb + nbits * p;
+        if (p > 0)  // (the extraction counted the first pass's digits)
+            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_hist<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tps, shift, dmask,
+                       e->d_blockhist.p);
+        FSK_LAUNCH(fsk::k_sx_scan_slot, dim3(nb), dim3(1024), 0, e->stream, e->d_blockhist.p, tps, e->d_totals.p);
+        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_scatter<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, rec[cur], rec[cur ^ 1], nfeat,
+                   tps, shift, nbits, e->d_blockhist.p, e->d_totals.p);
+        cur ^= 1;
+        e->st.launches += 3;
+    }
+    e->toc(&e->st.ms_sort);
+    e->st.sort_records += nrec;
+    e->st.sort_passes = passes;
+
+    e->tic();
+    const uint32_t maxprod = (1u << e->sx_pb) - 1u;
+    const uint32_t cmax = maxprod / std::max<uint32_t>(1u, e->maxW);  // multiplicities up to here: one word per pair
+    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_seg_count<RecT>), dim3(tpg, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tpg, sb,
+               e->d_tile_ent.p, e->d_tile_lrh.p, skip_from, skipping ? e->d_tile_lth.p : (int*)nullptr);
+    {
+        const int* lth = skipping ? (const int*)e->d_tile_lth.p : (const int*)nullptr;
+        int* ts = skipping ? e->d_tile_ts.p : (int*)nullptr;
+        if (ntiles <= 4096u && !e->force_seg_chunks) {  // one workgroup walks the tile records
+            FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(1), dim3(1024), 0, e->stream, (const uint32_t*)e->d_tile_ent.p, (const int*)e->d_tile_lrh.p, ntiles,
+                       e->d_ebase.p, e->d_tile_rs.p, lth, ts, (const uint32_t*)nullptr, (const int*)nullptr, (const int*)nullptr,
+                       (uint32_t*)nullptr, (int*)nullptr, (int*)nullptr);
+        } else {  // chunk totals, the same scan over the chunk records, the chunks with their carries
+            const uint32_t nch = (ntiles + 1023u) / 1024u;
+            FSK_HIP(e->d_segc.reserve((size_t)6 * (nch + 1)));
+            uint32_t* c_tot = e->d_segc.p;
+            int* c_lrh = reinterpret_cast<int*>(c_tot + (nch + 1));
+            int* c_lth = c_lrh + (nch + 1);
+            uint32_t* c_ex = reinterpret_cast<uint32_t*>(c_lth + (nch + 1));
+            int* c_h = reinterpret_cast<int*>(c_ex + (nch + 1));
+            int* c_t = c_h + (nch + 1);
+            FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(nch), dim3(1024), 0, e->stream, (const uint32_t*)e->d_tile_ent.p, (const int*)e->d_tile_lrh.p, ntiles,
+                       (uint32_t*)nullptr, (int*)nullptr, lth, (int*)nullptr, (const uint32_t*)nullptr, (const int*)nullptr, (const int*)nullptr,
+                       c_tot, c_lrh, c_lth);
+            FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(1), dim3(1024), 0, e->stream, (const uint32_t*)c_tot, (const int*)c_lrh, nch, c_ex, c_h,
+                       skipping ? (const int*)c_lth : (const int*)nullptr, skipping ? c_t : (int*)nullptr, (const uint32_t*)nullptr,
+                       (const int*)nullptr, (const int*)nullptr, (uint32_t*)nullptr, (int*)nullptr, (int*)nullptr);
+            FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(nch), dim3(1024), 0, e->stream, (const uint32_t*)e->d_tile_ent.p, (const int*)e->d_tile_lrh.p, ntiles,
+                       e->d_ebase.p, e->d_tile_rs.p, lth, ts, (const uint32_t*)c_ex, (const int*)c_h, (const int*)c_t, (uint32_t*)nullptr,
+                       (int*)nullptr, (int*)nullptr);
+            e->st.launches += 2;
+        }
+    }
+    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_seg_write<RecT>), dim3(tpg, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tpg, sb,
+               e->d_ebase.p, e->d_tile_rs.p, e->d_E.p, e->d_Pk.p, e->sx_own_shift, O,
+               lists ? e->d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->d_tile_stat.p,
+               skip_from, skipping ? (const int*)e->d_tile_ts.p : (const int*)nullptr, skipping ? e->d_Tk.p : (uint32_t*)nullptr);
+    stat_pin[0] = stat_pin[1] = 0;
+    e->st.launches += 3;
+    u64 words = 0;
+    if (lists) {  // where every (tile, owner) share of the update streams starts (+ the batch's pair and word totals)
+        FSK_LAUNCH(fsk::k_sx_ucol_sum, dim3(nchunks), dim3(256), 0, e->stream, (const uint32_t*)e->d_ucount.p, ntiles, O, e->d_uchunk.p,
+                   (const u64*)e->d_tile_stat.p, e->d_sxstat.p, stat_pin);
+        FSK_LAUNCH(fsk::k_sx_ucol_scan, dim3(O), dim3(256), 0, e->stream, e->d_uchunk.p, nchunks, O, e->d_utot.p);
+        FSK_LAUNCH(fsk::k_sx_ucol_apply, dim3(nchunks), dim3(256), 0, e->stream, e->d_ucount.p, ntiles, O, (const uint32_t*)e->d_uchunk.p,
+                   (const uint32_t*)e->d_utot.p, e->d_list_off.p);
+        e->st.launches += 3;
+    } else {
+        FSK_LAUNCH(fsk::k_sx_stat_sum, dim3(32), dim3(256), 0, e->stream, (const u64*)e->d_tile_stat.p, ntiles, e->d_sxstat.p, stat_pin);
+        e->st.launches += 1;
+    }
+    const bool guarded = guard_cap != 0;
+    u64 cap_words = ~(u64)0;
+    if (guarded) {
+        words = lists ? std::max<u64>(1, std::min(e->sx_words_seen, guard_cap)) : 0;  // (sizes the parts; the kernels read the true offsets)
+        cap_words = guard_cap;
+    } else {
+        FSK_HIP(hipStreamSynchronize(e->stream));  // the update streams are sized exactly
+        e->u_extra += stat_pin[0];
+        words = stat_pin[1];
+        e->sx_words_seen = std::max(e->sx_words_seen, words);
+    }
+    e->toc(&e->st.ms_segment);
+
+    e->tic();
+    const bool use_lists = lists && words < e->sx_max_words;
+    if (slot_stride != 0 && !use_lists) return FSK_RETRY_UNGROUPED;  // (nothing of this batch has touched K yet)
+    if (use_lists) {
+        if (words > 0 || slot_stride != 0) {
+            if (!guarded && (size_t)words > e->d_ulist.cap)  // (grown with headroom: the batches of a pass differ by a few percent)
+                FSK_HIP(e->d_ulist.reserve((size_t)std::max<u64>(1, words + words / 4)));
+            // (function pointers: a template-id with a comma cannot pass through the launch macro)
+            auto k_emit = skipping ? fsk::k_sx_emit<false, true> : fsk::k_sx_emit<false, false>;
+            FSK_LAUNCH(k_emit, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
+                       (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)e->d_list_off.p,
+                       (const uint32_t*)e->d_ucount.p, e->d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
+                       slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr, (const u64*)e->d_sxstat.p, cap_words);
+            const size_t lds = (size_t)e->sx_cap * sizeof(uint32_t);
+#ifndef FSK_EMU
+            FSK_HIP(hipFuncSetAttribute((const void*)fsk::k_sx_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#endif
+            // parts of about `target` words: ~1024 workgroups, and never so short that the flush of a
+            // part (up to sx_cap cells) outweighs the words it summed
+            const uint32_t target = (uint32_t)std::max<u64>((u64)4 * e->sx_cap, (words + 1023) / 1024);
+            const uint32_t max_parts = O + (uint32_t)(((guarded ? guard_cap : words) + target - 1) / target);
+            if (slot_stride != 0) {  // one triangle per slot: a slot's words of a stream are one contiguous piece
+                FSK_LAUNCH(fsk::k_sx_consume, dim3(O, e->sx_rounds, nb), dim3(fsk::CS_THREADS), lds, e->stream, (const uint32_t*)e->d_ulist.p,
+                           (const uint32_t*)e->d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)nullptr, O, target,
+                           e->sx_cap, e->sx_pb, K, (const uint32_t*)e->d_ucount.p, tpg, slot_stride, (const u64*)e->d_sxstat.p, cap_words);
+            } else {
+                FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, e->stream, (const uint32_t*)e->d_list_off.p, O, target, e->d_part_base.p,
+                           (const u64*)e->d_sxstat.p, cap_words);
+                FSK_LAUNCH(fsk::k_sx_consume, dim3(max_parts, e->sx_rounds), dim3(fsk::CS_THREADS), lds, e->stream, (const uint32_t*)e->d_ulist.p,
+                           (const uint32_t*)e->d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)e->d_part_base.p, O, target,
+                           e->sx_cap, e->sx_pb, K, (const uint32_t*)nullptr, tpg, (u64)0, (const u64*)e->d_sxstat.p, cap_words);
+                e->st.launches += 1;
+            }
+            e->st.launches += 2;
+        }
+    } else {
+        auto k_emit = skipping ? fsk::k_sx_emit<true, true> : fsk::k_sx_emit<true, false>;
+        FSK_LAUNCH(k_emit, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
+                   (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)nullptr,
+                   (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
+                   slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr, (const u64*)nullptr, ~(u64)0);
+        e->st.launches += 1;
+    }
+    e->toc(&e->st.ms_pairs);
+    FSK_HIP(hipGetLastError());
+    return FSK_OK;
+}
+
+int ensure_featseq(fsk_engine* e) {
+    if (e->featseq_ready) return FSK_OK;
+    std::vector<uint32_t> fs((size_t)e->nfeat);
+    for (int64_t i = 0; i < e->N; ++i)
+        for (uint32_t f = e->h_fstart[i]; f < e->h_fstart[i + 1]; ++f) fs[f] = (uint32_t)i;
+    FSK_HIP(e->d_featseq.reserve((size_t)e->nfeat));
+    FSK_HIP(hipMemcpy(e->d_featseq.p, fs.data(), fs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    e->featseq_ready = true;
+    return FSK_OK;
+}
+
+constexpr int SX_DEFER = 8;          // variance mode: batches whose counts are read at their hand-over
+constexpr int SX_DEFER_COMBOS = 16;  //                combos of such a batch at most
+
+int sx_pinned(fsk_engine* e, size_t pos_bytes, size_t stat_words) {
+    if (pos_bytes > e->h_sx_pos_cap) {
+        if (e->h_sx_pos) (void)hipHostFree(e->h_sx_pos);
+        e->h_sx_pos = nullptr; e->h_sx_pos_cap = 0;
+        FSK_HIP(hipHostMalloc((void**)&e->h_sx_pos, pos_bytes + pos_bytes / 2));
+        e->h_sx_pos_cap = pos_bytes + pos_bytes / 2;
+    }
+    if (stat_words > e->h_sx_stat_cap) {
+        if (e->h_sx_stat) (void)hipHostFree(e->h_sx_stat);
+        e->h_sx_stat = nullptr; e->h_sx_stat_cap = 0;
+        FSK_HIP(hipHostMalloc((void**)&e->h_sx_stat, (stat_words + stat_words / 2) * sizeof(u64)));
+        e->h_sx_stat_cap = stat_words + stat_words / 2;
+    }
+    return FSK_OK;
+}
+
+// how many words a batch may hold when it is enqueued before its count is known (0: size it exactly)
+u64 sx_guard_for(fsk_engine* e) {
+    if (e->sx_sync || e->cfg.profile) return 0;
+    if (!e->sx_lists || e->force_global_pairs) return ~(u64)0;       // no streams: nothing to size
+    if (e->sx_words_seen == 0) return 0;                                // (the first batch of these sequences)
+    if (e->sx_guard_cap) return std::min<u64>(e->sx_guard_cap, (u64)e->d_ulist.cap);
+    const u64 want = e->sx_words_seen + e->sx_words_seen / 2;
+    if (want >= e->sx_max_words) return 0;
+    if ((u64)e->d_ulist.cap < want && e->d_ulist.reserve((size_t)want) != hipSuccess) return 0;
+    return std::min<u64>((u64)e->d_ulist.cap, e->sx_max_words - 1);
+}
+
+// the counts of deferred batch `slot` (its kernels have finished): false when it has to be redone
+bool sx_harvest(fsk_engine* e, int slot) {
+    if (slot < 0 || !e->sx_defer[slot].active) return true;
+    e->sx_defer[slot].active = false;
+    const u64 pairs = e->h_sx_stat[2 * slot], words = e->h_sx_stat[2 * slot + 1];
+    e->sx_words_seen = std::max(e->sx_words_seen, words);
+    if (words > e->sx_defer[slot].cap) { e->sx_redone += 1; return false; }
+    e->u_extra += pairs;
+    return true;
+}
+
+// slot_stride != 0 (variance mode): combo q of the list goes to its own u32 triangle (uint32_t*)K + q * slot_stride,
+// written whole; returns FSK_RETRY_UNGROUPED when that form cannot be used for this batch.
+// defer >= 0 (variance mode): the call returns with the batch enqueued; the caller passes `defer` to
+// sx_harvest() once the batch has finished and redoes the batch (with e->sx_sync set) if that says so.
+int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0, int64_t row1, u64 slot_stride,
+                      int defer) {
+    { int rcz = materialise_zero(e); if (rcz) return rcz; }
+    int rc = ensure_featseq(e);
+    if (rc) return rc;
+    // batch so that the record count stays below the cap ...
+    size_t per = SPARSE_MAX_RECORDS / (size_t)std::max<int64_t>(1, e->nfeat);
+    int B = (int)std::max<size_t>(1, std::min<size_t>(per, (size_t)n));
+    // ... and the owner bands can sum a batch in u32 LDS cells: per cell and combo <= maxW^2
+    B = (int)std::max<u64>(1, std::min<u64>((u64)B, 0xffffffffull / std::max<u64>(1, (u64)e->maxW * e->maxW)));
+    B = std::min(B, 65535);  // grid.y
+    const int recbits = e->sx_keybits + e->sx_sb;  // (<= 62 + 31: a 128-bit record always holds it)
+    const int nbatches = (n + B - 1) / B;
+    if (defer >= 0 && (defer >= SX_DEFER || nbatches != 1 || n > SX_DEFER_COMBOS)) defer = -1;
+    const size_t pos_head = (size_t)SX_DEFER * SX_DEFER_COMBOS * e->k, stat_head = (size_t)2 * SX_DEFER;
+    rc = sx_pinned(e, pos_head + (size_t)n * e->k, stat_head + (size_t)2 * nbatches);
+    if (rc) return rc;
+    auto one = [&](int s, int nb, unsigned char* pos_pin, u64* stat_pin, u64 guard) {
+        // (slot triangles are u32 arrays, slot_stride cells apart)
+        u64* Kb = slot_stride ? reinterpret_cast<u64*>(reinterpret_cast<uint32_t*>(K) + (u64)s * slot_stride) : K;
+        return recbits <= 32   ? sparse_batch<uint32_t>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard)
+               : recbits <= 64 ? sparse_batch<u64>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard)
+                               : sparse_batch<u128>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard);
+    };
+    if (defer >= 0) {
+        const u64 guard = sx_guard_for(e);
+        e->sx_defer[defer].active = guard != 0;
+        e->sx_defer[defer].cap = guard;
+        rc = one(0, n, e->h_sx_pos + (size_t)defer * SX_DEFER_COMBOS * e->k, e->h_sx_stat + 2 * defer, guard);
+        if (rc) e->sx_defer[defer].active = false;
+        return rc;
+    }
+    std::vector<u64> caps((size_t)nbatches, 0);  // per batch: the guard it was enqueued under (0: sized exactly)
+    bool waiting = false;
+    for (int s = 0, q = 0; s < n; s += B, ++q) {
+        const int nb = std::min(B, n - s);
+        caps[q] = sx_guard_for(e);
+        waiting |= caps[q] != 0;
+        rc = one(s, nb, e->h_sx_pos + pos_head + (size_t)s * e->k, e->h_sx_stat + stat_head + 2 * q, caps[q]);
+        if (rc) return rc;
+    }
+    if (!waiting) return FSK_OK;
+    FSK_HIP(hipStreamSynchronize(e->stream));
+    for (int s = 0, q = 0; s < n; s += B, ++q) {
+        if (!caps[q]) continue;
+        const u64 pairs = e->h_sx_stat[stat_head + 2 * q], words = e->h_sx_stat[stat_head + 2 * q + 1];
+        e->sx_words_seen = std::max(e->sx_words_seen, words);
+        if (words <= caps[q]) { e->u_extra += pairs; continue; }
+        // the batch did not fit and has left K alone: once more, sized exactly
+        e->sx_redone += 1;
+        const int was = e->sx_sync;
+        e->sx_sync = 1;
+        rc = one(s, std::min(B, n - s), e->h_sx_pos + pos_head + (size_t)s * e->k, e->h_sx_stat + stat_head + 2 * q, 0);
+        e->sx_sync = was;
+        if (rc) return rc;
+    }
+    return FSK_OK;
+}
+
+}  // namespace fsk_detail

@@ -1,0 +1,290 @@
+// fsk_engine_variance.hip — approx / variance mode (fastsk_kernel.cpp:108-143, 188-262): T Welford chains,
+// batches of iterations run ahead of the stop test, the exact sequential fp64 sum on the device.
+#include "fsk_engine_internal.h"
+#include "fsk_kernels_variance.h"
+
+using namespace fsk_detail;
+
+namespace fsk_detail {
+
+// the reference's `avg` of get_variance (fastsk_kernel.cpp:116-131): sum of n doubles in index order,
+// on the device (k_seq_prep on all CUs + k_seq_chain); bsum = approximate sums per SQ_BLOCK values
+// (zero on entry, zero again on exit), result to out[0]
+// `count` independent sums laid out `stride` values apart (their block sums / block records / results
+// follow each other); the chains run on `chain_stream`
+// grp: 2 * SQ_GROUPS group records per block, laid out like blk
+int enqueue_sequential_sum(fsk_engine* e, const double* d_vals, u64 n, double* bsum, fsk::SeqBlk* blk, fsk::SeqGrp* grp, double* out,
+                           int count = 1, u64 stride = 0, hipStream_t chain_stream = nullptr, hipEvent_t handoff = nullptr) {
+    const uint32_t nblocks = (uint32_t)((n + fsk::SQ_BLOCK - 1) / fsk::SQ_BLOCK);
+    if (nblocks > 0)
+        FSK_LAUNCH(fsk::k_seq_prep, dim3(nblocks, count), dim3(256), 0, e->stream, d_vals, n, (const double*)bsum, blk, stride, nblocks);
+    hipStream_t cs = chain_stream ? chain_stream : e->stream;
+    if (chain_stream) {
+        FSK_HIP(hipEventRecord(handoff, e->stream));
+        FSK_HIP(hipStreamWaitEvent(chain_stream, handoff, 0));
+    }
+    if (nblocks > 0)  // (the few blocks that need group records: on the chains' stream, beside the next batch's kernels)
+        FSK_LAUNCH(fsk::k_seq_prep_groups, dim3(nblocks, count), dim3(256), 0, cs, d_vals, n, (const fsk::SeqBlk*)blk, stride, nblocks, grp);
+    FSK_LAUNCH(fsk::k_seq_chain, dim3(count), dim3(64), 0, cs, d_vals, n, (const fsk::SeqBlk*)blk, nblocks, bsum, out, stride,
+               (const fsk::SeqGrp*)grp);
+    return FSK_OK;
+}
+
+// variance mode: T sequential Welford chains (fastsk_kernel.cpp:188-262, 286-315)
+// chains tid = chain_first, chain_first + chain_step, ... < T (all of them: 0, 1); stdevs are chain 0's
+int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
+    { int rcz = materialise_zero(e); if (rcz) return rcz; }
+    const int64_t pairs = e->pairs;
+    const int64_t train_pairs = (int64_t)((e->n_train / (double)2) * (e->n_train + 1));
+    const size_t tp = (size_t)std::max<int64_t>(1, train_pairs);
+    // The stop test of iteration i needs avg_variance, a SEQUENTIAL fp64 sum in triangle-index
+    // order (fastsk_kernel.cpp:116-131), to the last bit. It is computed on the device
+    // (enqueue_sequential_sum), so only 8 bytes per iteration come back; the engine still runs AHEAD
+    // of its stop test: iterations are issued in batches of AHEAD with up to DEPTH batches in flight,
+    // the Welford state of every untested iteration is kept in a ring, and whatever lies beyond the
+    // stopping iteration is dropped.
+    // (two batches in flight: the sums of one run on the second stream under the kernels of the next;
+    // a third would only add iterations that are thrown away when the stop test fires)
+    constexpr int AHEAD = 4, MAX_DEPTH = 2;
+    const int DEPTH = MAX_DEPTH;
+    const int RING = DEPTH * AHEAD + 1;
+    const bool trace = getenv("FSK_TRACE") != nullptr;  // stderr: where the wall time of this mode goes
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+    double t_wait = 0;
+    const auto t_begin = now();
+    const size_t nblk = (tp + fsk::SQ_BLOCK - 1) / fsk::SQ_BLOCK;
+    const size_t slots = (size_t)DEPTH * AHEAD;
+    FSK_HIP(e->d_Kf64.reserve((size_t)pairs));
+    FSK_HIP(e->d_Khat.reserve((size_t)pairs * RING));
+    FSK_HIP(e->d_prod.reserve(tp * slots));
+    FSK_HIP(e->d_bsum.reserve(nblk * slots + slots));
+    FSK_HIP(e->d_seqblk.reserve(nblk * slots * (sizeof(fsk::SeqBlk) + 2 * fsk::SQ_GROUPS * sizeof(fsk::SeqGrp))));
+    fsk::SeqGrp* const seq_grp = reinterpret_cast<fsk::SeqGrp*>(e->d_seqblk.p + nblk * slots * sizeof(fsk::SeqBlk));
+    FSK_HIP(hipMemsetAsync(e->d_Kf64.p, 0, (size_t)pairs * sizeof(double), e->stream));
+    FSK_HIP(hipMemsetAsync(e->d_bsum.p, 0, (nblk * slots + slots) * sizeof(double), e->stream));
+    if (e->h_prod_cap < slots) {
+        if (e->h_prod) (void)hipHostFree(e->h_prod);
+        e->h_prod = nullptr; e->h_prod_cap = 0;
+        FSK_HIP(hipHostMalloc((void**)&e->h_prod, slots * sizeof(double)));
+        e->h_prod_cap = slots;
+    }
+    double* h_avg = e->h_prod;  // pinned
+    if (!e->chain_stream) FSK_HIP(hipStreamCreateWithFlags(&e->chain_stream, hipStreamNonBlocking));
+    hipEvent_t ev_done[MAX_DEPTH], ev_hand[MAX_DEPTH];
+    for (auto& ev : ev_done) FSK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (auto& ev : ev_hand) FSK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    struct Cleanup {
+        hipEvent_t* a; hipEvent_t* b; fsk_engine* e;
+        ~Cleanup() {
+            (void)hipStreamSynchronize(e->stream);  // nothing of this call may still be in flight
+            (void)hipStreamSynchronize(e->chain_stream);
+            for (int i = 0; i < MAX_DEPTH; ++i) { (void)hipEventDestroy(a[i]); (void)hipEventDestroy(b[i]); }
+        }
+    } cleanup{ev_done, ev_hand, e};
+    const double t_alloc = ms_since(t_begin);
+    const uint32_t blocks = (uint32_t)((pairs + 255) / 256);                                       // one cell per thread
+    const uint32_t wblocks = (uint32_t)((pairs + 256 * fsk::WF_ITEMS - 1) / (256 * fsk::WF_ITEMS)); // k_welford
+    const int n_order = (int)e->order.size();
+    auto khat = [&](int i) { return e->d_Khat.p + (size_t)(i % RING) * (size_t)pairs; };
+    struct Batch { int n = 0, first_iter = 0, first_item = 0, base = 0, part = 0; bool grouped = false; };
+    // how many iterations can still follow (end of the work list, max_iters)
+    auto plan = [&](int first_iter, int first_item) {
+        int n = AHEAD;
+        n = std::min(n, first_item < n_order ? (n_order - first_item + T - 1) / T : 0);
+        if (e->cfg.max_iters != -1) n = std::min(n, e->cfg.max_iters - first_iter + 1);
+        return std::max(n, 0);
+    };
+    // the batch that would follow B if all of B is accepted
+    auto after = [&](const Batch& B) {
+        Batch N;
+        N.first_iter = B.first_iter + B.n; N.first_item = B.first_item + B.n * T; N.base = B.base + B.n;
+        N.part = (B.part + 1) % DEPTH;
+        N.n = plan(N.first_iter, N.first_item);
+        return N;
+    };
+    // sparse dataflow: the iterations of a batch are sorted and segmented together (one slot each) and
+    // land in AHEAD separate triangles; dense dataflow: one iteration at a time into the engine's triangle
+    // (u32 triangles written whole by k_sx_consume; without update streams — huge N — pairs go to K with
+    // atomics and the iterations run one at a time like the dense ones)
+    bool grouped = e->path == FSK_PATH_SPARSE && e->sx_lists && !e->force_global_pairs;
+    // Dense dataflow with a tile kernel that can STORE (one workgroup per tile, the direct-to-LDS kernel, no
+    // key compaction, no test-block filter): every iteration's tile launch stores its counts into a u64
+    // triangle of its own — no zero fill — and the batch's Welford updates run as one pass like the sparse
+    // batches' (while the slot triangles stay a modest share of the memory).
+    const bool dense_slots = e->path == FSK_PATH_DENSE && e->tile_dma && !e->compact && !(e->cfg.skip_test_block && e->n_test > 0) &&
+                             (u64)pairs * AHEAD * DEPTH * sizeof(u64) <= ((u64)8 << 30) && e->variance_dense_slots;
+    // (one set of slot triangles per batch in flight: a stop inside a batch runs its Welford prefix again)
+    if (grouped) FSK_HIP(e->d_Kslots.reserve(((size_t)pairs * AHEAD * DEPTH + 1) / 2));
+    if (dense_slots) FSK_HIP(e->d_Kslots.reserve((size_t)pairs * AHEAD * DEPTH));
+    auto slots_of = [&](int part) { return reinterpret_cast<uint32_t*>(e->d_Kslots.p) + (size_t)part * AHEAD * (size_t)pairs; };
+    auto slots64_of = [&](int part) { return e->d_Kslots.p + (size_t)part * AHEAD * (size_t)pairs; };
+    static_assert(AHEAD <= fsk::WF_SLOTS, "k_welford_batch carries a batch's iterations in registers");
+    auto issue = [&](Batch& B) -> int {
+        if (grouped) {
+            int32_t combos[AHEAD];
+            for (int b = 0; b < B.n; ++b) combos[b] = e->order[B.first_item + b * T];
+            int rc = do_accumulate(e, combos, B.n, reinterpret_cast<u64*>(slots_of(B.part)), 0, -1, (u64)pairs, B.part);
+            if (rc == FSK_RETRY_UNGROUPED) grouped = false;  // too many updates for one stream: from here on one iteration at a time
+            else if (rc) return rc;
+        }
+        B.grouped = grouped || dense_slots;  // (the batch's counts sit in slot triangles, its Welford update is one pass)
+        if (grouped) {  // K_hat through the batch's iterations in one pass; only the state after the batch is written
+            const size_t slot0 = (size_t)B.part * AHEAD;
+            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<uint32_t>), dim3(wblocks), dim3(256), 0, e->stream, (const uint32_t*)slots_of(B.part), B.n,
+                       (const double*)khat(B.base), khat(B.base + B.n), e->d_prod.p + slot0 * tp, (u64)tp, (u64)pairs, (u64)train_pairs,
+                       (double)B.first_iter, e->d_bsum.p + slot0 * nblk, (uint32_t)nblk, 1);
+        } else if (dense_slots) {
+            for (int b = 0; b < B.n; ++b) {
+                int32_t combo = e->order[B.first_item + b * T];
+                e->store_next = true;
+                int rc = do_accumulate(e, &combo, 1, slots64_of(B.part) + (size_t)b * pairs);
+                e->store_next = false;
+                if (rc) return rc;
+            }
+            const size_t slot0 = (size_t)B.part * AHEAD;
+            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<u64>), dim3(wblocks), dim3(256), 0, e->stream, (const u64*)slots64_of(B.part), B.n,
+                       (const double*)khat(B.base), khat(B.base + B.n), e->d_prod.p + slot0 * tp, (u64)tp, (u64)pairs, (u64)train_pairs,
+                       (double)B.first_iter, e->d_bsum.p + slot0 * nblk, (uint32_t)nblk, 1);
+        }
+        for (int b = 0; b < B.n && !B.grouped; ++b) {
+            const size_t slot = (size_t)(B.part * AHEAD + b);
+            FSK_HIP(hipMemsetAsync(e->d_K, 0, (size_t)pairs * sizeof(u64), e->stream));
+            int32_t combo = e->order[B.first_item + b * T];
+            int rc = do_accumulate(e, &combo, 1, e->d_K);
+            if (rc) return rc;
+            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford<u64>), dim3(wblocks), dim3(256), 0, e->stream, (const u64*)e->d_K, (const double*)khat(B.base + b),
+                       khat(B.base + b + 1), e->d_prod.p + slot * tp, (u64)pairs, (u64)train_pairs, (double)(B.first_iter + b),
+                       e->d_bsum.p + slot * nblk);
+        }
+        // the batch's sums: block totals on all CUs, then one wave per iteration walks its blocks — on a
+        // second stream, under the kernels of the batches that follow
+        const size_t slot0 = (size_t)B.part * AHEAD;
+        int rc = enqueue_sequential_sum(e, e->d_prod.p + slot0 * tp, (u64)train_pairs, e->d_bsum.p + slot0 * nblk,
+                                        reinterpret_cast<fsk::SeqBlk*>(e->d_seqblk.p) + slot0 * nblk,
+                                        seq_grp + slot0 * nblk * (2 * fsk::SQ_GROUPS), h_avg + slot0, B.n, (u64)tp,
+                                        e->chain_stream, ev_hand[B.part]);  // (the sums land in pinned host memory)
+        if (rc) return rc;
+        FSK_HIP(hipEventRecord(ev_done[B.part], e->chain_stream));
+        return FSK_OK;
+    };
+    e->stdevs.clear();
+    for (int tid = chain_first; tid < T; tid += chain_step) {
+        int cur = 0;  // ring position of the state after the last accepted iteration
+        FSK_HIP(hipMemsetAsync(khat(cur), 0, (size_t)pairs * sizeof(double), e->stream));
+        int iter = 1, item = tid;
+        std::vector<Batch> q;  // issued, untested batches, oldest first (at most DEPTH)
+        {
+            Batch A;
+            A.first_iter = iter; A.first_item = item; A.base = cur; A.part = 0;
+            A.n = std::max(1, plan(iter, item));  // (the reference always runs the first iteration)
+            int rc = issue(A);
+            if (rc) return rc;
+            q.push_back(A);
+        }
+        bool working = true;
+        while (working) {
+            while ((int)q.size() < DEPTH) {  // keep the device DEPTH batches ahead of the stop test
+                Batch N = after(q.back());
+                if (N.n == 0) break;
+                int rc = issue(N);
+                if (rc) return rc;
+                q.push_back(N);
+            }
+            const Batch A = q.front();
+            auto t0 = now();
+            FSK_HIP(hipEventSynchronize(ev_done[A.part]));
+            t_wait += ms_since(t0);
+            if (!sx_harvest(e, A.part)) {
+                // A was enqueued ahead of its word count and did not fit the update streams: its slot
+                // triangles were not written. Everything issued after it started from A's state: drop
+                // it all and run A again, sized exactly.
+                FSK_HIP(hipStreamSynchronize(e->stream));
+                FSK_HIP(hipStreamSynchronize(e->chain_stream));
+                for (const Batch& B : q) { e->st.combos_done -= B.n; e->sx_defer[B.part].active = false; }
+                q.clear();
+                const int was = e->sx_sync;
+                e->sx_sync = 1;
+                Batch R = A;
+                int rc = issue(R);
+                e->sx_sync = was;
+                if (rc) return rc;
+                q.push_back(R);
+                continue;
+            }
+            int accepted = 0;
+            for (int b = 0; b < A.n && working; ++b) {
+                double v = h_avg[(size_t)A.part * AHEAD + b] / (double)train_pairs;
+                if (iter == 1) v = 9999999;
+                else v /= iter - 1;
+                const double sd = std::sqrt(v / iter);
+                if (tid == 0) e->stdevs.push_back(sd);
+                if (e->cfg.delta / sd > 1.96) working = false;
+                if (e->cfg.max_iters != -1 && iter >= e->cfg.max_iters) working = false;
+                item += T;
+                if (item >= n_order) working = false;
+                iter++;
+                accepted = b + 1;
+            }
+            cur = A.base + accepted;
+            e->st.combos_done -= A.n - accepted;  // iterations run ahead of the stop are dropped
+            q.erase(q.begin());
+            if (!working) {
+                for (const Batch& B : q) e->st.combos_done -= B.n;
+                if (!q.empty()) {  // dropped batches drain before their buffers are reused
+                    FSK_HIP(hipStreamSynchronize(e->stream));
+                    FSK_HIP(hipStreamSynchronize(e->chain_stream));
+                }
+                for (const Batch& B : q) (void)sx_harvest(e, B.part);
+                if (A.grouped && accepted < A.n) {  // the stop fell inside the batch: the state after its accepted prefix
+                    if (dense_slots)
+                        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<u64>), dim3(wblocks), dim3(256), 0, e->stream, (const u64*)slots64_of(A.part),
+                                   accepted, (const double*)khat(A.base), khat(A.base + accepted), (double*)nullptr, (u64)0, (u64)pairs,
+                                   (u64)train_pairs, (double)A.first_iter, (double*)nullptr, (uint32_t)0, 0);
+                    else
+                        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<uint32_t>), dim3(wblocks), dim3(256), 0, e->stream,
+                                   (const uint32_t*)slots_of(A.part), accepted, (const double*)khat(A.base), khat(A.base + accepted),
+                                   (double*)nullptr, (u64)0, (u64)pairs, (u64)train_pairs, (double)A.first_iter, (double*)nullptr, (uint32_t)0, 0);
+                }
+                break;
+            }
+            // (working implies more items and iterations: the queue is not empty)
+        }
+        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_add_nonzero<double>), dim3(blocks), dim3(256), 0, e->stream, e->d_Kf64.p, (const double*)khat(cur), (u64)pairs);
+    }
+    e->result_f64 = true;
+    FSK_HIP(hipStreamSynchronize(e->stream));
+    if (trace)
+        fprintf(stderr, "[fsk] variance mode: setup %.2f ms, waiting for the GPU %.2f ms, total %.2f ms (%lld cells/iteration, %d batches in flight)\n",
+                t_alloc, t_wait, ms_since(t_begin), (long long)train_pairs, DEPTH);
+    return FSK_OK;
+}
+
+}  // namespace fsk_detail
+
+extern "C" {
+
+int fsk_sequential_sum(fsk_engine* e, const double* values, int64_t n, double* out) {
+    if (!e) return FSK_EINVAL;
+    if (n < 0 || (n > 0 && !values) || !out) return e->fail(FSK_EINVAL, "bad arguments");
+    FSK_ON_DEVICE(e);
+    const size_t nblk = ((size_t)n + fsk::SQ_BLOCK - 1) / fsk::SQ_BLOCK;
+    DevBuf<double> vals, bsum;
+    DevBuf<unsigned char> blk;
+    struct Free { DevBuf<double>&a, &b; DevBuf<unsigned char>& c; ~Free() { a.release(); b.release(); c.release(); } } guard{vals, bsum, blk};
+    FSK_HIP(vals.reserve((size_t)std::max<int64_t>(1, n)));
+    FSK_HIP(bsum.reserve(nblk + 1));
+    FSK_HIP(blk.reserve((nblk + 1) * (sizeof(fsk::SeqBlk) + 2 * fsk::SQ_GROUPS * sizeof(fsk::SeqGrp))));
+    FSK_HIP(hipMemcpyAsync(vals.p, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    FSK_HIP(hipMemsetAsync(bsum.p, 0, (nblk + 1) * sizeof(double), e->stream));
+    if (n > 0)  // approximate block sums (what k_welford accumulates on the way in variance mode)
+        FSK_LAUNCH(fsk::k_block_sums, dim3((uint32_t)nblk), dim3(256), 0, e->stream, (const double*)vals.p, (u64)n, bsum.p);
+    int rc = enqueue_sequential_sum(e, vals.p, (u64)n, bsum.p, reinterpret_cast<fsk::SeqBlk*>(blk.p),
+                                    reinterpret_cast<fsk::SeqGrp*>(blk.p + (nblk + 1) * sizeof(fsk::SeqBlk)), bsum.p + nblk);
+    if (rc) return rc;
+    FSK_HIP(hipMemcpyAsync(out, bsum.p + nblk, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    FSK_HIP(hipStreamSynchronize(e->stream));
+    return FSK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,10 @@
+// fsk_kernels_sparse.h — SPARSE dataflow (the reference's: gather -> sort -> run-length -> K +=, as streams).
+// Included by fsk_engine_sparse.hip only.
+#pragma once
+#include "fsk_common.h"
+
+namespace fsk {
+
+#include "fsk_sparse_kernels.inc"
+
+}  // namespace fsk

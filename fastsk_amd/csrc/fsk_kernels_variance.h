@@ -1,0 +1,486 @@
+// fsk_kernels_variance.h — approx / variance mode: Welford updates and the exact left-to-right fp64 sum of
+// get_variance (fastsk_kernel.cpp:108-143) on the device. Included by fsk_engine_variance.hip only.
+#pragma once
+#include "fsk_common.h"
+
+namespace fsk {
+
+// =============================================================================================
+// APPROX / VARIANCE MODE  (get_variance, fastsk_kernel.cpp:108-143)
+// =============================================================================================
+// K_hat' = K_hat + (Ks - K_hat)/iter; prod = delta * (Ks - K_hat') for the train x train prefix.
+// The reference then sums prod SEQUENTIALLY in index order (fastsk_kernel.cpp:116-131) and the stop
+// test reads that sum to the last bit; k_seq_prep / k_seq_chain below reproduce it on the device.
+// K_hat is read from one buffer and written to another: the host runs a few iterations ahead of
+// its stop test and keeps the state of every iteration it has not yet accepted.
+// bsum[i / SQ_BLOCK] += prod (any order: only a PREDICTION of the running sum's binade is made from it).
+constexpr int SQ_BLOCK = 8192;
+constexpr int WF_ITEMS = 4;  // cells per thread: 1024 per workgroup, SQ_BLOCK / 1024 workgroups add to one block sum
+template <typename SrcT>
+__global__ __launch_bounds__(256) void k_welford(const SrcT* Ks, const double* K_hat_in, double* K_hat_out, double* prod, u64 pairs,
+                                                 u64 train_pairs, double iter, double* bsum) {
+    __shared__ double part[4];
+    const u64 base = (u64)blockIdx.x * (256 * WF_ITEMS);
+    double pr = 0.0;
+#pragma unroll
+    for (int q = 0; q < WF_ITEMS; ++q) {
+        const u64 i = base + (u64)q * 256 + threadIdx.x;
+        if (i < pairs) {
+            const double x = (double)Ks[i];
+            const double old = K_hat_in[i];
+            const double delta = __dsub_rn(x, old);
+            const double kh = __dadd_rn(old, __ddiv_rn(delta, iter));
+            K_hat_out[i] = kh;
+            if (i < train_pairs) {
+                const double v = __dmul_rn(delta, __dsub_rn(x, kh));
+                prod[i] = v;
+                pr += v;
+            }
+        }
+    }
+    // (any order: the block sum only PREDICTS the running sum's binade; the 1024 cells of a workgroup lie
+    // inside one SQ_BLOCK)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) pr += __shfl_xor(pr, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = pr;
+    __syncthreads();
+    if (threadIdx.x == 0 && base < train_pairs) {
+        const double t = (part[0] + part[1]) + (part[2] + part[3]);
+        if (t != 0.0) atomicAdd(&bsum[base / SQ_BLOCK], t);
+    }
+}
+
+// The same for the `nslots` consecutive iterations of a batch whose counts lie in triangles `pairs`
+// cells apart (u32: sparse dataflow, grouped batches; u64: dense dataflow, one storing tile launch per iteration): K_hat is read once, carried through the iterations in
+// a register and written once — the state after the batch; the states in between exist only if the
+// host asks for them by running a prefix of the batch again (it does when its stop test fires inside
+// the batch). Per cell and iteration the same IEEE operations in the same order as k_welford.
+// prod / bsum of slot q: prod + q * prod_stride, bsum + q * nblk; write_prod = 0: only K_hat_out.
+constexpr int WF_SLOTS = 4;
+template <typename SrcT>
+__global__ __launch_bounds__(256) void k_welford_batch(const SrcT* Ks, int nslots, const double* K_hat_in, double* K_hat_out, double* prod,
+                                                       u64 prod_stride, u64 pairs, u64 train_pairs, double first_iter, double* bsum,
+                                                       uint32_t nblk, int write_prod) {
+    __shared__ double part[WF_SLOTS][4];
+    const u64 base = (u64)blockIdx.x * (256 * WF_ITEMS);
+    double pr[WF_SLOTS];
+#pragma unroll
+    for (int s = 0; s < WF_SLOTS; ++s) pr[s] = 0.0;
+#pragma unroll
+    for (int q = 0; q < WF_ITEMS; ++q) {
+        const u64 i = base + (u64)q * 256 + threadIdx.x;
+        if (i < pairs) {
+            SrcT xs[WF_SLOTS];
+#pragma unroll
+            for (int s = 0; s < WF_SLOTS; ++s) xs[s] = s < nslots ? Ks[(u64)s * pairs + i] : (SrcT)0;  // (all loads before the dependent chain)
+            double kh = K_hat_in[i];
+#pragma unroll
+            for (int s = 0; s < WF_SLOTS; ++s) {
+                if (s < nslots) {
+                    const double x = (double)xs[s];
+                    const double delta = __dsub_rn(x, kh);
+                    kh = __dadd_rn(kh, __ddiv_rn(delta, first_iter + (double)s));
+                    if (write_prod && i < train_pairs) {
+                        const double v = __dmul_rn(delta, __dsub_rn(x, kh));
+                        prod[(u64)s * prod_stride + i] = v;
+                        pr[s] += v;
+                    }
+                }
+            }
+            K_hat_out[i] = kh;
+        }
+    }
+    if (!write_prod || base >= train_pairs) return;  // (uniform per workgroup)
+#pragma unroll
+    for (int s = 0; s < WF_SLOTS; ++s) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) pr[s] += __shfl_xor(pr[s], d);
+        if ((threadIdx.x & 63) == 0) part[s][threadIdx.x >> 6] = pr[s];
+    }
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)nslots) {
+        const double t = (part[threadIdx.x][0] + part[threadIdx.x][1]) + (part[threadIdx.x][2] + part[threadIdx.x][3]);
+        if (t != 0.0) atomicAdd(&bsum[(size_t)threadIdx.x * nblk + base / SQ_BLOCK], t);
+    }
+}
+
+// ---- exact sequential summation, in parallel ---------------------------------------------------
+// s_i = fl(s_{i-1} + p_i), p_i >= 0, round to nearest even. While the running sum stays inside one
+// binade [2^e, 2^(e+1)) every s_i is a multiple of u = 2^(e-52), so fl(s + p) = s + R(p) with R(p) the
+// multiple of u nearest to p — independent of s unless p lies exactly half-way (a tie: the parity of
+// s decides). Hence for a block of values with no tie whose integer total S/u + sum R(p)/u stays
+// below 2^53 the sequential result is exactly that integer total times u, whatever the order of the
+// additions. k_seq_prep computes sum R(p)/u per block for the binade PREDICTED from approximate block
+// sums, on all CUs; k_seq_chain (one wave) walks the blocks with the exact running sum, accepts a
+// block when the prediction was right and its conditions hold, and otherwise redoes the block
+// itself, in sub-blocks, down to plain sequential additions — so the result is the sequential sum
+// for ANY input; only the speed depends on the values being non-negative.
+struct SeqBlk {
+    int e;            // binade the block's integer total was computed for
+    uint32_t flags;   // 1: negative or NaN value, 2: value too large for the integer total, 4: tie, 8: no prediction,
+                      // 16: every value of the block is zero (the block changes no running sum),
+                      // 32: the block has group records (below)
+    u64 Q;            // sum of R(p) / u over the block
+};
+// A block that will not go through as one integer total — it holds a tie or an outsized value, or the
+// approximate sums say the running sum crosses into the next binade inside it — also gets one record per
+// group of SQ_GROUP values, for the predicted binade e (records 0..7) and for e + 1 (records 8..15): the
+// chain then redoes only the group where the crossing / the tie actually is, not the block.
+constexpr int SQ_GROUP = 1024, SQ_GROUPS = 8192 / SQ_GROUP;
+struct SeqGrp {
+    u64 Q;            // sum of R(p) / u over the group
+    uint32_t flags;   // 1, 2, 4, 16 as above
+    uint32_t pad;
+};
+union DblBits { double d; u64 u; };
+// unbiased exponent of a normal positive double within +-900, else INT32_MIN (zero, subnormal, huge, NaN)
+__device__ __forceinline__ int seq_exponent(double s) {
+    DblBits b; b.d = s;
+    if (b.u >> 63) return INT32_MIN;
+    const int e = (int)((b.u >> 52) & 0x7ffu) - 1023;
+    return (e < -900 || e > 900) ? INT32_MIN : e;
+}
+__device__ __forceinline__ double seq_pow2(int e) {  // 2^e, -1022 <= e <= 1023
+    DblBits b; b.u = (u64)(e + 1023) << 52;
+    return b.d;
+}
+// R(p)/u of one value for scale = 1/u, added to q; limit (<= 2^52) bounds a single value so that q cannot
+// wrap and so that x + 2^52 is x rounded to the nearest integer (ties to even), held in the low 52 bits
+__device__ __forceinline__ void seq_classify(double p, double scale, double limit, u64& q, uint32_t& flags) {
+    if (!(p >= 0.0)) { flags |= 1u; return; }  // (-0.0 passes and adds nothing)
+    const double x = p * scale;                // exact: a power of two
+    if (!(x < limit)) { flags |= 2u; return; }
+    DblBits y;
+    y.d = __dadd_rn(x, 4503599627370496.0);
+    if (fabs(__dsub_rn(x, __dsub_rn(y.d, 4503599627370496.0))) == 0.5) flags |= 4u;  // (both differences are exact)
+    q += y.u & 0xfffffffffffffull;
+}
+
+// bsum[b] = sum of block b in any order (stand-alone use of the summation; variance mode gets these
+// from k_welford); grid = blocks of SQ_BLOCK values
+__global__ __launch_bounds__(256) void k_block_sums(const double* p, u64 n, double* bsum) {
+    __shared__ double part[4];
+    const uint32_t tid = threadIdx.x;
+    const u64 lo = (u64)blockIdx.x * SQ_BLOCK;
+    double a = 0.0;
+    for (int j = 0; j < SQ_BLOCK / 256; ++j) {
+        const u64 i = lo + (u64)j * 256 + tid;
+        if (i < n) a += p[i];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
+    if ((tid & 63u) == 0) part[tid >> 6] = a;
+    __syncthreads();
+    if (tid == 0) bsum[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// grid = blocks of SQ_BLOCK values, 256 threads
+// (blockIdx.y = one of several independent sums laid out `stride` values / `nblk` blocks apart)
+__global__ __launch_bounds__(256) void k_seq_prep(const double* p, u64 n, const double* bsum, SeqBlk* blk, u64 stride, uint32_t nblk) {
+    __shared__ double s_pre[4];
+    __shared__ u64 s_q[4];
+    __shared__ uint32_t s_f[4];
+    const uint32_t tid = threadIdx.x, b = blockIdx.x;
+    p += (u64)blockIdx.y * stride;
+    bsum += (size_t)blockIdx.y * nblk;
+    blk += (size_t)blockIdx.y * nblk;
+    double pre = 0.0;
+    for (uint32_t i = tid; i < b; i += 256) pre += bsum[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d);
+    if ((tid & 63u) == 0) s_pre[tid >> 6] = pre;
+    __syncthreads();
+    pre = (s_pre[0] + s_pre[1]) + (s_pre[2] + s_pre[3]);
+    const int e = seq_exponent(pre);
+    const double scale = seq_pow2(52 - (e == INT32_MIN ? 0 : e));
+    const u64 lo = (u64)b * SQ_BLOCK;
+    u64 q = 0;
+    uint32_t fl = e == INT32_MIN ? 8u : 0u, nonzero = 0u;
+#pragma unroll 4
+    for (int j = 0; j < SQ_BLOCK / 256; ++j) {
+        const u64 i = lo + (u64)j * 256 + tid;
+        if (i < n) {
+            const double v = p[i];
+            if (v != 0.0) nonzero = 1u;  // (NaN counts as non-zero)
+            seq_classify(v, scale, 1125899906842624.0 /* 2^50 */, q, fl);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        q += __shfl_xor(q, d);
+        fl |= __shfl_xor(fl, d);
+        nonzero |= __shfl_xor(nonzero, d);
+    }
+    if ((tid & 63u) == 0) { s_q[tid >> 6] = q; s_f[tid >> 6] = fl | (nonzero << 8); }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t all = s_f[0] | s_f[1] | s_f[2] | s_f[3];
+        const bool zero = (all >> 8) == 0u;
+        // group records when the block cannot be one integer total (a tie, an outsized or negative value)
+        // or is predicted to end in another binade than it starts in
+        const bool need = e != INT32_MIN && !zero && ((all & 7u) != 0u || seq_exponent(pre + bsum[b]) != e);
+        blk[b].e = e == INT32_MIN ? 0 : e;
+        blk[b].flags = (all & 0xffu) | (zero ? 16u : 0u) | (need ? 32u : 0u);
+        blk[b].Q = s_q[0] + s_q[1] + s_q[2] + s_q[3];
+    }
+}
+
+// the group records of the blocks k_seq_prep marked (a few per sum): same grid; a kernel of its own so
+// that the common path above stays lean
+__global__ __launch_bounds__(256) void k_seq_prep_groups(const double* p, u64 n, const SeqBlk* blk, u64 stride, uint32_t nblk, SeqGrp* grp) {
+    static_assert(SQ_GROUP * SQ_GROUPS == SQ_BLOCK && SQ_GROUP % 256 == 0, "groups of a block");
+    const uint32_t tid = threadIdx.x, b = blockIdx.x;
+    blk += (size_t)blockIdx.y * nblk;
+    if (!(blk[b].flags & 32u)) return;  // (uniform)
+    __shared__ u64 s_gq[4][2 * SQ_GROUPS];
+    __shared__ uint32_t s_gf[4][2 * SQ_GROUPS];
+    p += (u64)blockIdx.y * stride;
+    grp += ((size_t)blockIdx.y * nblk + b) * (2 * SQ_GROUPS);
+    const u64 lo = (u64)b * SQ_BLOCK;
+    // thread tid holds values lo + 256 j + tid: j / (SQ_GROUP / 256) is the group
+    const double scale = seq_pow2(52 - blk[b].e), scale1 = scale * 0.5;  // binades e and e + 1
+    for (int g = 0; g < SQ_GROUPS; ++g) {
+        u64 q0 = 0, q1 = 0;
+        uint32_t f0 = 0, f1 = 0, nz = 0;
+#pragma unroll
+        for (int jj = 0; jj < SQ_GROUP / 256; ++jj) {
+            const u64 i = lo + (u64)(g * (SQ_GROUP / 256) + jj) * 256 + tid;
+            if (i < n) {
+                const double v = p[i];
+                if (v != 0.0) nz = 1u;
+                seq_classify(v, scale, 1125899906842624.0 /* 2^50 */, q0, f0);
+                seq_classify(v, scale1, 1125899906842624.0, q1, f1);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            q0 += __shfl_xor(q0, d);
+            q1 += __shfl_xor(q1, d);
+            f0 |= __shfl_xor(f0, d);
+            f1 |= __shfl_xor(f1, d);
+            nz |= __shfl_xor(nz, d);
+        }
+        if ((tid & 63u) == 0) {
+            s_gq[tid >> 6][g] = q0; s_gq[tid >> 6][SQ_GROUPS + g] = q1;
+            s_gf[tid >> 6][g] = f0 | (nz << 8); s_gf[tid >> 6][SQ_GROUPS + g] = f1 | (nz << 8);
+        }
+    }
+    __syncthreads();
+    if (tid < 2u * SQ_GROUPS) {
+        const uint32_t all = s_gf[0][tid] | s_gf[1][tid] | s_gf[2][tid] | s_gf[3][tid];
+        SeqGrp r;
+        r.Q = s_gq[0][tid] + s_gq[1][tid] + s_gq[2][tid] + s_gq[3][tid];
+        r.flags = (all & 7u) | ((all >> 8) ? 0u : 16u);
+        r.pad = 0u;
+        grp[tid] = r;
+    }
+}
+
+// value of lane `src` (wave-uniform index) in every lane: a scalar read, not an LDS permute
+__device__ __forceinline__ uint32_t wave_bcast_u32(uint32_t x, uint32_t src) {
+#ifdef FSK_EMU
+    return __shfl(x, (int)src);
+#else
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)src);
+#endif
+}
+__device__ __forceinline__ u64 wave_bcast_u64(u64 x, uint32_t src) {
+    return ((u64)wave_bcast_u32((uint32_t)(x >> 32), src) << 32) | wave_bcast_u32((uint32_t)x, src);
+}
+__device__ __forceinline__ double wave_bcast_f64(double x, uint32_t src) {
+    DblBits b; b.d = x;
+    b.u = wave_bcast_u64(b.u, src);
+    return b.d;
+}
+
+// sum of x over the 64 lanes, in every lane. On the critical path of k_seq_chain (one wave, nothing to
+// overlap with), so through the DPP row shifts / broadcasts of the VALU rather than six dependent LDS
+// permutes per 32-bit half: rows of 16 lanes first, then row 0 -> 1 and 2 -> 3, then lane 31 -> rows 2-3.
+__device__ __forceinline__ u64 wave_sum_u64(u64 x) {
+#ifdef FSK_EMU
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+    return x;
+#else
+#define FSK_DPP_ADD64(ctrl, rows)                                                                                   \
+    {                                                                                                               \
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, ctrl, rows, 0xf, true);      \
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), ctrl, rows, 0xf, true); \
+        x += ((u64)hi << 32) | lo;                                                                                  \
+    }
+    FSK_DPP_ADD64(0x111, 0xf)  // row_shr:1
+    FSK_DPP_ADD64(0x112, 0xf)  // row_shr:2
+    FSK_DPP_ADD64(0x114, 0xf)  // row_shr:4
+    FSK_DPP_ADD64(0x118, 0xf)  // row_shr:8  -> lane 15 of every row holds the row's sum
+    FSK_DPP_ADD64(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+    FSK_DPP_ADD64(0x143, 0xc)  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+#undef FSK_DPP_ADD64
+    return wave_bcast_u64(x, 63u);
+#endif
+}
+
+// PER values per lane (held in registers; 0.0 where the range ended) added to s as one integer total,
+// if the conditions hold
+template <int PER>
+__device__ __forceinline__ bool seq_try_regs(const double (&v)[PER], double& s) {
+    const int e = seq_exponent(s);
+    const bool usable = e != INT32_MIN && s > 0.0;
+    const double scale = seq_pow2(52 - (usable ? e : 0));
+    u64 q = 0;
+    uint32_t fl = 0, nonzero = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (v[k] != 0.0) nonzero = 1u;
+        seq_classify(v[k], scale, 4503599627370496.0 /* 2^52 */, q, fl);
+    }
+    if (__ballot(nonzero != 0u) == 0ull) return true;  // zeros change no running sum, whatever it is (s starts at +0 and +0 + -0 = +0)
+    if (!usable || __ballot(fl != 0u) != 0ull) return false;
+    const u64 tot = (u64)(s * scale) + wave_sum_u64(q);
+    if (tot >= ((u64)1 << 53)) return false;
+    s = (double)tot * seq_pow2(e - 52);
+    return true;
+}
+// The values [lo, hi) added to s by one wave (a workgroup of its own): SQ_STAGE values at a time go
+// through registers into LDS — the loads of the next stage are in flight while this one is summed — and
+// are taken from there in groups of 1024 (16 per lane, value 64 k + lane in register k), then for a
+// group that crosses a binade, holds a tie or a negative value in its 16 sub-groups of 64, then by plain
+// sequential additions. s and every decision are wave-uniform.
+constexpr int SQ_STAGE = 4096;
+__device__ __forceinline__ double seq_range(const double* p, u64 lo, u64 hi, double s, double* stage) {
+    const uint32_t lane = threadIdx.x & 63u;
+    constexpr int PER = SQ_STAGE / 64;
+    double nx[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const u64 i = lo + (u64)k * 64 + lane;
+        nx[k] = i < hi ? p[i] : 0.0;
+    }
+    for (u64 c0 = lo; c0 < hi; c0 += SQ_STAGE) {
+        __syncthreads();  // (one wave: orders the LDS reads of the stage before with these writes)
+#pragma unroll
+        for (int k = 0; k < PER; ++k) stage[k * 64 + (int)lane] = nx[k];
+        if (c0 + SQ_STAGE < hi) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const u64 i = c0 + SQ_STAGE + (u64)k * 64 + lane;
+                nx[k] = i < hi ? p[i] : 0.0;
+            }
+        }
+        __syncthreads();
+        const uint32_t here = hi - c0 < (u64)SQ_STAGE ? (uint32_t)(hi - c0) : (uint32_t)SQ_STAGE;
+        for (uint32_t g0 = 0; g0 < here; g0 += 1024u) {
+            double cur[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) cur[k] = stage[g0 + (uint32_t)k * 64u + lane];  // (0.0 beyond hi)
+            if (seq_try_regs<16>(cur, s)) continue;
+#pragma unroll 1
+            for (uint32_t k = 0; k < 16u; ++k) {  // (rolled: a rare path, kept small)
+                const uint32_t q0 = g0 + k * 64u;
+                const double one[1] = {stage[q0 + lane]};
+                if (!seq_try_regs<1>(one, s)) {
+                    const uint32_t cn = q0 >= here ? 0u : (here - q0 < 64u ? here - q0 : 64u);
+                    for (uint32_t j = 0; j < cn; ++j) s = __dadd_rn(s, wave_bcast_f64(one[0], j));
+                }
+            }
+        }
+    }
+    return s;
+}
+
+// one wave: out[0] = the sequential sum of p[0..n); zeroes bsum for the slot's next use
+// (blockIdx.x = one of several independent sums laid out `stride` values / `nblocks` blocks apart)
+__global__ __launch_bounds__(64) void k_seq_chain(const double* p, u64 n, const SeqBlk* blk, uint32_t nblocks, double* bsum, double* out,
+                                                  u64 stride, const SeqGrp* grp) {
+    __shared__ double stage[SQ_STAGE];
+    const uint32_t lane = threadIdx.x;
+    p += (u64)blockIdx.x * stride;
+    blk += (size_t)blockIdx.x * nblocks;
+    grp += (size_t)blockIdx.x * nblocks * (2 * SQ_GROUPS);
+    bsum += (size_t)blockIdx.x * nblocks;
+    out += blockIdx.x;
+    // the running sum is kept either as a double s, or — between accepted blocks of one binade — as the
+    // integer S = s / 2^(e-52) in [2^52, 2^53), so that an accepted block is one 64-bit add and a compare
+    double s = 0.0;
+    bool as_int = false;
+    int e = 0;
+    u64 S = 0;
+    for (uint32_t c0 = 0; c0 < nblocks; c0 += 64) {
+        // 64 block records at a time, one per lane, handed round with scalar reads (no dependent loads in the chain)
+        SeqBlk mine;
+        mine.e = 0; mine.flags = 8u; mine.Q = 0;
+        if (c0 + lane < nblocks) mine = blk[c0 + lane];
+        const uint32_t cn = nblocks - c0 < 64u ? nblocks - c0 : 64u;
+        for (uint32_t j = 0; j < cn; ++j) {
+            const uint32_t kf = wave_bcast_u32(mine.flags, j);
+            if (kf & 16u) continue;  // all zeros
+            if (kf == 0u) {
+                const int ke = (int)wave_bcast_u32((uint32_t)mine.e, j);
+                const u64 kq = wave_bcast_u64(mine.Q, j);
+                if (!as_int && s > 0.0 && seq_exponent(s) == ke) {
+                    e = ke;
+                    S = (u64)(s * seq_pow2(52 - e));
+                    as_int = true;
+                }
+                if (as_int && e == ke && S + kq < ((u64)1 << 53)) {
+                    S += kq;
+                    continue;
+                }
+            }
+            const u64 lo = (u64)(c0 + j) * SQ_BLOCK, hi = lo + SQ_BLOCK < n ? lo + SQ_BLOCK : n;
+            if (kf & 32u) {
+                // group records: the groups before and after the crossing / the tie go through as integer
+                // totals of their binade; only the group in between is redone
+                const int ke = (int)wave_bcast_u32((uint32_t)mine.e, j);
+                SeqGrp mg;
+                mg.Q = 0; mg.flags = 1u; mg.pad = 0u;
+                if (lane < 2u * SQ_GROUPS) mg = grp[(size_t)(c0 + j) * (2 * SQ_GROUPS) + lane];
+                for (uint32_t g = 0; g < (uint32_t)SQ_GROUPS; ++g) {
+                    const u64 glo = lo + (u64)g * SQ_GROUP;
+                    if (glo >= hi) break;
+                    if (wave_bcast_u32(mg.flags, g) & 16u) continue;  // all zeros
+                    if (!as_int && s > 0.0 && seq_exponent(s) != INT32_MIN) {
+                        e = seq_exponent(s);
+                        S = (u64)(s * seq_pow2(52 - e));
+                        as_int = true;
+                    }
+                    if (as_int && (e == ke || e == ke + 1)) {
+                        const uint32_t r = (e == ke ? 0u : (uint32_t)SQ_GROUPS) + g;
+                        const u64 gq = wave_bcast_u64(mg.Q, r);
+                        if (wave_bcast_u32(mg.flags, r) == 0u && S + gq < ((u64)1 << 53)) {
+                            S += gq;
+                            continue;
+                        }
+                    }
+                    if (as_int) {
+                        s = (double)S * seq_pow2(e - 52);
+                        as_int = false;
+                    }
+                    const u64 ghi = glo + SQ_GROUP < hi ? glo + SQ_GROUP : hi;
+                    s = seq_range(p, glo, ghi, s, stage);
+                }
+                continue;
+            }
+            if (as_int) {
+                s = (double)S * seq_pow2(e - 52);
+                as_int = false;
+            }
+            s = seq_range(p, lo, hi, s, stage);
+        }
+    }
+    if (as_int) s = (double)S * seq_pow2(e - 52);
+    if (lane == 0) {
+        out[0] = s;
+        __threadfence_system();  // (`out` may be pinned host memory: the variance mode reads it after the stream's event)
+    }
+    for (uint32_t b = lane; b < nblocks; b += 64) bsum[b] = 0.0;
+}
+
+// K += val where val != 0 (fastsk_kernel.cpp:286-315)
+template <typename SrcT>
+__global__ __launch_bounds__(256) void k_add_nonzero(double* K, const SrcT* src, u64 pairs) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pairs) return;
+    const double v = (double)src[i];
+    if (v != 0.0) K[i] = __dadd_rn(K[i], v);
+}
+
+}  // namespace fsk

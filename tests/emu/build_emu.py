@@ -7,15 +7,19 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SRC = os.path.join(ROOT, "fastsk_amd", "csrc", "fsk_engine.hip")
+CSRC = os.path.join(ROOT, "fastsk_amd", "csrc")
 OUT = os.path.join(HERE, "libfastsk_emu.so")
 
 
 def _current():
-    deps = [SRC, os.path.join(HERE, "hip_emu.h"), os.path.join(ROOT, "include", "fastsk_amd.h")]
-    deps += [os.path.join(ROOT, "fastsk_amd", "csrc", f)
-             for f in ("fsk_kernels.h", "fsk_tile_kernel.inc", "fsk_tile_kernel_dma.inc", "fsk_sparse_kernels.inc", "fsk_platform.h", "fsk_fasta.cpp")]
+    deps = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")] + [os.path.join(ROOT, "include", "fastsk_amd.h")]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc", ".cpp")) and f != "bindings.cpp"]
     return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps)
+
+
+def units():
+    """The translation units of libfastsk_amd.so (everything but the pybind11 module)."""
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip")) + [os.path.join(CSRC, "fsk_fasta.cpp")]
 
 
 def build(force=False):
@@ -28,16 +32,32 @@ def build(force=False):
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and _current():  # somebody else built it while we waited
             return OUT
+        from concurrent.futures import ThreadPoolExecutor
         tmp = OUT + ".tmp%d" % os.getpid()
-        cmd = ["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-pthread", "-DFSK_EMU", "-ffp-contract=off",
-               "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-I", HERE, "-x", "c++", SRC,
-               os.path.join(ROOT, "fastsk_amd", "csrc", "fsk_fasta.cpp"), "-o", tmp]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            if os.path.exists(tmp):
-                os.remove(tmp)
-            raise RuntimeError("emu build failed:\n" + r.stderr)
-        os.replace(tmp, OUT)
+        objs = []
+
+        def compile_unit(src):
+            obj = "%s.%s.o" % (tmp, os.path.splitext(os.path.basename(src))[0])
+            objs.append(obj)
+            cmd = ["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-pthread", "-DFSK_EMU", "-ffp-contract=off", "-Wall",
+                   "-Wno-unused-function", "-Wno-unknown-pragmas", "-I", HERE, "-x", "c++", "-c", src, "-o", obj]
+            return subprocess.run(cmd, capture_output=True, text=True)
+        try:
+            with ThreadPoolExecutor(max_workers=4) as pool:
+                results = list(pool.map(compile_unit, units()))
+            bad = [r for r in results if r.returncode != 0]
+            if not bad:
+                r = subprocess.run(["g++", "-shared", "-pthread"] + objs + ["-ldl", "-o", tmp], capture_output=True, text=True)
+                bad = [r] if r.returncode != 0 else []
+            if bad:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                raise RuntimeError("emu build failed:\n" + "\n".join(r.stderr for r in bad))
+            os.replace(tmp, OUT)
+        finally:
+            for o in objs:
+                if os.path.exists(o):
+                    os.remove(o)
     return OUT
 
 

@@ -135,6 +135,37 @@ def test_emu_variance_mode_stops_anywhere(emu_lib, port, path, monkeypatch):
     assert len(lengths) >= (6 if full else 4)  # stops landed at many different places inside the batches
 
 
+def poly_a_sequences(n=24, L=300, seed=11):
+    """DNA with a few 290-long runs of one symbol: a k-mer count above 255 in one sequence, which the
+    dense dataflow's u8 panels cannot hold (the batch goes to the general dataflow)."""
+    rng = np.random.default_rng(seed)
+    X = [rng.integers(1, 5, size=int(l)).astype(np.int32) for l in rng.integers(L - 20, L + 20, size=n)]
+    for i in (2, 9, 17):
+        X[i][5:295] = 1
+    return X
+
+
+@pytest.mark.parametrize("form", ["dense_slots", "dense_fill", "sparse"])
+def test_emu_variance_mode_count_above_255(emu_lib, port, form, monkeypatch):
+    """Variance mode on the dense dataflow keeps one triangle per iteration in flight and lets the
+    tile launch STORE into it; an iteration whose counts overflow the panels is diverted to the
+    general dataflow, which adds — into a triangle that must have been zeroed first."""
+    from fastsk_amd import _native
+    if form == "dense_fill":
+        monkeypatch.setenv("FSK_VARIANCE_DENSE_SLOTS", "0")
+    tok, off = _native.flatten(poly_a_sequences())
+    g, m, T = 5, 2, 2
+    order = np.random.default_rng(3).permutation(port.num_combos(g, m)).astype(np.int32)
+    want, sd, _ = port.compute(tok, off, 16, 8, g, m, t=T, approx=True, delta=0.025, max_iters=-1, order=order)
+    e = _native.Engine(g, m, t=T, approx=True, path=2 if form == "sparse" else 1, lib=emu_lib)
+    e.set_combo_order(order)
+    e.compute(tok, off, 16, 8)
+    assert e.stats()["max_windows"] > 255
+    assert np.array_equal(e.get_stdevs(), sd)
+    assert np.array_equal(e.get_triangle(), want)
+    e.close()
+
+
 def test_emu_reset_then_storing_launch(emu_lib, port, monkeypatch):
     """fsk_reset_counts leaves the zeros to the next tile launch when that launch can STORE its
     sums (dense dataflow, one workgroup per tile, rows starting at the reset range's lower edge);

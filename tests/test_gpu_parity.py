@@ -721,6 +721,30 @@ def test_variance_mode_stops_anywhere(native, port, path, monkeypatch):
     assert len(lengths) >= 6  # stops landed at many different places inside the batches
 
 
+@pytest.mark.parametrize("form", ["dense_slots", "dense_fill", "sparse"])
+def test_variance_mode_count_above_255(native, port, form, monkeypatch):
+    """Variance mode, dense dataflow, a sequence with more than 255 equal windows: the iteration is
+    diverted to the general dataflow, which adds into the iteration's own triangle — zeroed first
+    (the storing tile launch that normally writes every cell of it is not coming)."""
+    if form == "dense_fill":
+        monkeypatch.setenv("FSK_VARIANCE_DENSE_SLOTS", "0")
+    rng = np.random.default_rng(11)
+    X = [rng.integers(1, 5, size=int(l)).astype(np.int32) for l in rng.integers(280, 320, size=24)]
+    for i in (2, 9, 17):
+        X[i][5:295] = 1
+    tok, off = native.flatten(X)
+    g, m, T = 5, 2, 2
+    order = np.random.default_rng(3).permutation(port.num_combos(g, m)).astype(np.int32)
+    want, sd, _ = port.compute(tok, off, 16, 8, g, m, t=T, approx=True, delta=0.025, max_iters=-1, order=order)
+    e = native.Engine(g, m, t=T, approx=True, path=2 if form == "sparse" else 1)
+    e.set_combo_order(order)
+    e.compute(tok, off, 16, 8)
+    assert e.stats()["max_windows"] > 255
+    assert np.array_equal(e.get_stdevs(), sd)
+    assert np.array_equal(e.get_triangle(), want)
+    e.close()
+
+
 def test_sequential_sum_on_the_device(native):
     """The device replacement of get_variance's sequential fp64 sum (fastsk_kernel.cpp:116-131): the
     adversarial cases of tests/test_sequential_sum.py on the real kernels, plus a 2.7 M-value sum of
