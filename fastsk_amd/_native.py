@@ -14,6 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfastsk_amd.so")
 
 PATH_AUTO, PATH_DENSE, PATH_SPARSE = 0, 1, 2
+COLL_AUTO, COLL_RCCL, COLL_P2P = 0, 1, 2
+ABI_VERSION = 2
 
 ERRORS = {-1: "FSK_EINVAL", -2: "FSK_ESHORT", -3: "FSK_ESTATE", -4: "FSK_EDEVICE", -5: "FSK_ENOMEM",
           -6: "FSK_EUNSUPPORTED"}
@@ -29,7 +31,8 @@ class Config(C.Structure):
     _fields_ = [("g", C.c_int32), ("m", C.c_int32), ("t", C.c_int32), ("approx", C.c_int32),
                 ("delta", C.c_double), ("max_iters", C.c_int32), ("skip_variance", C.c_int32),
                 ("device", C.c_int32), ("path", C.c_int32), ("profile", C.c_int32),
-                ("skip_test_block", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("skip_test_block", C.c_int32), ("collective", C.c_int32), ("bands", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
 
 
 class Stats(C.Structure):
@@ -48,6 +51,19 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
+class MultiInfo(C.Structure):
+    _fields_ = [("ndev", C.c_int32), ("devices", C.c_int32 * 16), ("collective", C.c_int32), ("comm_ranks", C.c_int32),
+                ("bands", C.c_int32), ("narrow", C.c_int32), ("reduce_bytes", C.c_int64),
+                ("combos_per_engine", C.c_int64 * 16), ("reserved", C.c_double * 4)]
+
+    def as_dict(self):
+        n = self.ndev
+        return {"ndev": n, "devices": list(self.devices[:n]),
+                "collective": {COLL_RCCL: "rccl", COLL_P2P: "p2p"}.get(self.collective, "none"),
+                "comm_ranks": self.comm_ranks, "bands": self.bands, "narrow": bool(self.narrow),
+                "reduce_bytes": self.reduce_bytes, "combos_per_engine": list(self.combos_per_engine[:n])}
+
+
 # every symbol include/fastsk_amd.h declares (checked by tests/test_abi.py)
 SYMBOLS = ["fsk_create", "fsk_destroy", "fsk_last_error", "fsk_abi_version", "fsk_device_count", "fsk_compute",
            "fsk_set_combo_order", "fsk_set_seed", "fsk_load_sequences", "fsk_bind_counts",
@@ -55,7 +71,8 @@ SYMBOLS = ["fsk_create", "fsk_destroy", "fsk_last_error", "fsk_abi_version", "fs
            "fsk_get_block", "fsk_get_block_device", "fsk_get_train", "fsk_get_test", "fsk_get_triangle", "fsk_get_counts",
            "fsk_get_counts_block", "fsk_get_counts_cells", "fsk_get_stdevs", "fsk_save_kernel", "fsk_get_stats", "fsk_num_combos",
            "fsk_combo_positions", "fsk_stream_wait_engine", "fsk_engine_wait_stream", "fsk_read_fasta", "fsk_sequential_sum",
-           "fsk_run_chains", "fsk_get_kernel_sum_device", "fsk_set_kernel_sum_device"]
+           "fsk_run_chains", "fsk_get_kernel_sum_device", "fsk_set_kernel_sum_device", "fsk_create_multi", "fsk_get_multi_info",
+           "fsk_counts_digest", "fsk_alloc_block_device", "fsk_free_device", "fsk_set_skip_test_block"]
 
 
 _hip_shared = False
@@ -132,6 +149,10 @@ class Library:
         if path == LIB_PATH:
             check_single_hip_runtime()
         self.path = path
+        L.fsk_abi_version.restype = C.c_int
+        if L.fsk_abi_version() != ABI_VERSION:  # a stale build: its structs and symbols are not the ones bound below
+            raise ImportError("%s speaks ABI version %d, this package needs %d: rebuild it (python -c 'import __graft_entry__ "
+                              "as g; g.build()')" % (path, L.fsk_abi_version(), ABI_VERSION))
         vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
         sig = {
             "fsk_create": ([C.POINTER(Config), C.POINTER(vp)], C.c_int),
@@ -171,6 +192,12 @@ class Library:
             "fsk_get_stats": ([vp, C.POINTER(Stats)], C.c_int),
             "fsk_num_combos": ([i32, i32], i64),
             "fsk_combo_positions": ([i32, i32, i64, vp], C.c_int),
+            "fsk_create_multi": ([C.POINTER(Config), vp, i32, C.POINTER(vp)], C.c_int),
+            "fsk_get_multi_info": ([vp, C.POINTER(MultiInfo)], C.c_int),
+            "fsk_counts_digest": ([vp, i64, i64, vp], C.c_int),
+            "fsk_alloc_block_device": ([vp, i64, i64, i64, i64, C.POINTER(vp)], C.c_int),
+            "fsk_free_device": ([vp, vp], C.c_int),
+            "fsk_set_skip_test_block": ([vp, i32], C.c_int),
         }
         for name, (argtypes, restype) in sig.items():
             fn = getattr(L, name)
@@ -218,18 +245,30 @@ def flatten(X):
 
 
 class Engine:
-    """One engine handle = one device, one HIP stream. Mirrors the C ABI one to one."""
+    """One engine handle = one device, one HIP stream — or, with ``devices=[...]``, one engine per listed GPU
+    of this process behind the same handle (``fsk_create_multi``). Mirrors the C ABI one to one."""
 
     def __init__(self, g, m, t=-1, approx=False, delta=0.025, max_iters=-1, skip_variance=False, device=0,
-                 path=PATH_AUTO, profile=False, lib=None, skip_test_block=False):
+                 path=PATH_AUTO, profile=False, lib=None, skip_test_block=False, devices=None, collective=COLL_AUTO,
+                 bands=0):
         self.lib = lib or library()
+        if devices is not None:
+            devices = [int(d) for d in devices]
+            if not devices:
+                raise ValueError("devices must list at least one GPU")
+            device = devices[0]
         cfg = Config(g=g, m=m, t=t, approx=int(bool(approx)), delta=delta, max_iters=max_iters,
                      skip_variance=int(bool(skip_variance)), device=device, path=path, profile=int(bool(profile)),
-                     skip_test_block=int(bool(skip_test_block)))
+                     skip_test_block=int(bool(skip_test_block)), collective=int(collective), bands=int(bands))
         h = C.c_void_p()
-        rc = self.lib.L.fsk_create(C.byref(cfg), C.byref(h))
+        if devices is None:
+            rc = self.lib.L.fsk_create(C.byref(cfg), C.byref(h))
+        else:
+            arr = (C.c_int32 * len(devices))(*devices)
+            rc = self.lib.L.fsk_create_multi(C.byref(cfg), arr, len(devices), C.byref(h))
         if rc:
             raise FskError(rc, (self.lib.L.fsk_last_error(None) or b"").decode())
+        self.devices = devices
         self.h = h
         self.g, self.m = g, m
         self.device = device
@@ -351,6 +390,21 @@ class Engine:
         out = np.empty(self.pairs, dtype=np.uint64)
         self._ck(self.lib.L.fsk_get_counts(self.h, out.ctypes.data))
         return out
+
+    def counts_digest(self, row_begin=0, row_end=None):
+        """(sum, xor of cell * (index | 1)) over the integer cells of rows [row_begin, row_end), mod 2^64: an
+        order-free digest computed on the device; digests of disjoint row ranges combine by + and ^."""
+        out = (C.c_uint64 * 2)()
+        self._ck(self.lib.L.fsk_counts_digest(self.h, row_begin, self.N if row_end is None else row_end, out))
+        return int(out[0]), int(out[1])
+
+    def multi_info(self):
+        info = MultiInfo()
+        self._ck(self.lib.L.fsk_get_multi_info(self.h, C.byref(info)))
+        return info.as_dict()
+
+    def set_skip_test_block(self, skip):
+        self._ck(self.lib.L.fsk_set_skip_test_block(self.h, int(bool(skip))))
 
     def get_counts_block(self, i0, i1, j0, j1):
         out = np.empty((i1 - i0, j1 - j0), dtype=np.uint64)

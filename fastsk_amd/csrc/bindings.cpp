@@ -7,7 +7,11 @@
 //   - errors raise ValueError / RuntimeError instead of printf + exit(1) (fastsk.cpp:53-58);
 //   - fit() / score() (LIBSVM, fastsk.cpp:239-530) are outside this path and raise
 //     NotImplementedError (they are unusable from Python in the reference as well);
-//   - additive keyword arguments (device, path, seed, quiet) and numpy getters.
+//   - additive keyword arguments (device, devices, collective, path, seed, skip_test_block), numpy and
+//     DLPack getters. devices=[0,1,...]: one engine per listed GPU behind the same object (fsk_create_multi) —
+//     the reference parallelises the same call over t host threads (fastsk_kernel.cpp:54-93).
+//   - the test x test block, which no getter of the reference exposes (fastsk.cpp:190-217), is not computed
+//     until something asks for it (get_block over test x test cells, get_counts_np, save_kernel).
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -37,6 +41,24 @@ struct Flat {
     }
 };
 
+// ---- DLPack (the ABI of dlpack.h v0.8, restated: nothing else of it is needed here) --------------------
+struct DLDevice { int32_t device_type; int32_t device_id; };
+struct DLDataType { uint8_t code; uint8_t bits; uint16_t lanes; };
+struct DLTensor {
+    void* data; DLDevice device; int32_t ndim; DLDataType dtype; int64_t* shape; int64_t* strides; uint64_t byte_offset;
+};
+struct DLManagedTensor { DLTensor dl_tensor; void* manager_ctx; void (*deleter)(DLManagedTensor*); };
+constexpr int32_t kDLROCM = 10;
+constexpr uint8_t kDLFloat = 2;
+struct BlockOwner { int64_t shape[2]; };   // manager_ctx of a block handed out through DLPack
+
+int parse_collective(const std::string& c) {
+    if (c == "auto") return FSK_COLL_AUTO;
+    if (c == "rccl") return FSK_COLL_RCCL;
+    if (c == "p2p") return FSK_COLL_P2P;
+    throw std::invalid_argument("collective must be 'auto', 'rccl' or 'p2p'");
+}
+
 int parse_path(const std::string& p) {
     if (p == "auto") return FSK_PATH_AUTO;
     if (p == "dense") return FSK_PATH_DENSE;
@@ -48,6 +70,11 @@ class FastSK {
     fsk_engine* h_ = nullptr;
     int64_t n_train_ = 0, n_test_ = 0;
     bool computed_ = false;
+    int device0_ = 0;
+    // skip_test_block=None: the test x test block is left out of compute_kernel and computed only if asked for
+    bool lazy_test_block_ = false, test_block_missing_ = false;
+    std::vector<int32_t> kept_tokens_;   // the call's input, kept while the test x test block is missing
+    std::vector<int64_t> kept_offsets_;
 
     void check(int rc) const {
         if (rc == FSK_OK) return;
@@ -55,16 +82,72 @@ class FastSK {
         if (rc == FSK_EINVAL || rc == FSK_ESHORT) throw py::value_error(msg);
         throw std::runtime_error(msg);
     }
-    void run(const Flat& f, int64_t n_train, int64_t n_test) {
+    void run_flat(const int32_t* tokens, const int64_t* offsets, int64_t n_train, int64_t n_test) {
+        const bool skip = lazy_test_block_ && n_test > 0;
+        if (lazy_test_block_) check(fsk_set_skip_test_block(h_, skip ? 1 : 0));
         int rc;
         {
             py::gil_scoped_release nogil;  // the reference holds the GIL for the whole call
-            rc = fsk_compute(h_, f.tokens.data(), f.offsets.data(), n_train, n_test);
+            rc = fsk_compute(h_, tokens, offsets, n_train, n_test);
         }
         check(rc);
         n_train_ = n_train;
         n_test_ = n_test;
         computed_ = true;
+        test_block_missing_ = skip;
+        if (skip) {
+            if (tokens != kept_tokens_.data()) {
+                kept_tokens_.assign(tokens + offsets[0], tokens + offsets[n_train + n_test]);
+                kept_offsets_.assign(offsets, offsets + n_train + n_test + 1);
+                for (auto& o : kept_offsets_) o -= offsets[0];
+            }
+        } else {
+            kept_tokens_.clear(); kept_tokens_.shrink_to_fit();
+            kept_offsets_.clear();
+        }
+    }
+    void run(const Flat& f, int64_t n_train, int64_t n_test) { run_flat(f.tokens.data(), f.offsets.data(), n_train, n_test); }
+    // something wants cells with both sequences in the test set: the same call again, nothing left out
+    void need_test_block() {
+        if (!test_block_missing_) return;
+        check(fsk_set_skip_test_block(h_, 0));
+        int rc;
+        {
+            py::gil_scoped_release nogil;
+            rc = fsk_compute(h_, kept_tokens_.data(), kept_offsets_.data(), n_train_, n_test_);
+        }
+        check(rc);
+        test_block_missing_ = false;
+        kept_tokens_.clear(); kept_tokens_.shrink_to_fit();
+        kept_offsets_.clear();
+    }
+    py::capsule dlpack_block(int64_t i0, int64_t i1, int64_t j0, int64_t j1) {
+        if (!computed_) throw std::runtime_error("call compute_kernel or compute_train first");
+        if (i1 < i0 || j1 < j0) throw py::value_error("empty block");
+        if (i1 > n_train_ && j1 > n_train_) need_test_block();
+        double* dev = nullptr;
+        check(fsk_alloc_block_device(h_, i0, i1, j0, j1, &dev));
+        auto* owner = new BlockOwner{{i1 - i0, j1 - j0}};
+        auto* mt = new DLManagedTensor{};
+        mt->dl_tensor.data = dev;
+        mt->dl_tensor.device = DLDevice{kDLROCM, device0_};
+        mt->dl_tensor.ndim = 2;
+        mt->dl_tensor.dtype = DLDataType{kDLFloat, 64, 1};
+        mt->dl_tensor.shape = owner->shape;
+        mt->dl_tensor.strides = nullptr;  // compact row-major
+        mt->dl_tensor.byte_offset = 0;
+        mt->manager_ctx = owner;
+        mt->deleter = [](DLManagedTensor* t) {  // (the block outlives the FastSK object if its consumer does)
+            (void)fsk_free_device(nullptr, t->dl_tensor.data);
+            delete static_cast<BlockOwner*>(t->manager_ctx);
+            delete t;
+        };
+        return py::capsule(mt, "dltensor", [](PyObject* cap) {
+            if (PyCapsule_IsValid(cap, "dltensor")) {  // never consumed: ours to free
+                auto* t = static_cast<DLManagedTensor*>(PyCapsule_GetPointer(cap, "dltensor"));
+                if (t && t->deleter) t->deleter(t);
+            }
+        });
     }
     py::array_t<double> block(bool test) const {
         if (!computed_) throw std::runtime_error("call compute_kernel or compute_train first");
@@ -83,12 +166,24 @@ class FastSK {
 
 public:
     FastSK(int g, int m, int t, bool approx, double delta, int max_iters, bool skip_variance, int device,
-           const std::string& path, py::object seed, bool skip_test_block) {
+           const std::string& path, py::object seed, py::object skip_test_block, py::object devices,
+           const std::string& collective) {
         fsk_config c{};
-        c.skip_test_block = skip_test_block;
+        lazy_test_block_ = skip_test_block.is_none();
+        c.skip_test_block = lazy_test_block_ ? 0 : (skip_test_block.cast<bool>() ? 1 : 0);
         c.g = g; c.m = m; c.t = t; c.approx = approx; c.delta = delta; c.max_iters = max_iters;
         c.skip_variance = skip_variance; c.device = device; c.path = parse_path(path);
-        int rc = fsk_create(&c, &h_);
+        c.collective = parse_collective(collective);
+        int rc;
+        if (devices.is_none()) {
+            device0_ = device;
+            rc = fsk_create(&c, &h_);
+        } else {
+            const std::vector<int32_t> devs = devices.cast<std::vector<int32_t>>();
+            if (devs.empty()) throw py::value_error("devices must list at least one GPU");
+            device0_ = devs[0];
+            rc = fsk_create_multi(&c, devs.data(), (int32_t)devs.size(), &h_);
+        }
         if (rc != FSK_OK) {
             std::string msg = fsk_last_error(nullptr);
             if (rc == FSK_EINVAL) throw py::value_error(msg);
@@ -132,15 +227,7 @@ public:
         const int64_t n = (int64_t)offsets.shape(0) - 1;
         if (n_train <= 0 || n_train > n) throw py::value_error("n_train out of range");
         if (offsets.data()[0] != 0 || offsets.data()[n] != (int64_t)tokens.shape(0)) throw py::value_error("offsets must start at 0 and end at len(tokens)");
-        int rc;
-        {
-            py::gil_scoped_release nogil;
-            rc = fsk_compute(h_, tokens.data(), offsets.data(), n_train, n - n_train);
-        }
-        check(rc);
-        n_train_ = n_train;
-        n_test_ = n - n_train;
-        computed_ = true;
+        run_flat(tokens.data(), offsets.data(), n_train, n - n_train);
     }
     static void add_array(Flat& f, const py::array_t<int32_t, py::array::c_style>& X) {
         const py::ssize_t n = X.shape(0), L = X.shape(1);
@@ -165,16 +252,26 @@ public:
         if (n) check(fsk_get_stdevs(h_, v.data(), n, &n));
         return v;
     }
-    void save_kernel(const std::string& path) const { check(fsk_save_kernel(h_, path.c_str())); }  // fastsk.cpp:223-237
+    void save_kernel(const std::string& path) {  // fastsk.cpp:223-237 (the whole N x N matrix)
+        need_test_block();
+        check(fsk_save_kernel(h_, path.c_str()));
+    }
+    // the same blocks as device-resident DLPack capsules (float64, row-major, on the engine's first GPU):
+    // torch.from_dlpack(f.get_train_kernel_dlpack()) keeps the kernel matrix on the GPU for the SVM stage
+    py::capsule get_train_kernel_dlpack() { return dlpack_block(0, n_train_, 0, n_train_); }
+    py::capsule get_test_kernel_dlpack() { return dlpack_block(n_train_, n_train_ + n_test_, 0, n_train_); }
+    py::capsule get_block_dlpack(int64_t i0, int64_t i1, int64_t j0, int64_t j1) { return dlpack_block(i0, i1, j0, j1); }
     void set_combo_order(std::vector<int32_t> order) { check(fsk_set_combo_order(h_, order.data(), (int32_t)order.size())); }
-    py::array_t<double> get_block(int64_t i0, int64_t i1, int64_t j0, int64_t j1) const {
+    py::array_t<double> get_block(int64_t i0, int64_t i1, int64_t j0, int64_t j1) {
         if (i1 < i0 || j1 < j0) throw py::value_error("empty block");
+        if (i1 > n_train_ && j1 > n_train_) need_test_block();
         py::array_t<double> out({(py::ssize_t)(i1 - i0), (py::ssize_t)(j1 - j0)});
         check(fsk_get_block(h_, i0, i1, j0, j1, out.mutable_data()));
         return out;
     }
-    py::array_t<uint64_t> get_counts_np() const {
+    py::array_t<uint64_t> get_counts_np() {
         if (!computed_) throw std::runtime_error("call compute_kernel or compute_train first");
+        need_test_block();
         const int64_t N = n_train_ + n_test_;
         py::array_t<uint64_t> out((py::ssize_t)(N * (N + 1) / 2));
         check(fsk_get_counts(h_, out.mutable_data()));
@@ -189,6 +286,15 @@ public:
         d["path_used"] = s.path_used == FSK_PATH_DENSE ? "dense" : "sparse";
         d["n_combos_total"] = s.n_combos_total; d["combos_done"] = s.combos_done;
         d["cell_updates"] = s.cell_updates; d["launches"] = s.launches;
+        d["test_block_computed"] = computed_ && !test_block_missing_;
+        fsk_multi_info mi;
+        check(fsk_get_multi_info(h_, &mi));
+        py::list devs;
+        for (int r = 0; r < mi.ndev; ++r) devs.append(mi.devices[r]);
+        if (mi.ndev == 0) devs.append(device0_);
+        d["devices"] = devs;
+        d["collective"] = mi.ndev == 0 ? "none" : mi.collective == FSK_COLL_RCCL ? "rccl" : "p2p";
+        d["comm_ranks"] = mi.comm_ranks; d["exchange_bands"] = mi.bands; d["exchange_int32"] = (bool)mi.narrow;
         return d;
     }
     void fit(double, double, double, const std::string&) const {
@@ -208,10 +314,12 @@ public:
 PYBIND11_MODULE(_fastsk, m) {
     m.doc() = "MI355X-native gapped-k-mer kernel engine behind the FastSK Python surface";
     py::class_<FastSK>(m, "FastSK")
-        .def(py::init<int, int, int, bool, double, int, bool, int, const std::string&, py::object, bool>(),
+        .def(py::init<int, int, int, bool, double, int, bool, int, const std::string&, py::object, py::object, py::object,
+                      const std::string&>(),
              py::arg("g"), py::arg("m"), py::arg("t") = -1, py::arg("approx") = false, py::arg("delta") = 0.025,
              py::arg("max_iters") = -1, py::arg("skip_variance") = false, py::arg("device") = 0,
-             py::arg("path") = "auto", py::arg("seed") = py::none(), py::arg("skip_test_block") = false)
+             py::arg("path") = "auto", py::arg("seed") = py::none(), py::arg("skip_test_block") = py::none(),
+             py::arg("devices") = py::none(), py::arg("collective") = "auto")
         .def("compute_kernel", &FastSK::compute_kernel_np, py::arg("Xtrain").noconvert(), py::arg("Xtest").noconvert())
         .def("compute_kernel", &FastSK::compute_kernel, py::arg("Xtrain"), py::arg("Xtest"))
         .def("compute_kernel_flat", &FastSK::compute_kernel_flat, py::arg("tokens").noconvert(), py::arg("offsets").noconvert(),
@@ -229,6 +337,9 @@ PYBIND11_MODULE(_fastsk, m) {
         .def("get_train_kernel_np", &FastSK::get_train_kernel_np)
         .def("get_test_kernel_np", &FastSK::get_test_kernel_np)
         .def("get_block", &FastSK::get_block, py::arg("i0"), py::arg("i1"), py::arg("j0"), py::arg("j1"))
+        .def("get_train_kernel_dlpack", &FastSK::get_train_kernel_dlpack)
+        .def("get_test_kernel_dlpack", &FastSK::get_test_kernel_dlpack)
+        .def("get_block_dlpack", &FastSK::get_block_dlpack, py::arg("i0"), py::arg("i1"), py::arg("j0"), py::arg("j1"))
         .def("get_counts_np", &FastSK::get_counts_np)
         .def("set_combo_order", &FastSK::set_combo_order, py::arg("order"))
         .def("stats", &FastSK::stats);

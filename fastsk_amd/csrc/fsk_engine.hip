@@ -19,6 +19,8 @@ thread_local std::string g_create_error;
 
 namespace fsk_detail {
 
+void set_create_error(const std::string& msg) { g_create_error = msg; }
+
 int64_t n_choose_k(int n, int k) {  // nchoosek, shared.cpp:335-345 (exact in 64 bits)
     if (k < 0 || k > n) return 0;
     if (k * 2 > n) k = n - k;
@@ -308,6 +310,13 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
 
 void fsk_destroy(fsk_engine* e) {
     if (!e) return;
+    if (e->group) { group_destroy(e); return; }
+    one_destroy(e);
+}
+
+}  // extern "C"
+
+void fsk_detail::one_destroy(fsk_engine* e) {
     DeviceScope on_device(e->cfg.device);
     (void)hipStreamSynchronize(e->stream);
     e->d_words.release(); e->d_wstart.release(); e->d_len.release(); e->d_fstart.release(); e->d_featseq.release();
@@ -321,7 +330,8 @@ void fsk_destroy(fsk_engine* e) {
     if (e->h_sx_pos) (void)hipHostFree(e->h_sx_pos);
     if (e->h_sx_stat) (void)hipHostFree(e->h_sx_stat);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
-    if (e->ev_order) (void)hipEventDestroy(e->ev_order);
+    if (e->ev_out) (void)hipEventDestroy(e->ev_out);
+    if (e->ev_in) (void)hipEventDestroy(e->ev_in);
     if (e->chain_stream) { (void)hipStreamSynchronize(e->chain_stream); (void)hipStreamDestroy(e->chain_stream); }
     (void)hipEventDestroy(e->ev0);
     (void)hipEventDestroy(e->ev1);
@@ -329,8 +339,16 @@ void fsk_destroy(fsk_engine* e) {
     delete e;
 }
 
+extern "C" {
+
 int fsk_set_combo_order(fsk_engine* e, const int32_t* order, int32_t n) {
     if (!e) return FSK_EINVAL;
+    return e->group ? group_set_combo_order(e, order, n) : one_set_combo_order(e, order, n);
+}
+
+}  // extern "C"
+
+int fsk_detail::one_set_combo_order(fsk_engine* e, const int32_t* order, int32_t n) {
     if (!order || n <= 0 || n > e->ncomb) return e->fail(FSK_EINVAL, "combo order must hold 1..C(g,m) ids");
     std::vector<char> seen((size_t)e->ncomb, 0);
     for (int i = 0; i < n; ++i) {
@@ -342,14 +360,23 @@ int fsk_set_combo_order(fsk_engine* e, const int32_t* order, int32_t n) {
     return FSK_OK;
 }
 
+extern "C" {
+
 int fsk_set_seed(fsk_engine* e, uint64_t seed) {
     if (!e) return FSK_EINVAL;
+    if (e->group) return group_set_seed(e, seed);
     e->seed = seed;
     return FSK_OK;
 }
 
 int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offsets, int64_t n_train, int64_t n_test) {
     if (!e) return FSK_EINVAL;
+    return e->group ? group_load_sequences(e, tokens, offsets, n_train, n_test) : one_load_sequences(e, tokens, offsets, n_train, n_test);
+}
+
+}  // extern "C"
+
+int fsk_detail::one_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offsets, int64_t n_train, int64_t n_test) {
     if (!offsets || n_train <= 0 || n_test < 0) return e->fail(FSK_EINVAL, "need n_train >= 1, n_test >= 0 and offsets");
     FSK_ON_DEVICE(e);
     const int64_t N = n_train + n_test;
@@ -622,6 +649,8 @@ int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offs
     return FSK_OK;
 }
 
+extern "C" {
+
 int fsk_bind_counts(fsk_engine* e, void* device_u64, int64_t n_cells) {
     if (!e) return FSK_EINVAL;
     if (!device_u64 || n_cells <= 0) return e->fail(FSK_EINVAL, "bad counts buffer");
@@ -649,6 +678,122 @@ int fsk_counts_device_ptr(fsk_engine* e, void** out) {
 
 int fsk_reset_counts(fsk_engine* e) {
     if (!e) return FSK_EINVAL;
+    return e->group ? group_reset_counts(e, 0, -1) : one_reset_counts(e);
+}
+
+int fsk_reset_counts_rows(fsk_engine* e, int64_t row_begin, int64_t row_end) {
+    if (!e) return FSK_EINVAL;
+    if (e->group && (row_begin < 0 || row_end < row_begin)) return e->fail(FSK_EINVAL, "bad row range");
+    return e->group ? group_reset_counts(e, row_begin, row_end) : one_reset_counts_rows(e, row_begin, row_end);
+}
+
+int fsk_accumulate(fsk_engine* e, const int32_t* combos, int32_t n) {
+    if (!e) return FSK_EINVAL;
+    if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
+    if (n < 0 || (n > 0 && !combos)) return e->fail(FSK_EINVAL, "bad combo list");
+    if (e->group) return group_accumulate(e, combos, n);
+    return one_accumulate_rows(e, combos, n, 0, e->N);
+}
+
+int fsk_accumulate_rows(fsk_engine* e, const int32_t* combos, int32_t n, int64_t row_begin, int64_t row_end) {
+    if (!e) return FSK_EINVAL;
+    if (e->group) return e->fail(FSK_ESTATE, "fsk_accumulate_rows is a single-engine call: a group bands its accumulate itself");
+    return one_accumulate_rows(e, combos, n, row_begin, row_end);
+}
+
+int fsk_synchronize(fsk_engine* e) {
+    if (!e) return FSK_EINVAL;
+    return e->group ? group_synchronize(e) : one_synchronize(e);
+}
+
+// Ordering against a stream of the caller (torch's current stream, which RCCL collectives are
+// ordered after) without blocking the host: an event recorded on one stream, waited for by the other
+// (one event per direction: a wait captures the record that precedes it).
+int fsk_stream_wait_engine(fsk_engine* e, void* hip_stream) {
+    if (!e) return FSK_EINVAL;
+    FSK_ON_DEVICE(e);
+    if (!e->ev_out) FSK_HIP(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
+    FSK_HIP(hipEventRecord(e->ev_out, e->stream));
+    FSK_HIP(hipStreamWaitEvent((hipStream_t)hip_stream, e->ev_out, 0));
+    return FSK_OK;
+}
+
+int fsk_engine_wait_stream(fsk_engine* e, void* hip_stream) {
+    if (!e) return FSK_EINVAL;
+    FSK_ON_DEVICE(e);
+    if (!e->ev_in) FSK_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+    FSK_HIP(hipEventRecord(e->ev_in, (hipStream_t)hip_stream));
+    FSK_HIP(hipStreamWaitEvent(e->stream, e->ev_in, 0));
+    return FSK_OK;
+}
+
+int fsk_finalize(fsk_engine* e) {
+    if (!e) return FSK_EINVAL;
+    return e->group ? group_finalize(e) : one_finalize(e);
+}
+
+int fsk_compute(fsk_engine* e, const int32_t* tokens, const int64_t* offsets, int64_t n_train, int64_t n_test) {
+    if (!e) return FSK_EINVAL;
+    if (e->group) return group_compute(e, tokens, offsets, n_train, n_test);
+    FSK_ON_DEVICE(e);
+    int rc = one_load_sequences(e, tokens, offsets, n_train, n_test);
+    if (rc) return rc;
+    const fsk_config& c = e->cfg;
+    if (!c.approx) {  // exact: every combination, order irrelevant (integer sum)
+        std::vector<int32_t> all((size_t)e->ncomb);
+        for (int64_t i = 0; i < e->ncomb; ++i) all[i] = (int32_t)i;
+        rc = do_accumulate(e, all.data(), (int)all.size(), e->d_K);
+        if (rc) return rc;
+        return make_diag(e);
+    }
+    if (!e->order_set) default_order(e);
+    if (c.skip_variance) {  // chains only select which combos enter the integer sum
+        std::vector<int32_t> used;
+        skip_variance_combos(e, used);
+        rc = do_accumulate(e, used.data(), (int)used.size(), e->d_K);
+        if (rc) return rc;
+        return make_diag(e);
+    }
+    rc = run_variance_mode(e, approx_chains(e));
+    if (rc) return rc;
+    return make_diag(e);
+}
+
+int fsk_run_chains(fsk_engine* e, int32_t first, int32_t step) {
+    if (!e) return FSK_EINVAL;
+    if (e->group) return e->fail(FSK_ESTATE, "fsk_run_chains is a single-engine call: a group deals its chains itself (fsk_compute)");
+    if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
+    const fsk_config& c = e->cfg;
+    if (!c.approx || c.skip_variance) return e->fail(FSK_ESTATE, "fsk_run_chains is the variance mode (approx=1, skip_variance=0)");
+    if (first < 0 || step < 1) return e->fail(FSK_EINVAL, "need first >= 0 and step >= 1");
+    FSK_ON_DEVICE(e);
+    if (!e->order_set) default_order(e);
+    e->finalized = false;
+    return run_variance_mode(e, approx_chains(e), first, step);
+}
+
+}  // extern "C"
+
+namespace fsk_detail {
+
+int approx_chains(const fsk_engine* e) {
+    const int T = e->cfg.t == -1 ? 20 : e->cfg.t;  // fastsk_kernel.cpp:54-61
+    return std::max(1, std::min<int>(T, (int)e->order.size()));
+}
+
+void skip_variance_combos(fsk_engine* e, std::vector<int32_t>& used) {
+    const int T = approx_chains(e);
+    used.clear();
+    for (int tid = 0; tid < T; ++tid) {
+        int iters = 0;
+        for (size_t item = tid; item < e->order.size(); item += T) {
+            used.push_back(e->order[item]);
+            if (e->cfg.max_iters != -1 && ++iters >= e->cfg.max_iters) break;
+        }
+    }
+}
+
+int one_reset_counts(fsk_engine* e) {
     if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
     FSK_ON_DEVICE(e);
     if (lazy_zero_possible(e)) {
@@ -663,8 +808,7 @@ int fsk_reset_counts(fsk_engine* e) {
     return FSK_OK;
 }
 
-int fsk_reset_counts_rows(fsk_engine* e, int64_t row_begin, int64_t row_end) {
-    if (!e) return FSK_EINVAL;
+int one_reset_counts_rows(fsk_engine* e, int64_t row_begin, int64_t row_end) {
     if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
     if (row_begin < 0 || row_end > e->N || row_begin > row_end) return e->fail(FSK_EINVAL, "bad row range");
     FSK_ON_DEVICE(e);
@@ -681,31 +825,25 @@ int fsk_reset_counts_rows(fsk_engine* e, int64_t row_begin, int64_t row_end) {
     return FSK_OK;
 }
 
-int fsk_accumulate(fsk_engine* e, const int32_t* combos, int32_t n) {
-    if (!e) return FSK_EINVAL;
-    if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
-    if (n < 0 || (n > 0 && !combos)) return e->fail(FSK_EINVAL, "bad combo list");
-    if (n == 0) return FSK_OK;
-    FSK_ON_DEVICE(e);
-    e->finalized = false;
-    return do_accumulate(e, combos, n, e->d_K);
-}
-
-int fsk_accumulate_rows(fsk_engine* e, const int32_t* combos, int32_t n, int64_t row_begin, int64_t row_end) {
-    if (!e) return FSK_EINVAL;
+int one_accumulate_rows(fsk_engine* e, const int32_t* combos, int32_t n, int64_t row_begin, int64_t row_end) {
     if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
     if (n < 0 || (n > 0 && !combos)) return e->fail(FSK_EINVAL, "bad combo list");
     if (row_begin < 0 || row_end > e->N || row_begin > row_end || row_begin % fsk::TILE != 0 ||
         (row_end % fsk::TILE != 0 && row_end != e->N))
         return e->fail(FSK_EINVAL, "row band must be [a,b) with a, b multiples of %d (b may be N)", fsk::TILE);
-    if (n == 0 || row_begin == row_end) return FSK_OK;
+    if (row_begin == row_end) return FSK_OK;
     FSK_ON_DEVICE(e);
+    if (n == 0) {
+        // Nothing to add — but rows that a reset left to a storing launch get their zeros now: the caller
+        // may hand these rows to another stream next (fsk_stream_wait_engine), e.g. a rank of a job with
+        // more ranks than combos, whose share of the all-reduce must be zeros, not the previous pass.
+        return materialise_zero(e);
+    }
     e->finalized = false;
     return do_accumulate(e, combos, n, e->d_K, row_begin, row_end);
 }
 
-int fsk_synchronize(fsk_engine* e) {
-    if (!e) return FSK_EINVAL;
+int one_synchronize(fsk_engine* e) {
     FSK_ON_DEVICE(e);
     { int rcz = materialise_zero(e); if (rcz) return rcz; }
     FSK_HIP(hipStreamSynchronize(e->stream));
@@ -713,81 +851,16 @@ int fsk_synchronize(fsk_engine* e) {
     return FSK_OK;
 }
 
-// Ordering against a stream of the caller (torch's current stream, which RCCL collectives are
-// ordered after) without blocking the host: an event recorded on one stream, waited for by the other.
-int fsk_stream_wait_engine(fsk_engine* e, void* hip_stream) {
-    if (!e) return FSK_EINVAL;
-    FSK_ON_DEVICE(e);
-    if (!e->ev_order) FSK_HIP(hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming));
-    FSK_HIP(hipEventRecord(e->ev_order, e->stream));
-    FSK_HIP(hipStreamWaitEvent((hipStream_t)hip_stream, e->ev_order, 0));
-    return FSK_OK;
-}
-
-int fsk_engine_wait_stream(fsk_engine* e, void* hip_stream) {
-    if (!e) return FSK_EINVAL;
-    FSK_ON_DEVICE(e);
-    if (!e->ev_order) FSK_HIP(hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming));
-    FSK_HIP(hipEventRecord(e->ev_order, (hipStream_t)hip_stream));
-    FSK_HIP(hipStreamWaitEvent(e->stream, e->ev_order, 0));
-    return FSK_OK;
-}
-
-int fsk_finalize(fsk_engine* e) {
-    if (!e) return FSK_EINVAL;
+int one_finalize(fsk_engine* e) {
     if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
     FSK_ON_DEVICE(e);
     { int rcz = materialise_zero(e); if (rcz) return rcz; }
     return make_diag(e);
 }
 
-int fsk_compute(fsk_engine* e, const int32_t* tokens, const int64_t* offsets, int64_t n_train, int64_t n_test) {
-    if (!e) return FSK_EINVAL;
-    FSK_ON_DEVICE(e);
-    int rc = fsk_load_sequences(e, tokens, offsets, n_train, n_test);
-    if (rc) return rc;
-    const fsk_config& c = e->cfg;
-    if (!c.approx) {  // exact: every combination, order irrelevant (integer sum)
-        std::vector<int32_t> all((size_t)e->ncomb);
-        for (int64_t i = 0; i < e->ncomb; ++i) all[i] = (int32_t)i;
-        rc = do_accumulate(e, all.data(), (int)all.size(), e->d_K);
-        if (rc) return rc;
-        return make_diag(e);
-    }
-    if (!e->order_set) default_order(e);
-    int T = c.t == -1 ? 20 : c.t;  // fastsk_kernel.cpp:54-61
-    T = std::max(1, std::min<int>(T, (int)e->order.size()));
-    if (c.skip_variance) {  // chains only select which combos enter the integer sum
-        std::vector<int32_t> used;
-        for (int tid = 0; tid < T; ++tid) {
-            int iters = 0;
-            for (size_t item = tid; item < e->order.size(); item += T) {
-                used.push_back(e->order[item]);
-                if (c.max_iters != -1 && ++iters >= c.max_iters) break;
-            }
-        }
-        rc = do_accumulate(e, used.data(), (int)used.size(), e->d_K);
-        if (rc) return rc;
-        return make_diag(e);
-    }
-    rc = run_variance_mode(e, T);
-    if (rc) return rc;
-    return make_diag(e);
-}
+}  // namespace fsk_detail
 
-int fsk_run_chains(fsk_engine* e, int32_t first, int32_t step) {
-    if (!e) return FSK_EINVAL;
-    if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
-    const fsk_config& c = e->cfg;
-    if (!c.approx || c.skip_variance) return e->fail(FSK_ESTATE, "fsk_run_chains is the variance mode (approx=1, skip_variance=0)");
-    if (first < 0 || step < 1) return e->fail(FSK_EINVAL, "need first >= 0 and step >= 1");
-    FSK_ON_DEVICE(e);
-    if (!e->order_set) default_order(e);
-    int T = c.t == -1 ? 20 : c.t;  // fastsk_kernel.cpp:54-61
-    T = std::max(1, std::min<int>(T, (int)e->order.size()));
-    e->finalized = false;
-    return run_variance_mode(e, T, first, step);
-}
+extern "C" {
 
 int fsk_get_kernel_sum_device(fsk_engine* e, double* device_out) {
     if (!e) return FSK_EINVAL;
@@ -960,6 +1033,56 @@ int fsk_save_kernel(fsk_engine* e, const char* path) {
 
 int fsk_get_stats(fsk_engine* e, fsk_stats* out) {
     if (!e || !out) return FSK_EINVAL;
+    return e->group ? group_get_stats(e, out) : one_get_stats(e, out);
+}
+
+int fsk_counts_digest(fsk_engine* e, int64_t row_begin, int64_t row_end, uint64_t out[2]) {
+    if (!e || !out) return FSK_EINVAL;
+    if (!e->loaded) return e->fail(FSK_ESTATE, "load sequences first");
+    if (e->result_f64) return e->fail(FSK_ESTATE, "variance mode keeps a floating-point mean, not integer counts");
+    if (row_begin < 0 || row_end > e->N || row_begin > row_end) return e->fail(FSK_EINVAL, "bad row range");
+    FSK_ON_DEVICE(e);
+    { int rcz = materialise_zero(e); if (rcz) return rcz; }
+    const u64 c0 = (u64)row_begin * ((u64)row_begin + 1) / 2, c1 = (u64)row_end * ((u64)row_end + 1) / 2;
+    FSK_HIP(e->d_stage_u64.reserve(2));
+    FSK_HIP(hipMemsetAsync(e->d_stage_u64.p, 0, 2 * sizeof(u64), e->stream));
+    if (c1 > c0) {
+        const u64 per_block = (u64)256 * fsk::DG_ITEMS;
+        const uint32_t blocks = (uint32_t)std::min<u64>((c1 - c0 + per_block - 1) / per_block, (u64)1 << 16);
+        FSK_LAUNCH(fsk::k_digest, dim3(blocks), dim3(256), 0, e->stream, (const u64*)e->d_K, c0, c1 - c0, e->d_stage_u64.p);
+    }
+    FSK_HIP(hipMemcpyAsync(out, e->d_stage_u64.p, 2 * sizeof(u64), hipMemcpyDeviceToHost, e->stream));
+    FSK_HIP(hipStreamSynchronize(e->stream));
+    return FSK_OK;
+}
+
+int fsk_alloc_block_device(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1, double** device_out) {
+    if (!e || !device_out) return FSK_EINVAL;
+    *device_out = nullptr;
+    if (!e->finalized) return e->fail(FSK_ESTATE, "no finalized kernel: call fsk_compute or fsk_finalize first");
+    if (i0 < 0 || j0 < 0 || i1 > e->N || j1 > e->N || i0 > i1 || j0 > j1) return e->fail(FSK_EINVAL, "block out of range");
+    FSK_ON_DEVICE(e);
+    const size_t cells = (size_t)(i1 - i0) * (size_t)(j1 - j0);
+    double* p = nullptr;
+    if (hipMalloc((void**)&p, std::max<size_t>(1, cells) * sizeof(double)) != hipSuccess)
+        return e->fail(FSK_ENOMEM, "cannot allocate a %lld x %lld block on device %d", (long long)(i1 - i0), (long long)(j1 - j0), e->cfg.device);
+    const int rc = fsk_get_block_device(e, i0, i1, j0, j1, p);
+    if (rc) { (void)hipFree(p); return rc; }
+    *device_out = p;
+    return FSK_OK;
+}
+
+int fsk_free_device(fsk_engine* e, void* device_ptr) {
+    if (!device_ptr) return FSK_OK;
+    if (!e) return hipFree(device_ptr) == hipSuccess ? FSK_OK : FSK_EDEVICE;  // (the engine may be gone before its block)
+    FSK_ON_DEVICE(e);
+    FSK_HIP(hipFree(device_ptr));
+    return FSK_OK;
+}
+
+}  // extern "C"
+
+int fsk_detail::one_get_stats(fsk_engine* e, fsk_stats* out) {
     if (e->d_U.p && e->loaded) {
         DeviceScope on_device(e->cfg.device);
         u64 U = 0;
@@ -972,4 +1095,10 @@ int fsk_get_stats(fsk_engine* e, fsk_stats* out) {
     return FSK_OK;
 }
 
-}  // extern "C"
+extern "C" int fsk_set_skip_test_block(fsk_engine* e, int32_t skip) {
+    if (!e) return FSK_EINVAL;
+    if (e->group) return fsk_detail::group_set_skip_test_block(e, skip);
+    e->cfg.skip_test_block = skip ? 1 : 0;
+    e->tab_n = 0;  // (the tile table leaves out test x test tiles)
+    return FSK_OK;
+}

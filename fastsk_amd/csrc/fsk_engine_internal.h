@@ -88,7 +88,8 @@ struct fsk_engine {
     int64_t ncomb = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t ev_order = nullptr;       // fsk_stream_wait_engine / fsk_engine_wait_stream
+    hipEvent_t ev_out = nullptr, ev_in = nullptr;  // fsk_stream_wait_engine / fsk_engine_wait_stream: one event per direction
+    fsk_group* group = nullptr;          // fsk_create_multi: this engine leads a group (fsk_multi.hip); its other engines have none
     hipStream_t chain_stream = nullptr;  // variance mode: the sequential sums of a batch, under the next batches' kernels
     // fsk_reset_counts does not fill K when the next accumulate can STORE its sums instead of adding
     // them (dense dataflow, one workgroup per tile): rows [lazy_lo, lazy_hi) are zero by contract
@@ -223,6 +224,7 @@ constexpr u64 SX_MAX_LIST_WORDS = (u64)1 << 31;  // update words of one sparse b
 constexpr int FSK_RETRY_UNGROUPED = 1;  // internal: a per-slot sparse batch has to be redone one combo at a time
 
 // fsk_engine.hip
+void set_create_error(const std::string& msg);  // what fsk_last_error(NULL) reports (per thread)
 int64_t n_choose_k(int n, int k);
 int materialise_zero(fsk_engine* e);
 bool lazy_zero_possible(const fsk_engine* e);
@@ -245,5 +247,33 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
 
 // fsk_engine_variance.hip
 int run_variance_mode(fsk_engine* e, int T, int chain_first = 0, int chain_step = 1);
+
+// The single-engine bodies of the C-ABI calls that a group (fsk_create_multi) spreads over its engines;
+// the extern "C" entry points dispatch on fsk_engine::group. fsk_engine.hip.
+int one_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offsets, int64_t n_train, int64_t n_test);
+int one_reset_counts(fsk_engine* e);
+int one_reset_counts_rows(fsk_engine* e, int64_t row_begin, int64_t row_end);
+int one_accumulate_rows(fsk_engine* e, const int32_t* combos, int32_t n, int64_t row_begin, int64_t row_end);
+int one_synchronize(fsk_engine* e);
+int one_finalize(fsk_engine* e);
+int one_set_combo_order(fsk_engine* e, const int32_t* order, int32_t n);
+int one_get_stats(fsk_engine* e, fsk_stats* out);
+void one_destroy(fsk_engine* e);
+// the combos the approx modes accumulate as plain integer sums (skip_variance): fastsk_kernel.cpp:148,275
+void skip_variance_combos(fsk_engine* e, std::vector<int32_t>& used);
+int approx_chains(const fsk_engine* e);  // T of fastsk_kernel.cpp:54-61
+
+// fsk_multi.hip: the same calls on a group (e->group != nullptr)
+int group_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offsets, int64_t n_train, int64_t n_test);
+int group_reset_counts(fsk_engine* e, int64_t row_begin, int64_t row_end);
+int group_accumulate(fsk_engine* e, const int32_t* combos, int32_t n);
+int group_synchronize(fsk_engine* e);
+int group_finalize(fsk_engine* e);
+int group_compute(fsk_engine* e, const int32_t* tokens, const int64_t* offsets, int64_t n_train, int64_t n_test);
+int group_set_combo_order(fsk_engine* e, const int32_t* order, int32_t n);
+int group_set_seed(fsk_engine* e, uint64_t seed);
+int group_get_stats(fsk_engine* e, fsk_stats* out);
+int group_set_skip_test_block(fsk_engine* e, int32_t skip);
+void group_destroy(fsk_engine* e);
 
 }  // namespace fsk_detail

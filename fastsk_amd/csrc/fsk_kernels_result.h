@@ -64,4 +64,33 @@ __global__ __launch_bounds__(256) void k_triangle(const SrcT* K, const double* d
     out[t] = normalised_cell(x, diag[i], diag[j], i == j);
 }
 
+
+// Order-free digest of count cells [c0, c0 + count): out[0] += sum of the cells, out[1] ^= xor of
+// cell * (index | 1), both mod 2^64 (fsk_counts_digest). Streams the cells once, 16 bytes per load.
+constexpr int DG_ITEMS = 16;  // cells per thread and trip
+__global__ __launch_bounds__(256) void k_digest(const u64* K, u64 c0, u64 count, u64* out) {
+    u64 s = 0, x = 0;
+    const u64 stride = (u64)gridDim.x * 256 * DG_ITEMS;
+    for (u64 base = (u64)blockIdx.x * 256 * DG_ITEMS; base < count; base += stride) {
+#pragma unroll
+        for (int q = 0; q < DG_ITEMS; ++q) {
+            const u64 c = base + (u64)q * 256 + threadIdx.x;
+            if (c < count) {
+                const u64 v = K[c0 + c];
+                s += v;
+                x ^= v * ((c0 + c) | 1ull);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        s += __shfl_xor(s, d);
+        x ^= __shfl_xor(x, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (s) atomicAdd(&out[0], s);
+        if (x) atomicXor(&out[1], x);
+    }
+}
+
 }  // namespace fsk

@@ -1,0 +1,693 @@
+// fsk_multi.hip — ONE engine over several GPUs of this process: fsk_create_multi and the group forms of the
+// C-ABI calls (include/fastsk_amd.h).
+//
+// What it replaces: KernelFunction::compute_kernel fans one call out over t host threads — thread r takes
+// work items r, r + T, ... (fastsk_kernel.cpp:54-93, 148, 275) — and the threads add their private triangles
+// into K under range locks (fastsk_kernel.cpp:286-315). Here engine r of R lives on devices[r] with a replica
+// of the packed sequences, a host thread of its own and a HIP stream pair (compute, exchange); it takes
+// combos r, r + R, ... of every accumulate, and the partial triangles are summed by ONE logical all-reduce:
+// RCCL's ncclAllReduce over xGMI (librccl is bound with dlopen, next to the HIP runtime the process already
+// uses — no link-time dependency, and no second copy beside torch's), or the engine's own peer-mapped
+// reduce-scatter + all-gather kernels (FSK_COLL_P2P). The all-reduce is issued per equal-area row band on the
+// exchange stream while the compute stream accumulates the next band, ordered by events, never by the host;
+// as int32 when C(g,m) * max_windows^2 < 2^31 (half the link bytes). Integer sums are order free, so the
+// result is bit-identical to one engine's for every R. Variance mode deals the T Welford chains over the
+// engines and sums their K_hat with one fp64 all-reduce.
+#include "fsk_engine_internal.h"
+#include "fsk_kernels_exchange.h"
+
+#ifndef FSK_EMU
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#endif
+
+using namespace fsk_detail;
+
+namespace {
+
+// reusable barrier of the group's worker threads (host side only: nobody waits for a GPU here)
+struct HostBarrier {
+    std::mutex m;
+    std::condition_variable cv;
+    int n = 1, arrived = 0;
+    unsigned gen = 0;
+    void wait() {
+        std::unique_lock<std::mutex> lk(m);
+        const unsigned g = gen;
+        if (++arrived == n) { arrived = 0; ++gen; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+
+// one persistent host thread per engine; run(fn) executes fn(r) on thread r for every r and returns the codes
+struct WorkerPool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv_go, cv_done;
+    const std::function<int(int)>* fn = nullptr;
+    std::vector<int> rc;
+    unsigned gen = 0;
+    int pending = 0;
+    bool stop = false;
+    void start(int n) {
+        rc.assign((size_t)n, 0);
+        for (int r = 0; r < n; ++r)
+            th.emplace_back([this, r] {
+                unsigned seen = 0;
+                for (;;) {
+                    const std::function<int(int)>* f;
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cv_go.wait(lk, [&] { return stop || gen != seen; });
+                        if (stop) return;
+                        seen = gen;
+                        f = fn;
+                    }
+                    const int code = (*f)(r);
+                    std::lock_guard<std::mutex> lk(m);
+                    rc[(size_t)r] = code;
+                    if (--pending == 0) cv_done.notify_all();
+                }
+            });
+    }
+    void run(const std::function<int(int)>& f) {
+        std::unique_lock<std::mutex> lk(m);
+        fn = &f;
+        pending = (int)th.size();
+        ++gen;
+        cv_go.notify_all();
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv_go.notify_all();
+        for (auto& t : th) t.join();
+        th.clear();
+    }
+};
+
+enum class XType { I32, U64, F64 };
+size_t xsize(XType t) { return t == XType::I32 ? 4 : 8; }
+
+// In-place sum of `count` elements over the R engines' buffers; rank r's worker thread calls it with its own
+// buffer and stream, every rank the same sequence of calls. Asynchronous on `stream`.
+struct Collective {
+    int kind = 0, ranks = 0;
+    virtual ~Collective() {}
+    virtual int all_reduce(int r, void* buf, size_t count, XType type, hipStream_t stream, std::string& err) = 0;
+};
+
+// ---- FSK_COLL_P2P ----------------------------------------------------------------------------------------
+// rank r: record "my buffer is ready"; (host barrier: every rank's pointer and event are in place) wait for
+// the others' events; sum slice r over all buffers, write it to all; record "my slice is done"; (host
+// barrier) wait for the others' slices. The barrier of the NEXT call keeps a fast rank from re-recording
+// `done` before a slow one has enqueued its wait; `ready` is protected by this call's second barrier.
+struct P2PCollective : Collective {
+    std::vector<int> dev;
+    std::vector<void*> buf;
+    std::vector<hipEvent_t> ready, done;
+    HostBarrier bar;
+    int init(const std::vector<int>& devices, std::string& err) {
+        kind = FSK_COLL_P2P;
+        ranks = (int)devices.size();
+        dev = devices;
+        buf.assign(dev.size(), nullptr);
+        ready.assign(dev.size(), nullptr);
+        done.assign(dev.size(), nullptr);
+        bar.n = ranks;
+        for (size_t r = 0; r < dev.size(); ++r) {
+            DeviceScope on(dev[r]);
+            if (on.err != hipSuccess || hipEventCreateWithFlags(&ready[r], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&done[r], hipEventDisableTiming) != hipSuccess) {
+                err = "cannot create the events of the peer-to-peer exchange";
+                return FSK_EDEVICE;
+            }
+#ifndef FSK_EMU
+            for (size_t q = 0; q < dev.size(); ++q) {
+                if (dev[q] == dev[r]) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, dev[r], dev[q]) != hipSuccess || !can) {
+                    err = "device " + std::to_string(dev[r]) + " cannot map the memory of device " + std::to_string(dev[q]);
+                    return FSK_EDEVICE;
+                }
+                const hipError_t pe = hipDeviceEnablePeerAccess(dev[q], 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+                    err = std::string("hipDeviceEnablePeerAccess failed: ") + hipGetErrorString(pe);
+                    return FSK_EDEVICE;
+                }
+                (void)hipGetLastError();
+            }
+#endif
+        }
+        return FSK_OK;
+    }
+    ~P2PCollective() override {
+        for (size_t r = 0; r < dev.size(); ++r) {
+            DeviceScope on(dev[r]);
+            if (ready[r]) (void)hipEventDestroy(ready[r]);
+            if (done[r]) (void)hipEventDestroy(done[r]);
+        }
+    }
+    template <typename T, int PER>
+    void launch(int r, size_t count, hipStream_t stream) {
+        fsk::PeerBufs pb{};
+        bool aligned = true;
+        for (int q = 0; q < ranks; ++q) {
+            pb.p[q] = buf[(size_t)q];
+            aligned = aligned && (reinterpret_cast<uintptr_t>(buf[(size_t)q]) % 16 == 0);
+        }
+        const u64 R = (u64)ranks;
+        if (aligned && count >= (size_t)PER * 1024) {
+            const u64 pieces = count / PER;
+            const u64 lo = pieces * (u64)r / R, hi = pieces * ((u64)r + 1) / R;
+            if (hi > lo) {
+                const uint32_t blocks = (uint32_t)std::min<u64>((hi - lo + 255) / 256, 8192);
+                auto k = fsk::k_p2p_allreduce_wide<T, PER>;
+                FSK_LAUNCH(k, dim3(blocks), dim3(256), 0, stream, pb, ranks, lo, hi);
+            }
+            if (r == ranks - 1 && pieces * PER < count)  // the tail that is not a whole 16-byte piece
+                FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_p2p_allreduce<T>), dim3(1), dim3(256), 0, stream, pb, ranks, pieces * PER, (u64)count);
+        } else {
+            const u64 lo = (u64)count * (u64)r / R, hi = (u64)count * ((u64)r + 1) / R;
+            if (hi > lo) {
+                const uint32_t blocks = (uint32_t)std::min<u64>((hi - lo + 255) / 256, 8192);
+                FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_p2p_allreduce<T>), dim3(blocks), dim3(256), 0, stream, pb, ranks, lo, hi);
+            }
+        }
+    }
+    int all_reduce(int r, void* b, size_t count, XType type, hipStream_t stream, std::string& err) override {
+        buf[(size_t)r] = b;
+        hipError_t he = hipEventRecord(ready[(size_t)r], stream);
+        bar.wait();
+        for (int q = 0; q < ranks && he == hipSuccess; ++q)
+            if (q != r) he = hipStreamWaitEvent(stream, ready[(size_t)q], 0);
+        if (he == hipSuccess && count > 0) {
+            if (type == XType::I32) launch<int32_t, 4>(r, count, stream);
+            else if (type == XType::U64) launch<u64, 2>(r, count, stream);
+            else launch<double, 2>(r, count, stream);
+            he = hipGetLastError();
+        }
+        if (he == hipSuccess) he = hipEventRecord(done[(size_t)r], stream);
+        bar.wait();
+        for (int q = 0; q < ranks && he == hipSuccess; ++q)
+            if (q != r) he = hipStreamWaitEvent(stream, done[(size_t)q], 0);
+        if (he != hipSuccess) {
+            err = std::string("peer-to-peer all-reduce: ") + hipGetErrorString(he);
+            return FSK_EDEVICE;
+        }
+        return FSK_OK;
+    }
+};
+
+// ---- FSK_COLL_RCCL ---------------------------------------------------------------------------------------
+#ifndef FSK_EMU
+struct RcclApi {
+    void* handle = nullptr;
+    std::string path;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+};
+
+// librccl of the ROCm the process already runs on: the image that is mapped (torch's, when torch is
+// imported), else the one beside libamdhip64, else the loader's default search.
+RcclApi* rccl_api(std::string& err) {
+    static std::mutex m;
+    static RcclApi api;
+    static bool tried = false;
+    static std::string why;
+    std::lock_guard<std::mutex> lk(m);
+    if (!tried) {
+        tried = true;
+        std::vector<std::string> names;
+        void* h = nullptr;
+        for (const char* soname : {"librccl.so.1", "librccl.so"}) {
+            h = dlopen(soname, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+            if (h) { api.path = std::string(soname) + " (already mapped)"; break; }
+        }
+        if (!h) {
+            Dl_info info{};
+            if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+                std::string dir(info.dli_fname);
+                const size_t slash = dir.rfind('/');
+                if (slash != std::string::npos) {
+                    dir.resize(slash + 1);
+                    names.push_back(dir + "librccl.so.1");
+                    names.push_back(dir + "librccl.so");
+                }
+            }
+            names.push_back("librccl.so.1");
+            names.push_back("librccl.so");
+            names.push_back("/opt/rocm/lib/librccl.so.1");
+            for (const std::string& n : names) {
+                h = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
+                if (h) { api.path = n; break; }
+            }
+        }
+        if (!h) {
+            why = "librccl not found (tried the mapped image, the directory of the HIP runtime, the loader path)";
+        } else {
+            api.handle = h;
+            api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+            api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+            api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
+            api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(h, "ncclCommCount"));
+            api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+            api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(dlsym(h, "ncclGetVersion"));
+            if (!api.CommInitAll || !api.CommDestroy || !api.AllReduce || !api.GetErrorString) {
+                why = "librccl (" + api.path + ") lacks ncclCommInitAll / ncclAllReduce";
+                api.handle = nullptr;
+            }
+        }
+    }
+    if (!api.handle) { err = why; return nullptr; }
+    return &api;
+}
+
+struct RcclCollective : Collective {
+    RcclApi* api = nullptr;
+    std::vector<ncclComm_t> comm;
+    std::vector<int> dev;
+    int init(const std::vector<int>& devices, std::string& err) {
+        kind = FSK_COLL_RCCL;
+        api = rccl_api(err);
+        if (!api) return FSK_EDEVICE;
+        dev = devices;
+        comm.assign(dev.size(), nullptr);
+        const ncclResult_t r = api->CommInitAll(comm.data(), (int)dev.size(), dev.data());
+        if (r != ncclSuccess) {
+            err = std::string("ncclCommInitAll failed: ") + api->GetErrorString(r);
+            comm.clear();
+            return FSK_EDEVICE;
+        }
+        ranks = (int)dev.size();
+        if (api->CommCount) {
+            int n = 0;
+            if (api->CommCount(comm[0], &n) == ncclSuccess) ranks = n;
+        }
+        return FSK_OK;
+    }
+    ~RcclCollective() override {
+        for (size_t r = 0; r < comm.size(); ++r)
+            if (comm[r]) {
+                DeviceScope on(dev[r]);
+                (void)api->CommDestroy(comm[r]);
+            }
+    }
+    int all_reduce(int r, void* b, size_t count, XType type, hipStream_t stream, std::string& err) override {
+        if (count == 0) return FSK_OK;
+        const ncclDataType_t t = type == XType::I32 ? ncclInt32 : type == XType::U64 ? ncclUint64 : ncclFloat64;
+        const ncclResult_t rc = api->AllReduce(b, b, count, t, ncclSum, comm[(size_t)r], stream);
+        if (rc != ncclSuccess) {
+            err = std::string("ncclAllReduce failed: ") + api->GetErrorString(rc);
+            return FSK_EDEVICE;
+        }
+        return FSK_OK;
+    }
+};
+#endif  // !FSK_EMU
+
+int64_t cell_of(int64_t row) { return row * (row + 1) / 2; }
+
+// row boundaries (multiples of the tile edge, last = N) that cut the lower triangle into bands of about equal area
+std::vector<int64_t> band_edges(int64_t N, int n_bands) {
+    std::vector<int64_t> e{0};
+    for (int b = 1; b < n_bands; ++b) {
+        const int64_t r = (int64_t)std::llround((double)N * std::sqrt((double)b / n_bands) / fsk::TILE) * fsk::TILE;
+        if (r > e.back() && r < N) e.push_back(r);
+    }
+    e.push_back(N);
+    return e;
+}
+
+}  // namespace
+
+struct fsk_group {
+    std::vector<fsk_engine*> member;  // member[0] is the handle the caller holds
+    std::vector<int> device;
+    std::unique_ptr<Collective> coll;
+    std::vector<hipStream_t> xstream;            // the exchange stream of every engine
+    std::vector<hipEvent_t> ev_band, ev_xdone;   // compute -> exchange, exchange -> compute
+    std::vector<DevBuf<int32_t>> stage;          // a band of the triangle narrowed to int32
+    WorkerPool pool;
+    HostBarrier bar;
+    std::atomic<int> failed{0};
+    bool others_hold_total = false;   // engines 1.. hold a REDUCED triangle: zero them before they accumulate again
+    int64_t combos_since_reset = 0;   // bounds the cells of engine 0's triangle (narrowing)
+    fsk_multi_info info{};
+
+    int R() const { return (int)member.size(); }
+    // every worker reports its code; all leave together with the first failure (nobody is left waiting
+    // inside a collective for a rank that gave up)
+    bool agree(int rc) {
+        if (rc) failed.store(rc);
+        bar.wait();
+        const bool ok = failed.load() == 0;
+        bar.wait();
+        return ok;
+    }
+    // run fn on every engine's thread; the first failing engine's message becomes the handle's
+    int run(const std::function<int(int)>& fn) {
+        failed.store(0);
+        pool.run(fn);
+        for (int r = 0; r < R(); ++r)
+            if (pool.rc[(size_t)r]) {
+                if (r != 0) member[0]->err = "device " + std::to_string(device[(size_t)r]) + ": " + member[(size_t)r]->err;
+                return pool.rc[(size_t)r];
+            }
+        return FSK_OK;
+    }
+};
+
+namespace {
+
+// engine r's share of one accumulate: its combos over every band, each band's all-reduce on the exchange
+// stream behind an event, under the next band's kernels
+int member_accumulate(fsk_group* g, int r, const std::vector<int32_t>& mine, const std::vector<int64_t>& edges, bool narrow) {
+    fsk_engine* e = g->member[(size_t)r];
+    FSK_ON_DEVICE(e);
+    int rc = FSK_OK;
+    if (r > 0 && g->others_hold_total) rc = one_reset_counts(e);
+    hipStream_t xs = g->xstream[(size_t)r];
+    // After the ranks have agreed to go on, nothing below leaves early: a rank that skipped a collective
+    // would leave the others' exchange streams waiting for it for ever. Failures are collected and reported
+    // at the end (the exchange then ran on whatever the triangle held).
+    auto note = [&](hipError_t he, const char* what) {
+        if (he != hipSuccess && !rc) rc = e->fail(FSK_EDEVICE, "%s failed: %s", what, hipGetErrorString(he));
+    };
+    for (size_t b = 0; b + 1 < edges.size(); ++b) {
+        const int64_t lo = edges[b], hi = edges[b + 1];
+        if (!rc) rc = one_accumulate_rows(e, mine.data(), (int32_t)mine.size(), lo, hi);
+        if (!g->agree(rc)) return rc ? rc : e->fail(FSK_EDEVICE, "another engine of the group failed");
+        const u64 c0 = (u64)cell_of(lo), cells = (u64)cell_of(hi) - c0;
+        note(hipEventRecord(g->ev_band[(size_t)r], e->stream), "hipEventRecord");
+        note(hipStreamWaitEvent(xs, g->ev_band[(size_t)r], 0), "hipStreamWaitEvent");
+        std::string cerr;
+        int crc;
+        if (narrow) {
+            int32_t* st = g->stage[(size_t)r].p;
+            const uint32_t blocks = (uint32_t)std::min<u64>((cells + 255) / 256, 16384);
+            FSK_LAUNCH(fsk::k_narrow_u64_i32, dim3(blocks), dim3(256), 0, xs, (const u64*)(e->d_K + c0), st, cells);
+            crc = g->coll->all_reduce(r, st, (size_t)cells, XType::I32, xs, cerr);
+            FSK_LAUNCH(fsk::k_widen_i32_u64, dim3(blocks), dim3(256), 0, xs, (const int32_t*)st, e->d_K + c0, cells);
+        } else {
+            crc = g->coll->all_reduce(r, e->d_K + c0, (size_t)cells, XType::U64, xs, cerr);
+        }
+        if (crc && !rc) rc = e->fail(crc, "%s", cerr.c_str());
+        note(hipGetLastError(), "exchange kernels");
+    }
+    // the engine's next work (finalize, getters, another accumulate) starts after the reduced cells are in place
+    note(hipEventRecord(g->ev_xdone[(size_t)r], xs), "hipEventRecord");
+    note(hipStreamWaitEvent(e->stream, g->ev_xdone[(size_t)r], 0), "hipStreamWaitEvent");
+    return rc;
+}
+
+int group_sum_combos(fsk_engine* lead, const int32_t* combos, int32_t n) {
+    fsk_group* g = lead->group;
+    const int R = g->R();
+    const int64_t N = lead->N;
+    std::vector<std::vector<int32_t>> mine((size_t)R);
+    for (int32_t i = 0; i < n; ++i) mine[(size_t)(i % R)].push_back(combos[i]);  // fastsk_kernel.cpp:148,275
+    // bands: more, smaller bands leave less of the last band's exchange exposed — as long as a band's tile
+    // launch keeps one workgroup per tile (>= 16384 tiles), the form that stores instead of adding
+    int n_bands = lead->cfg.bands;
+    if (n_bands <= 0) {
+        const int64_t tr = (N + fsk::TILE - 1) / fsk::TILE, tiles = tr * (tr + 1) / 2;
+        n_bands = (lead->path == FSK_PATH_DENSE && N >= 8192) ? (tiles >= 16 * 16384 ? 16 : 8) : 1;
+    }
+    const std::vector<int64_t> edges = band_edges(N, std::max(1, std::min(n_bands, 64)));
+    g->combos_since_reset += n;
+    const double bound = (double)g->combos_since_reset * (double)lead->maxW * (double)lead->maxW;
+    const bool narrow = bound < 2147483648.0;  // every cell of every engine: <= combos since the reset x max_windows^2
+    u64 largest = 0;
+    for (size_t b = 0; b + 1 < edges.size(); ++b) largest = std::max<u64>(largest, (u64)(cell_of(edges[b + 1]) - cell_of(edges[b])));
+    g->info.bands = (int32_t)edges.size() - 1;
+    g->info.narrow = narrow ? 1 : 0;
+    g->info.reduce_bytes = (int64_t)((u64)lead->pairs * (narrow ? 4 : 8));
+    g->info.comm_ranks = g->coll->ranks;
+    for (int r = 0; r < R && r < 16; ++r) g->info.combos_per_engine[r] = (int64_t)mine[(size_t)r].size();
+    const int rc = g->run([&](int r) -> int {
+        fsk_engine* e = g->member[(size_t)r];
+        int rc1 = FSK_OK;
+        if (narrow) {
+            DeviceScope on(e->cfg.device);
+            if (g->stage[(size_t)r].reserve((size_t)largest) != hipSuccess)
+                rc1 = e->fail(FSK_ENOMEM, "cannot allocate %llu bytes of exchange staging", (unsigned long long)(largest * 4));
+        }
+        if (!g->agree(rc1)) return rc1 ? rc1 : e->fail(FSK_EDEVICE, "another engine of the group failed");
+        return member_accumulate(g, r, mine[(size_t)r], edges, narrow);
+    });
+    g->others_hold_total = true;
+    return rc;
+}
+
+}  // namespace
+
+// =============================================================================================
+namespace fsk_detail {
+
+int group_load_sequences(fsk_engine* lead, const int32_t* tokens, const int64_t* offsets, int64_t n_train, int64_t n_test) {
+    fsk_group* g = lead->group;
+    g->others_hold_total = false;
+    g->combos_since_reset = 0;
+    return g->run([&](int r) { return one_load_sequences(g->member[(size_t)r], tokens, offsets, n_train, n_test); });
+}
+
+int group_reset_counts(fsk_engine* lead, int64_t row_begin, int64_t row_end) {
+    fsk_group* g = lead->group;
+    const bool whole = row_end < 0;
+    if (whole) {
+        g->others_hold_total = false;
+        g->combos_since_reset = 0;
+    }
+    return g->run([&](int r) {
+        fsk_engine* e = g->member[(size_t)r];
+        return whole ? one_reset_counts(e) : one_reset_counts_rows(e, row_begin, row_end);
+    });
+}
+
+int group_accumulate(fsk_engine* lead, const int32_t* combos, int32_t n) {
+    for (int32_t i = 0; i < n; ++i)
+        if (combos[i] < 0 || combos[i] >= lead->ncomb) return lead->fail(FSK_EINVAL, "combo id %d out of range [0,%lld)", combos[i], (long long)lead->ncomb);
+    if (n == 0) return FSK_OK;
+    lead->finalized = false;
+    return group_sum_combos(lead, combos, n);
+}
+
+int group_synchronize(fsk_engine* lead) {
+    fsk_group* g = lead->group;
+    return g->run([&](int r) { return one_synchronize(g->member[(size_t)r]); });
+}
+
+int group_finalize(fsk_engine* lead) {
+    const int rc = group_synchronize(lead);  // every engine's share of the exchange has landed
+    return rc ? rc : one_finalize(lead);
+}
+
+int group_set_combo_order(fsk_engine* lead, const int32_t* order, int32_t n) {
+    for (fsk_engine* e : lead->group->member) {
+        const int rc = one_set_combo_order(e, order, n);
+        if (rc) { if (e != lead) lead->err = e->err; return rc; }
+    }
+    return FSK_OK;
+}
+
+int group_set_seed(fsk_engine* lead, uint64_t seed) {
+    for (fsk_engine* e : lead->group->member) e->seed = seed;
+    return FSK_OK;
+}
+
+int group_set_skip_test_block(fsk_engine* lead, int32_t skip) {
+    for (fsk_engine* e : lead->group->member) {
+        e->cfg.skip_test_block = skip ? 1 : 0;
+        e->tab_n = 0;
+    }
+    return FSK_OK;
+}
+
+int group_get_stats(fsk_engine* lead, fsk_stats* out) {
+    fsk_group* g = lead->group;
+    int rc = one_get_stats(lead, out);
+    for (int r = 1; r < g->R() && !rc; ++r) {  // what the group did: sums; HIP-event times stay engine 0's
+        fsk_stats s;
+        rc = one_get_stats(g->member[(size_t)r], &s);
+        out->combos_done += s.combos_done;  // (variance mode: the iterations of every chain)
+        out->cell_updates += s.cell_updates;
+        out->sort_records += s.sort_records;
+        out->launches += s.launches;
+        out->dense_macs += s.dense_macs;
+        out->panel_bytes += s.panel_bytes;
+    }
+    // integer modes: engines 1.. start every accumulate from a reset triangle (and a reset counter)
+    if (!lead->result_f64) out->combos_done = g->combos_since_reset;
+    return rc;
+}
+
+int group_compute(fsk_engine* lead, const int32_t* tokens, const int64_t* offsets, int64_t n_train, int64_t n_test) {
+    fsk_group* g = lead->group;
+    int rc = group_load_sequences(lead, tokens, offsets, n_train, n_test);
+    if (rc) return rc;
+    const fsk_config& c = lead->cfg;
+    if (!c.approx) {  // exact: every combination
+        std::vector<int32_t> all((size_t)lead->ncomb);
+        for (int64_t i = 0; i < lead->ncomb; ++i) all[(size_t)i] = (int32_t)i;
+        rc = group_sum_combos(lead, all.data(), (int32_t)all.size());
+        return rc ? rc : group_finalize(lead);
+    }
+    if (!lead->order_set) {  // one seeded order, the same on every engine
+        default_order(lead);
+        for (fsk_engine* e : g->member) e->order = lead->order;
+    }
+    if (c.skip_variance) {
+        std::vector<int32_t> used;
+        skip_variance_combos(lead, used);
+        rc = group_sum_combos(lead, used.data(), (int32_t)used.size());
+        return rc ? rc : group_finalize(lead);
+    }
+    // variance mode: chain t on engine t mod R, then the sum of fastsk_kernel.cpp:286-315 over the engines
+    const int T = approx_chains(lead), R = g->R();
+    rc = g->run([&](int r) -> int {
+        fsk_engine* e = g->member[(size_t)r];
+        FSK_ON_DEVICE(e);
+        e->finalized = false;
+        int rc1 = run_variance_mode(e, T, r, R);
+        if (!g->agree(rc1)) return rc1 ? rc1 : e->fail(FSK_EDEVICE, "another engine of the group failed");
+        std::string cerr;
+        rc1 = g->coll->all_reduce(r, e->d_Kf64.p, (size_t)e->pairs, XType::F64, e->stream, cerr);
+        if (rc1) return e->fail(rc1, "%s", cerr.c_str());
+        FSK_HIP(hipStreamSynchronize(e->stream));
+        return FSK_OK;
+    });
+    g->info.bands = 1;
+    g->info.narrow = 0;
+    g->info.reduce_bytes = lead->pairs * 8;
+    g->info.comm_ranks = g->coll->ranks;
+    return rc ? rc : one_finalize(lead);
+}
+
+void group_destroy(fsk_engine* lead) {
+    fsk_group* g = lead->group;
+    lead->group = nullptr;
+    for (int r = 0; r < g->R(); ++r) {  // nothing of the exchange may still be in flight
+        DeviceScope on(g->device[(size_t)r]);
+        if (g->xstream[(size_t)r]) (void)hipStreamSynchronize(g->xstream[(size_t)r]);
+        (void)hipStreamSynchronize(g->member[(size_t)r]->stream);
+    }
+    g->pool.shutdown();
+    g->coll.reset();
+    for (int r = 0; r < g->R(); ++r) {
+        DeviceScope on(g->device[(size_t)r]);
+        g->stage[(size_t)r].release();
+        if (g->ev_band[(size_t)r]) (void)hipEventDestroy(g->ev_band[(size_t)r]);
+        if (g->ev_xdone[(size_t)r]) (void)hipEventDestroy(g->ev_xdone[(size_t)r]);
+        if (g->xstream[(size_t)r]) (void)hipStreamDestroy(g->xstream[(size_t)r]);
+    }
+    for (fsk_engine* e : g->member) one_destroy(e);
+    delete g;
+}
+
+}  // namespace fsk_detail
+
+// =============================================================================================
+extern "C" {
+
+int fsk_create_multi(const fsk_config* cfg, const int32_t* devices, int32_t ndev, fsk_engine** out) {
+    if (!cfg || !out || !devices) { set_create_error("null argument"); return FSK_EINVAL; }
+    *out = nullptr;
+    if (ndev < 1 || ndev > 16) { set_create_error("need 1..16 devices"); return FSK_EINVAL; }
+    int collective = cfg->collective;
+    if (const char* f = getenv("FSK_MULTI_COLLECTIVE")) {
+        if (!strcmp(f, "p2p")) collective = FSK_COLL_P2P;
+        else if (!strcmp(f, "rccl")) collective = FSK_COLL_RCCL;
+    }
+    if (collective != FSK_COLL_AUTO && collective != FSK_COLL_RCCL && collective != FSK_COLL_P2P) {
+        set_create_error("collective must be FSK_COLL_AUTO, FSK_COLL_RCCL or FSK_COLL_P2P");
+        return FSK_EINVAL;
+    }
+    bool distinct = true;
+    for (int a = 0; a < ndev; ++a)
+        for (int b = a + 1; b < ndev; ++b) distinct = distinct && devices[a] != devices[b];
+    if (!distinct && collective == FSK_COLL_RCCL) {
+        set_create_error("RCCL needs distinct devices (a device listed twice runs over FSK_COLL_P2P)");
+        return FSK_EINVAL;
+    }
+    std::unique_ptr<fsk_group> g(new fsk_group);
+    auto undo = [&](int rc, const std::string& msg) {
+        g->coll.reset();
+        for (size_t r = 0; r < g->member.size(); ++r) {
+            DeviceScope on(g->device[r]);
+            if (r < g->ev_band.size() && g->ev_band[r]) (void)hipEventDestroy(g->ev_band[r]);
+            if (r < g->ev_xdone.size() && g->ev_xdone[r]) (void)hipEventDestroy(g->ev_xdone[r]);
+            if (r < g->xstream.size() && g->xstream[r]) (void)hipStreamDestroy(g->xstream[r]);
+        }
+        for (fsk_engine* e : g->member) one_destroy(e);
+        set_create_error(msg);
+        return rc;
+    };
+    for (int r = 0; r < ndev; ++r) {
+        fsk_config c = *cfg;
+        c.device = devices[r];
+        fsk_engine* e = nullptr;
+        const int rc = fsk_create(&c, &e);
+        if (rc) return undo(rc, std::string("device ") + std::to_string(devices[r]) + ": " + fsk_last_error(nullptr));
+        g->member.push_back(e);
+        g->device.push_back(devices[r]);
+    }
+    g->xstream.assign((size_t)ndev, nullptr);
+    g->ev_band.assign((size_t)ndev, nullptr);
+    g->ev_xdone.assign((size_t)ndev, nullptr);
+    g->stage.resize((size_t)ndev);
+    for (int r = 0; r < ndev; ++r) {
+        DeviceScope on(devices[r]);
+        if (on.err != hipSuccess || hipStreamCreateWithFlags(&g->xstream[(size_t)r], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&g->ev_band[(size_t)r], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g->ev_xdone[(size_t)r], hipEventDisableTiming) != hipSuccess)
+            return undo(FSK_EDEVICE, "cannot create the exchange stream / events on device " + std::to_string(devices[r]));
+    }
+    const std::vector<int> devs(devices, devices + ndev);
+    std::string why;
+#ifndef FSK_EMU
+    if (collective != FSK_COLL_P2P && distinct) {
+        std::unique_ptr<RcclCollective> rc(new RcclCollective);
+        const int code = rc->init(devs, why);
+        if (code == FSK_OK) g->coll = std::move(rc);
+        else if (collective == FSK_COLL_RCCL) return undo(code, why);
+    }
+#else
+    if (collective == FSK_COLL_RCCL) return undo(FSK_EUNSUPPORTED, "no RCCL in this build");
+#endif
+    if (!g->coll) {
+        std::unique_ptr<P2PCollective> p(new P2PCollective);
+        const int code = p->init(devs, why);
+        if (code) return undo(code, why);
+        g->coll = std::move(p);
+    }
+    g->bar.n = ndev;
+    g->info.ndev = ndev;
+    for (int r = 0; r < ndev; ++r) g->info.devices[r] = devices[r];
+    g->info.collective = g->coll->kind;
+    g->info.comm_ranks = g->coll->ranks;
+    g->pool.start(ndev);
+    fsk_engine* lead = g->member[0];
+    lead->group = g.release();
+    *out = lead;
+    return FSK_OK;
+}
+
+int fsk_get_multi_info(fsk_engine* e, fsk_multi_info* out) {
+    if (!e || !out) return FSK_EINVAL;
+    if (!e->group) {
+        *out = fsk_multi_info{};
+        return FSK_OK;
+    }
+    *out = e->group->info;
+    return FSK_OK;
+}
+
+}  // extern "C"

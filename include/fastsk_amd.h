@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FSK_ABI_VERSION 1
+#define FSK_ABI_VERSION 2  /* 2: fsk_create_multi + fsk_config.collective/shard/bands, fsk_counts_digest, device-block allocation */
 
 enum {
     FSK_OK = 0,
@@ -48,6 +48,15 @@ enum {
                             64-bit atomicAdd per cell                                            */
     FSK_PATH_SPARSE = 2  /* radix sort of (k-mer, seq) -> run-length segments -> 64-bit atomicAdd
                             per (run, pair): the reference's dataflow, cntsrtna+countAndUpdateTri */
+};
+
+/* how the engines of fsk_create_multi sum their partial triangles (fastsk_kernel.cpp:286-315) */
+enum {
+    FSK_COLL_AUTO = 0,   /* RCCL when the listed devices are distinct and librccl can be loaded, else P2P  */
+    FSK_COLL_RCCL = 1,   /* ncclAllReduce over xGMI, one communicator rank per listed device               */
+    FSK_COLL_P2P = 2     /* the engine's own reduce-scatter + all-gather kernels over peer mappings (all
+                            devices live in this process); also what lets a device be listed twice, i.e.
+                            the multi-device host code exercised on a single GPU                          */
 };
 
 typedef struct fsk_engine fsk_engine; /* opaque; replaces class FastSK + KernelFunction state */
@@ -70,7 +79,10 @@ typedef struct fsk_config {
                                 (fastsk.cpp:190-217). Dense dataflow: whole tiles of such cells
                                 are not computed; sparse dataflow: a test row pairs only with the
                                 train sequences of its k-mer runs (and itself).                 */
-    int32_t reserved[4];
+    /* fsk_create_multi only (ignored by fsk_create): */
+    int32_t collective;    /* FSK_COLL_*                                                          */
+    int32_t bands;         /* row bands of the overlapped all-reduce; 0 = automatic               */
+    int32_t reserved[2];
 } fsk_config;
 
 /* Measured and algorithmic quantities of the work done so far. */
@@ -108,6 +120,32 @@ typedef struct fsk_stats {
 /* ---- lifecycle: replaces FastSK::FastSK (fastsk.cpp:19-28) and ~nothing (the reference leaks) */
 int fsk_create(const fsk_config* cfg, fsk_engine** out);
 void fsk_destroy(fsk_engine* e);
+/* One engine over SEVERAL GPUs of this process — what FastSK(..., devices=[0,1,...]) creates. The reference
+ * fans one compute_kernel call out over t host threads (fastsk_kernel.cpp:54-93: thread r takes work items
+ * r, r+T, ...) and sum-reduces their private triangles (fastsk_kernel.cpp:286-315); here engine r of R lives
+ * on devices[r], holds a replica of the packed sequences, takes combos r, r+R, ... of every accumulate and
+ * the partial triangles are summed by ONE logical all-reduce (RCCL over xGMI, or the P2P kernels), issued per
+ * row band on a communication stream under the next band's kernels, as int32 when every reduced cell provably
+ * fits (C(g,m) * max_windows^2 < 2^31). Variance mode: Welford chain c runs on engine c mod R, one fp64
+ * all-reduce of the chains' sums. Integer sums do not depend on their order: results are bit-identical to
+ * fsk_create's for every R. The returned handle is engine 0 and takes every call of this header: load /
+ * reset / accumulate / synchronize / finalize / compute act on the whole group (one host thread per
+ * device), getters read engine 0's copy of the reduced triangle, fsk_bind_counts binds engine 0's triangle,
+ * fsk_accumulate_rows and fsk_run_chains are single-engine calls and return FSK_ESTATE. ndev = 1 runs the
+ * same banded, collective code with a world of one. */
+int fsk_create_multi(const fsk_config* cfg, const int32_t* devices, int32_t ndev, fsk_engine** out);
+typedef struct fsk_multi_info {
+    int32_t ndev;            /* engines in the group (0: `e` came from fsk_create)                        */
+    int32_t devices[16];
+    int32_t collective;      /* FSK_COLL_RCCL or FSK_COLL_P2P: the one in use                              */
+    int32_t comm_ranks;      /* ranks of the communicator the last collective ran over                     */
+    int32_t bands;           /* row bands of the last accumulate                                           */
+    int32_t narrow;          /* 1: the last accumulate exchanged int32                                     */
+    int64_t reduce_bytes;    /* payload of the last accumulate's all-reduce, per engine                    */
+    int64_t combos_per_engine[16]; /* combos of the last accumulate                                        */
+    double reserved[4];
+} fsk_multi_info;
+int fsk_get_multi_info(fsk_engine* e, fsk_multi_info* out);
 /* message of the last failure on `e` (or of the last failed fsk_create when e == NULL) */
 const char* fsk_last_error(const fsk_engine* e);
 int fsk_abi_version(void);
@@ -159,8 +197,10 @@ int fsk_synchronize(fsk_engine* e);
  * `hip_stream` after the call waits for everything the engine has enqueued so far (e.g. RCCL's
  * all-reduce of a finished row band, issued on torch's stream, while the engine accumulates the next
  * band). Rows that an fsk_reset_counts left for a later storing launch are NOT filled by this call:
- * the other stream may read only rows already accumulated (fsk_synchronize fills the rest).
- * fsk_engine_wait_stream: the engine's later work waits for what `hip_stream` holds now. */
+ * the other stream may read only rows already accumulated (fsk_synchronize fills the rest; an accumulate
+ * with an empty combo list fills the rows it was given).
+ * fsk_engine_wait_stream: the engine's later work waits for what `hip_stream` holds now.
+ * `hip_stream` must be a stream of the engine's device. */
 int fsk_stream_wait_engine(fsk_engine* e, void* hip_stream);
 int fsk_engine_wait_stream(fsk_engine* e, void* hip_stream);
 /* extract the raw diagonal for normalisation (fastsk_kernel.cpp:96-103); call after the last
@@ -173,6 +213,13 @@ int fsk_get_block(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1,
 /* the same block written to DEVICE memory owned by the caller (e.g. a torch tensor): no host copy,
  * for consumers that keep the kernel matrix on the GPU */
 int fsk_get_block_device(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1, double* device_out);
+/* the same block in device memory the ENGINE allocates on its device (*device_out; release with
+ * fsk_free_device, whose `e` may be NULL once the engine is destroyed): for host code that has no allocator of its own for the GPU — the pybind11 class wraps
+ * it in a DLPack capsule, so the SVM stage can take the kernel matrix without a host bounce */
+int fsk_alloc_block_device(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1, double** device_out);
+int fsk_free_device(fsk_engine* e, void* device_ptr);
+/* change fsk_config.skip_test_block for later computes (a caller that finds it needs test x test cells after all) */
+int fsk_set_skip_test_block(fsk_engine* e, int32_t skip);
 int fsk_get_train(fsk_engine* e, double* out);      /* n_train x n_train, get_train_kernel()   */
 int fsk_get_test(fsk_engine* e, double* out);       /* n_test  x n_train, get_test_kernel()    */
 int fsk_get_triangle(fsk_engine* e, double* out);   /* double[N(N+1)/2], the reference's K     */
@@ -181,6 +228,12 @@ int fsk_get_counts_block(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int6
 /* raw integer cells (rows[q], cols[q]), q < n, of the symmetric matrix: scattered spot checks of a
  * triangle too large to copy out (tri_access of arbitrary pairs, shared.cpp:97-117) */
 int fsk_get_counts_cells(fsk_engine* e, const int64_t* rows, const int64_t* cols, int64_t n, uint64_t* out);
+/* Order-free digest of the integer cells of rows [row_begin, row_end): out[0] = sum of the cells (mod 2^64),
+ * out[1] = xor over the cells of cell * (index | 1) (mod 2^64), index = i(i+1)/2 + j. One pass on the device.
+ * Digests of disjoint row ranges combine (add / xor), so a triangle held in row bands by several ranks — or
+ * reduced over several GPUs — can be compared with the single-GPU one without copying it out: the
+ * "bit-identical at 1/2/4/8 GPUs" gate of the exact mode (integer sums, fastsk_kernel.cpp:286-315). */
+int fsk_counts_digest(fsk_engine* e, int64_t row_begin, int64_t row_end, uint64_t out[2]);
 /* The reduction inside get_variance (fastsk_kernel.cpp:116-131): the sum of n doubles in INDEX ORDER,
  * s = fl(s + values[i]) for i = 0 .. n-1, to the last bit, computed on the device (the stop test of
  * approx mode depends on it). `values` is a host array. Exposed so that the summation can be verified

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 #define FSK_EMU 1
@@ -138,7 +139,15 @@ inline void run_block(Block& b) {
     }
 }
 
+inline std::mutex& launch_mutex() {
+    static std::mutex m;
+    return m;
+}
+
 inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
+    // one launch at a time in the process (`__shared__` is `static`, the block below is shared): the worker
+    // threads of a multi-device group take turns
+    std::lock_guard<std::mutex> one_at_a_time(launch_mutex());
     static Block b;  // fibers (and their stacks) are reused across launches
     int nthreads = (int)(block.x * block.y * block.z);
     if ((int)b.fibers.size() < nthreads) {
@@ -237,6 +246,7 @@ template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + 
 static inline unsigned atomicAdd(unsigned* p, int v) { unsigned o = *p; *p = o + (unsigned)v; return o; }
 template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <typename T> static inline T atomicXor(T* p, T v) { T o = *p; *p = o ^ v; return o; }
 
 static inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool) {
     for (int i = 0; i < 4; ++i) c += ((a >> (8 * i)) & 255u) * ((b >> (8 * i)) & 255u);
@@ -261,9 +271,11 @@ constexpr hipError_t hipSuccess = 0;
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipGetLastError() { return 0; }
-static inline hipError_t hipSetDevice(int) { return 0; }
-static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
-static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
+// eight pretend devices (one address space: "device memory" is host memory), current device per thread
+namespace emu { inline int& cur_device() { static thread_local int d = 0; return d; } }
+static inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= 8) return 1; emu::cur_device() = d; return 0; }
+static inline hipError_t hipGetDevice(int* d) { *d = emu::cur_device(); return 0; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 8; return 0; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
 template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 static inline hipError_t hipFree(void* p) { free(p); return 0; }

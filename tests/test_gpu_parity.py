@@ -1165,3 +1165,191 @@ def test_many_high_count_kmers(native, port):
     e.finalize()
     assert np.array_equal(e.get_counts(), want)
     e.close()
+
+
+# ---- one engine over several devices of the process (fsk_create_multi) ---------------------------------
+def group_cases():
+    return [("rccl_world_of_one", [0], "auto"), ("p2p_two_engines", [0, 0], "auto"), ("p2p_four_engines", [0, 0, 0, 0], "p2p")]
+
+
+@pytest.mark.parametrize("label,devices,collective", group_cases())
+@pytest.mark.parametrize("name", ["f4_ep300_exact", "f5_prot11_exact", "f4_ep300_skipvar_T3", "f5_prot11_variance_T1_it9"])
+def test_group_golden_vectors(native, label, devices, collective, name):
+    """FastSK(devices=[...])'s engine on the GPU box: a world of one goes through the SAME banded exchange
+    with RCCL called from the host C++ (ncclCommInitAll + ncclAllReduce); a device listed twice or four
+    times runs the group's worker threads, streams and events for real, with the engine's peer-to-peer
+    all-reduce kernels as the collective (RCCL cannot put two ranks on one GPU)."""
+    d = load_golden(name)
+    e = engine_for(native, d, devices=devices, collective={"auto": 0, "rccl": 1, "p2p": 2}[collective])
+    e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+    info = e.multi_info()
+    assert info["ndev"] == len(devices) and info["comm_ranks"] == len(devices)
+    assert info["collective"] == ("rccl" if label.startswith("rccl") else "p2p"), info
+    assert np.array_equal(e.get_triangle(), d["tri"])
+    assert np.array_equal(e.get_train(), d["train"]) and np.array_equal(e.get_test(), d["test"])
+    assert np.array_equal(e.get_stdevs(), d["stdevs"])
+    if "counts" in d:
+        assert np.array_equal(e.get_counts(), d["counts"])
+    e.close()
+
+
+@pytest.mark.parametrize("label,devices,collective", group_cases())
+def test_group_banded_exchange_against_one_engine(native, label, devices, collective):
+    """N = 9000 DNA sequences: the dense dataflow in 8 equal-area row bands, every band's int32 all-reduce on
+    the exchange stream under the next band's tile kernels; two passes (the second starts from lazily
+    reset triangles), then an additive third accumulate. Digest and sampled blocks against ONE engine."""
+    tokens, offsets = synthetic_dna(9000, 60, seed=77)
+    g, m = 8, 4
+    combos = np.arange(0, 70, 2, dtype=np.int32)
+    one = native.Engine(g, m)
+    one.load_sequences(tokens, offsets, 9000, 0)
+    one.accumulate(combos)
+    one.finalize()
+    want = one.counts_digest()
+    e = native.Engine(g, m, devices=devices, collective={"auto": 0, "rccl": 1, "p2p": 2}[collective])
+    e.load_sequences(tokens, offsets, 9000, 0)
+    for _ in range(2):
+        e.reset_counts()
+        e.accumulate(combos)
+        e.finalize()
+        info = e.multi_info()
+        assert info["bands"] == 8 and info["narrow"] and info["reduce_bytes"] == 4 * e.pairs
+        assert e.counts_digest() == want
+    assert np.array_equal(e.get_counts_block(8000, 8200, 100, 400), one.get_counts_block(8000, 8200, 100, 400))
+    assert np.array_equal(e.get_block(0, 300, 0, 300), one.get_block(0, 300, 0, 300))
+    extra = np.array([1, 3, 5], dtype=np.int32)
+    one.accumulate(extra); one.finalize()
+    e.accumulate(extra); e.finalize()
+    assert e.counts_digest() == one.counts_digest()
+    assert e.stats()["combos_done"] == len(combos) + len(extra)
+    one.close(); e.close()
+
+
+def test_group_sparse_and_wide_cells(native, port):
+    """The sparse dataflow in a group (one band, every engine sorts its own combos) and the uint64 exchange
+    (one very long sequence: C(g,m) * max_windows^2 >= 2^31)."""
+    d = load_golden("f6_prot219_exact")
+    for devices in ([0, 0], [0, 0, 0]):
+        e = engine_for(native, d, path=2, devices=devices)
+        e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+        assert np.array_equal(e.get_counts(), d["counts"]) and np.array_equal(e.get_triangle(), d["tri"])
+        assert e.multi_info()["bands"] == 1
+        e.close()
+    rng = np.random.default_rng(21)
+    X = [rng.integers(1, 5, size=n).astype(np.int32) for n in (20000, 50, 64, 41, 77, 58)]
+    tok, off = native.flatten(X)
+    want, _, _ = port.compute(tok, off, 4, 2, 6, 2, t=1)
+    for devices in ([0], [0, 0]):
+        e = native.Engine(6, 2, devices=devices)
+        e.compute(tok, off, 4, 2)
+        assert not e.multi_info()["narrow"]
+        assert np.array_equal(e.get_triangle(), want)
+        e.close()
+
+
+@pytest.mark.parametrize("T", [2, 5])
+def test_group_variance_chains(native, port, T):
+    rng = np.random.default_rng(5)
+    X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(12, 40, size=30)]
+    tok, off = native.flatten(X)
+    g, m = 7, 3
+    order = rng.permutation(port.num_combos(g, m)).astype(np.int32)
+    want, sd, _ = port.compute(tok, off, 22, 8, g, m, t=T, approx=True, delta=0.5, max_iters=6, order=order)
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        e = native.Engine(g, m, t=T, approx=True, delta=0.5, max_iters=6, devices=devices)
+        e.set_combo_order(order)
+        e.compute(tok, off, 22, 8)
+        assert np.array_equal(e.get_stdevs(), sd)
+        if T <= 2:
+            assert np.array_equal(e.get_triangle(), want)
+        else:   # a sum of T fp64 terms: the reference adds them in thread-arrival order
+            assert np.allclose(e.get_triangle(), want, rtol=1e-14, atol=0)
+        e.close()
+
+
+def test_counts_digest_definition(native):
+    tokens, offsets = synthetic_dna(700, 50, seed=3)
+    e = native.Engine(7, 3)
+    e.compute(tokens, offsets, 700, 0)
+    K = e.get_counts()
+    idx = np.arange(K.size, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        want = (int(K.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(K * (idx | np.uint64(1)))))
+    assert e.counts_digest() == want
+    cell = lambda r: r * (r + 1) // 2
+    with np.errstate(over="ignore"):
+        part = (int(K[cell(128):cell(500)].sum(dtype=np.uint64)),
+                int(np.bitwise_xor.reduce(K[cell(128):cell(500)] * (idx[cell(128):cell(500)] | np.uint64(1)))))
+    assert e.counts_digest(128, 500) == part
+    e.close()
+
+
+def test_pybind_devices_dlpack_and_lazy_test_block(native, port):
+    """The drop-in class: devices=[...] (bindings.cpp:14-22 kwargs unchanged, additive), the device-resident
+    DLPack hand-off to the SVM stage, and the test x test block that no getter of the reference exposes
+    (fastsk.cpp:190-217) left out until something asks for it."""
+    import torch
+    from fastsk_amd import FastSK
+    d = load_golden("f4_ep300_exact")
+    tokens, offsets = d["tokens"], d["offsets"]
+    X = [tokens[offsets[i]:offsets[i + 1]].tolist() for i in range(len(offsets) - 1)]
+    N, ntr = len(X), d["n_train"]
+    sq = tri_to_square(d["tri"], N)
+    for kw in ({}, {"devices": [0]}, {"devices": [0, 0], "collective": "p2p"}, {"skip_test_block": False}):
+        f = FastSK(g=d["g"], m=d["m"], **kw)
+        f.compute_kernel(X[:ntr], X[ntr:])
+        st = f.stats()
+        assert st["test_block_computed"] == (kw.get("skip_test_block") is False)
+        assert st["devices"] == kw.get("devices", [0])
+        if "devices" in kw:
+            assert st["collective"] == ("p2p" if len(kw["devices"]) > 1 else "rccl") and st["comm_ranks"] == len(kw["devices"])
+        assert np.array_equal(np.array(f.get_train_kernel()), d["train"])
+        assert np.array_equal(np.array(f.get_test_kernel()), d["test"])
+        Ktr = torch.from_dlpack(f.get_train_kernel_dlpack())
+        Kte = torch.from_dlpack(f.get_test_kernel_dlpack())
+        assert Ktr.is_cuda and Ktr.dtype == torch.float64 and tuple(Kte.shape) == (N - ntr, ntr)
+        assert np.array_equal(Ktr.cpu().numpy(), d["train"]) and np.array_equal(Kte.cpu().numpy(), d["test"])
+        del f                                # the blocks outlive the engine
+        assert np.array_equal(Ktr.cpu().numpy(), d["train"])
+        f = FastSK(g=d["g"], m=d["m"], **kw)
+        f.compute_kernel(X[:ntr], X[ntr:])
+        assert np.array_equal(f.get_block(0, N, 0, ntr), sq[:, :ntr])          # no test x test cell: nothing recomputed
+        assert f.stats()["test_block_computed"] == (kw.get("skip_test_block") is False)
+        assert np.array_equal(f.get_block(ntr, N, ntr, N), sq[ntr:, ntr:])      # now they are needed
+        assert f.stats()["test_block_computed"]
+        assert np.array_equal(f.get_counts_np(), d["counts"])
+        unused = f.get_block_dlpack(0, 5, 0, 5)   # a capsule nobody consumes frees its block itself
+        del unused
+
+
+def test_tokeniser_to_kernel_on_the_gpu_box(native, port):
+    """SURVEY 8f-2 end to end on the box: FASTA file -> FastaUtility (reference reader semantics,
+    src/fastsk/utils.py:50-96) -> tokens equal to what the reference's reader produced -> compute_kernel ->
+    equal to the oracle on the same tokens; and read_packed -> compute_kernel_flat (test/run_check.py:40-46)."""
+    from fastsk import FastSK, FastaUtility   # the reference's import path
+    fasta = os.path.join(GOLD, "fasta")
+    want = np.load(os.path.join(fasta, "expected.npz"))
+    rd = FastaUtility()
+    Xtr, Ytr = rd.read_data(os.path.join(fasta, "messy.train.fasta"))
+    Xte, Yte = rd.read_data(os.path.join(fasta, "messy.test.fasta"))
+    assert [t for x in Xtr for t in x] == want["messy.train.fasta:tokens"].tolist()
+    assert [t for x in Xte for t in x] == want["messy.test.fasta:tokens"].tolist()
+    assert Ytr == want["messy.train.fasta:labels"].tolist() and Yte == want["messy.test.fasta:labels"].tolist()
+    g, m = 4, 2
+    with pytest.raises(ValueError, match="shortest train sequence has length 0"):   # the reference exit(1)s
+        FastSK(g=g, m=m).compute_kernel(Xtr, Xte)
+    Xtr = [x for x in Xtr if len(x) >= g]
+    tok, off = native.flatten(Xtr + Xte)
+    tri, _, _ = port.compute(tok, off, len(Xtr), len(Xte), g, m, t=1)
+    sq = tri_to_square(tri, len(Xtr) + len(Xte))
+    f = FastSK(g=g, m=m)
+    f.compute_kernel(Xtr, Xte)
+    assert np.array_equal(np.array(f.get_train_kernel()), sq[:len(Xtr), :len(Xtr)])
+    assert np.array_equal(np.array(f.get_test_kernel()), sq[len(Xtr):, :len(Xtr)])
+    toks, offs, labels = FastaUtility().read_packed(os.path.join(fasta, "protein.train.fasta"))
+    assert np.array_equal(toks, want["protein.train.fasta:tokens"]) and np.array_equal(labels, want["protein.train.fasta:labels"])
+    tri, _, _ = port.compute(toks, offs, 1, 1, 5, 2, t=1)
+    f = FastSK(g=5, m=2)
+    f.compute_kernel_flat(toks, offs, 1)
+    assert np.array_equal(f.get_train_kernel_np(), tri_to_square(tri, 2)[:1, :1])
+    assert np.array_equal(f.get_test_kernel_np(), tri_to_square(tri, 2)[1:, :1])
