@@ -19,6 +19,15 @@ under an external torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
           all combos over it: no cell is shared, the only exchange is the 0.8 MB diagonal, and the
           kernel matrix stays distributed.
 --shard rows swaps the two. value = combos/s of the whole job = C(g,m) * steps / max-over-ranks seconds.
+`--gpus N --inproc` runs the same job in ONE process: fastsk.FastSK(devices=[0..N-1])'s engine (fsk_create_multi:
+a host thread, a compute stream and an exchange stream per GPU, RCCL called from the host C++); a multi-process
+line carries that measurement as `inproc` (rank 0 starts it as a fresh child process once the ranks have
+released their GPUs).
+
+Every line carries `k_digest`: an order-free digest of the integer triangle computed on the device(s) after the
+timed steps (fsk_counts_digest). profiles/k_digests.json holds the single-GPU digests of the BASELINE workloads;
+a multi-GPU line compares its own — on every rank, after the reduce — with them: `bit_identical_to_1gpu`
+(BASELINE.md's "result identical at 1/2/4/8 GPUs" gate), and the run exits non-zero when that is false.
 
 One JSON line on rank 0. Extra objects:
   roofline      the dominant kernel. Config 5: k_dense_tile_dma is bound by the integer-VALU issue
@@ -161,26 +170,61 @@ def cpu_baseline(g, m, L, n_full, budget_s, sizes=(4000, 8000)):
     }
 
 
+def config_roofline(st, wall_s):
+    """SURVEY 8(d) for one whole fsk_compute call: algorithmic bytes = 16*U + per combo (16*P*nfeat + packed
+    input), over the wall time of the call, as a fraction of the HBM peak (sparse dataflow); the dense
+    dataflow's tile kernel is priced against the v_dot8 issue peak (count-MACs / tile-kernel time)."""
+    keybits = max(1, int(np.ceil(np.log2(max(2, st["key_space"])))))
+    P = (keybits + 7) // 8
+    alg = 16.0 * st["cell_updates"] + st["combos_done"] * (16.0 * P * st["n_feat"] + st["n_feat"] * st["bits_per_symbol"] / 8.0)
+    out = {"path": "dense" if st["path_used"] == 1 else "sparse", "cell_updates_U": int(st["cell_updates"]),
+           "algorithmic_GB": alg / 1e9, "algorithmic_GBs": alg / 1e9 / wall_s, "gpu_ms": 1e3 * wall_s,
+           "frac_of_hbm_peak": alg / 1e9 / wall_s / HBM_PEAK_GBS,
+           "kernel_ms": {k[3:]: round(st[k], 3) for k in ("ms_count", "ms_tile", "ms_extract", "ms_sort", "ms_segment", "ms_pairs") if st[k]}}
+    if st["path_used"] == 1 and st["ms_tile"] > 0:
+        out["valu_frac"] = st["dense_macs"] / (st["ms_tile"] * 1e-3) / 1e12 / VALU_DOT8_PEAK_TMACS
+        out["bound"] = "valu (v_dot8 issue); frac_of_hbm_peak prices a dataflow this kernel does not run"
+    else:
+        out["bound"] = "hbm"
+    return out
+
+
 def other_configs(_native):
     """The other BASELINE configs on the same GPU: the whole fsk_compute call, host buffers in, result
-    resident on the device (best of 4). Config 2 = BASELINE configs[1] (EP300 DNA, 2000+2000 x 100 bp,
-    g=10 m=6 exact); configs 1, 3, 4 from the golden descriptors (same modes and combo orders as the
-    parity tests)."""
+    resident on the device (best of 4), and its roofline (one more call with HIP-event timing and the
+    exact update count U). Config 2 = BASELINE configs[1] (EP300 DNA, 2000+2000 x 100 bp, g=10 m=6 exact);
+    configs 1, 3, 4 from the golden descriptors (same modes and combo orders as the parity tests)."""
     out = {}
-    path = os.path.join(ROOT, "tests", "golden", "tokens_EP300.npz")
-    if os.path.exists(path):
-        z = np.load(path)
-        tokens, offsets = z["tokens"].astype(np.int32), z["offsets"].astype(np.int64)
-        ntr, nte = int(z["n_train"]), int(z["n_test"])
-        e = _native.Engine(10, 6)
+
+    def measure(make, tokens, offsets, ntr, nte):
+        e = make(False)
         best = 1e9
         for _ in range(4):
             t0 = time.perf_counter()
             e.compute(tokens, offsets, ntr, nte)
             best = min(best, time.perf_counter() - t0)
+        done = int(e.stats()["combos_done"])
+        try:
+            digest = digest_hex(e.counts_digest())
+        except _native.FskError:
+            digest = None  # (variance mode keeps a floating-point mean, not integer counts)
         e.close()
+        e = make(True)
+        e.compute(tokens, offsets, ntr, nte)  # (allocations)
+        e.compute(tokens, offsets, ntr, nte)
+        st = e.stats()
+        e.close()
+        return best, done, config_roofline(st, best), digest
+
+    path = os.path.join(ROOT, "tests", "golden", "tokens_EP300.npz")
+    if os.path.exists(path):
+        z = np.load(path)
+        tokens, offsets = z["tokens"].astype(np.int32), z["offsets"].astype(np.int64)
+        ntr, nte = int(z["n_train"]), int(z["n_test"])
+        best, done, roof, digest = measure(lambda prof: _native.Engine(10, 6, profile=prof), tokens, offsets, ntr, nte)
         out["config2_ep300_exact"] = {"n_seq": ntr + nte, "seq_len": 100, "g": 10, "m": 6, "combos": 210, "seconds": best,
-                                      "combos_per_s": 210 / best, "reference_cpu_seconds_8_threads": 29.9}
+                                      "combos_per_s": 210 / best, "reference_cpu_seconds_8_threads": 29.9, "roofline": roof,
+                                      "k_digest": digest}
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from conftest import load_golden, load_tokens, GOLD
@@ -190,22 +234,39 @@ def other_configs(_native):
                 continue
             d = load_golden(name)
             tokens, offsets, ntr, nte, _, _ = load_tokens(d["data"])
-            e = _native.Engine(d["g"], d["m"], t=d["t"], approx=bool(d["approx"]), delta=d["delta"], max_iters=d["max_iters"],
-                               skip_variance=bool(d["skip_variance"]))
-            if d["approx"]:
-                e.set_combo_order(d["order"])
-            best = 1e9
-            for _ in range(4):
-                t0 = time.perf_counter()
-                e.compute(tokens, offsets, ntr, nte)
-                best = min(best, time.perf_counter() - t0)
-            done = int(e.stats()["combos_done"])
-            e.close()
+
+            def make(prof, d=d):
+                e = _native.Engine(d["g"], d["m"], t=d["t"], approx=bool(d["approx"]), delta=d["delta"], max_iters=d["max_iters"],
+                                   skip_variance=bool(d["skip_variance"]), profile=prof)
+                if d["approx"]:
+                    e.set_combo_order(d["order"])
+                return e
+            best, done, roof, digest = measure(make, tokens, offsets, ntr, nte)
             out[key] = {"n_seq": ntr + nte, "g": int(d["g"]), "m": int(d["m"]), "combos": done, "seconds": best,
-                        "combos_per_s": done / best, "reference_cpu_seconds": float(d["ref_seconds"])}
+                        "combos_per_s": done / best, "reference_cpu_seconds": float(d["ref_seconds"]), "roofline": roof,
+                        "k_digest": digest}
     except Exception as exc:  # the headline line must not depend on the extras
         out["error"] = repr(exc)
     return out or None
+
+
+# ---- digests of the integer triangle (fsk_counts_digest): the bit-identity gate of multi-GPU runs
+DIGESTS = os.path.join(ROOT, "profiles", "k_digests.json")
+
+
+def digest_hex(d):
+    return {"sum": "%016x" % d[0], "xor": "%016x" % d[1]}
+
+
+def digest_key(config, N, L, g, m, ncomb):
+    return "config%d:n_seq=%d,seq_len=%s,g=%d,m=%d,combos=%d" % (config, N, L, g, m, ncomb)
+
+
+def committed_digest(key):
+    try:
+        return json.load(open(DIGESTS)).get(key)
+    except (OSError, ValueError):
+        return None
 
 
 def describe(mode, world, replicate):
@@ -245,11 +306,212 @@ def parse_args():
                     help="multi-GPU decomposition reported as `value` (the other one is `alt`)")
     ap.add_argument("--replicate", action="store_true", help="rows: broadcast finished bands so every rank holds all of K")
     ap.add_argument("--no-alt", action="store_true", help="multi-GPU: do not time the other decomposition")
+    ap.add_argument("--inproc", action="store_true",
+                    help="run the N GPUs from ONE process: FastSK(devices=[0..N-1])'s engine (fsk_create_multi), RCCL from the host C++")
+    ap.add_argument("--collective", choices=["auto", "rccl", "p2p"], default="auto", help="--inproc: the exchange (auto = RCCL)")
+    ap.add_argument("--no-inproc-leg", action="store_true", help="multi-process run: do not add the in-process measurement")
+    ap.add_argument("--inproc-timeout", type=float, default=420.0, help="seconds the in-process child of a multi-process run may take")
     return ap.parse_args()
+
+
+def workload_of(args):
+    """(tokens, offsets, N, L, g, m, workload text, data text)"""
+    if args.config == 4:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "tokens_2.19.npz"))
+        tokens, offsets = z["tokens"].astype(np.int32), z["offsets"].astype(np.int64)
+        N, L = len(offsets) - 1, None
+        g, m = args.g or 14, args.m or 10
+        workload = "config4: protein 2.19, %d sequences (mean length %d), g=%d m=%d exact" % (N, int(offsets[-1] // N), g, m)
+        data = "real (data/2.19 FASTA tokens, tests/golden/tokens_2.19.npz)"
+    else:
+        N, L = args.n_seq, args.seq_len
+        g, m = args.g or 12, args.m or 8
+        tokens, offsets, _ = synthetic(N, L)
+        workload = "config5: synthetic DNA %d x %d bp, g=%d m=%d exact" % (N, L, g, m)
+        data = "synthetic"
+    return tokens, offsets, N, L, g, m, workload, data
+
+
+def roofline_of(args, s0, s1, dense, world, combos_rank, share_rows, offsets, n_mine):
+    """`roofline`, `phases_ms_per_step`, `dtype` from the engine's stats before / after the timed steps."""
+    d = lambda k: s1[k] - s0[k]
+    N = s1["n_seq"]
+    nfeat = s1["n_feat"]
+    b_in = (int(offsets[-1]) * s1["bits_per_symbol"] + 7) // 8
+    keybits = max(1, int(np.ceil(np.log2(max(2, s1["key_space"])))))
+    P = (keybits + 7) // 8  # 8-bit LSD passes SURVEY 8(d) prices the sort with
+    if dense:
+        # ---- roofline of the dominant kernel (tile accumulate), per launch
+        launches = max(1, d("n_tile_launches"))
+        tile_ms = d("ms_tile") / launches
+        # exact, from the count panels (whole triangle); a row-band launch owns its share of the cells
+        U = d("cell_updates") / launches * share_rows
+        combos_per_launch = combos_rank / launches
+        alg_bytes = 16.0 * U + combos_per_launch * (b_in + 16.0 * P * nfeat)
+        secs = tile_ms * 1e-3
+        alg_gbs = alg_bytes / secs / 1e9 if secs > 0 else 0.0
+        macs = d("dense_macs") / launches
+        tmacs = macs / secs / 1e12 if secs > 0 else 0.0
+        traffic, traffic_note = None, "no profiles/traffic.json for this launch shape"
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if world == 1 and os.path.exists(tpath):  # (measured on the single-GPU launch: does not describe a rank's band)
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("n_seq") != N or tj.get("combos_per_launch") != int(combos_per_launch):
+                    traffic_note = "profiles/traffic.json describes another launch shape"
+                elif tj.get("kernel_files") != kernel_hashes():
+                    traffic_note = "profiles/traffic.json was measured on other kernel sources (blob hashes differ): refused"
+                else:
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_note = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, NOT this run), commit %s" % tj.get("commit", "?")
+            except Exception as exc:
+                traffic_note = "profiles/traffic.json unreadable: %r" % exc
+        roofline = {
+            "bound": "valu", "kernel": "k_dense_tile_dma" if os.environ.get("FSK_TILE_DMA", "1") != "0" else "k_dense_tile",
+            "achieved": tmacs, "peak": VALU_DOT8_PEAK_TMACS, "unit": "T count-MAC/s (v_dot8_u32_u4: 64 lanes/clk/CU x 8 MACs, 256 CUs, 2.4 GHz)",
+            "frac": tmacs / VALU_DOT8_PEAK_TMACS, "traffic": traffic, "traffic_source": traffic_note,
+            "hbm_measured_frac": (traffic / secs / 1e9 / HBM_PEAK_GBS) if (traffic and secs > 0) else None,
+            "hbm_peak_GBs": HBM_PEAK_GBS,
+            "useful_update_frac": (U / secs / 1e12) / VALU_DOT8_PEAK_TMACS if secs > 0 else 0.0,
+            "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_equiv_GBs": alg_gbs,
+            "algorithmic_x_hbm_peak": alg_gbs / HBM_PEAK_GBS,
+            "launch_ms": tile_ms, "launches": int(launches), "combos_per_launch": combos_per_launch,
+            "cell_updates_per_launch": U, "count_macs_per_launch": macs,
+            "note": "the tile kernel computes K += sum_v cnt_i(v) cnt_j(v) as on-chip integer dot products, so the binding ceiling is "
+                    "the v_dot8 issue rate (frac); useful_update_frac = the reference's `+=` count U per second over the same peak "
+                    "(the rest of the MACs multiply by a zero count); algorithmic_* = SURVEY 8(d) bytes of the direct-atomic dataflow "
+                    "(16*U + sort + input per combo), which this kernel does NOT move through HBM — not a fraction of anything",
+        }
+        phases = {"count": d("ms_count") / args.steps, "tile": d("ms_tile") / args.steps, "accumulate_total": d("ms_total") / args.steps}
+        dtype = "u4 count planes (v_dot8_u32_u4), u32 register sums, u64 triangle (plain stores on the first pass over reset rows, else atomics)"
+    else:
+        # ---- sparse pipeline: SURVEY 8(d) algorithmic bytes over the GPU time of the pipeline
+        U = d("cell_updates") / max(1, args.steps)
+        alg_bytes = 16.0 * U + n_mine * (b_in + 16.0 * P * nfeat)
+        gpu_ms = (d("ms_extract") + d("ms_sort") + d("ms_segment") + d("ms_pairs")) / args.steps
+        alg_gbs = alg_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0
+        fam = {"extract": d("ms_extract"), "sort": d("ms_sort"), "segment": d("ms_segment"), "pairs": d("ms_pairs")}
+        # measured HBM bytes of one config-4 pass: the sum over the pipeline's kernels of the rocprofv3 --pmc passes in
+        # profiles/ (FETCH_SIZE x2 + WRITE_SIZE), accepted only for this workload and these sources
+        traffic, traffic_note = None, "not collected in this run (profiles/ holds the rocprofv3 --pmc passes of the sparse kernels)"
+        tpath = os.path.join(ROOT, "profiles", "traffic_config4.json")
+        if args.config == 4 and world == 1 and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("combos") != n_mine:
+                    traffic_note = "profiles/traffic_config4.json describes another combo count"
+                elif tj.get("kernel_files") != kernel_hashes(SPARSE_FILES):
+                    traffic_note = "profiles/traffic_config4.json was measured on other sources (blob hashes differ): refused"
+                else:
+                    traffic = tj.get("hbm_bytes_per_step")
+                    traffic_note = "profiles/traffic_config4.json (sum over the pipeline's kernels of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, NOT this run), commit %s" % tj.get("commit", "?")
+            except Exception as exc:
+                traffic_note = "profiles/traffic_config4.json unreadable: %r" % exc
+        roofline = {
+            "bound": "hbm", "kernel": "sparse pipeline (k_sx_extract, k_sx_scan_slot/scatter, k_sx_seg_*, k_sx_emit + k_sx_consume); largest family: %s" % max(fam, key=fam.get),
+            "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": traffic_note,
+            "hbm_measured_frac": (traffic / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and gpu_ms > 0) else None,
+            "algorithmic_bytes_per_step": alg_bytes, "cell_updates_per_step": U, "gpu_ms_per_step": gpu_ms,
+            "sort_passes_priced": P, "sort_passes_run": s1["sort_passes"],
+            "note": "algorithmic bytes = 16*U + 16*P*nfeat + input per combo (SURVEY 8d) over the HIP-event time of the pipeline's kernels",
+        }
+        phases = {k: v / args.steps for k, v in fam.items()}
+        phases["accumulate_total"] = d("ms_total") / args.steps
+        dtype = "u32/u64 packed k-mer keys, u32 LDS sums, u64 triangle (read-modify-write by the owner band, atomics beyond)"
+    return roofline, phases, dtype
+
+
+def finish(out, args, N, L, g, m, _native):
+    """rank 0 / the single process: extras that do not depend on the job's ranks, then the ONE JSON line."""
+    world = out["n_gpus"]
+    if world == 1 and not args.no_also:
+        out["also"] = other_configs(_native)
+    if world == 1 and not args.no_cpu_baseline:
+        full_n, full_L = (N, L) if args.config == 5 else (100000, 300)
+        bg, bm = (g, m) if args.config == 5 else (12, 8)
+        out["cpu_baseline"] = cpu_baseline(bg, bm, full_L, full_n, args.cpu_seconds)
+        if args.config != 5:
+            out["cpu_baseline"]["sample"] += " [config-5 generator: this run's own workload is --config %d]" % args.config
+    # RCCL prints a version banner through C stdio; flush it first so the JSON line is last
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
+    if out.get("bit_identical_to_1gpu") is False:
+        sys.exit("k_digest differs from the committed single-GPU digest (or between ranks): the result is NOT the 1-GPU result")
+
+
+def main_inproc(args):
+    """One process, N GPUs: the engine behind FastSK(devices=[0..N-1])."""
+    from fastsk_amd import _native
+    tokens, offsets, N, L, g, m, workload, data = workload_of(args)
+    # (FSK_BENCH_SHARE_GPU=1: a smoke test of the group on a 1-GPU box, every engine on device 0 over the P2P kernels)
+    devices = [0] * args.gpus if os.environ.get("FSK_BENCH_SHARE_GPU") == "1" else list(range(args.gpus))
+    coll = {"auto": _native.COLL_AUTO, "rccl": _native.COLL_RCCL, "p2p": _native.COLL_P2P}[args.collective]
+    eng = _native.Engine(g, m, devices=devices, collective=coll, bands=args.bands or 0, profile=True)
+    ncomb = eng.lib.num_combos(g, m)
+    workload += ", %d combos" % ncomb
+    t_load = time.perf_counter()
+    eng.load_sequences(tokens, offsets, N, 0)
+    eng.synchronize()
+    t_load = time.perf_counter() - t_load
+    every = np.arange(ncomb, dtype=np.int32)
+    dense = eng.stats()["path_used"] == 1
+
+    def step():
+        eng.reset_counts()
+        eng.accumulate(every)   # combos r, r + R, ... on engine r; the all-reduce band by band behind the kernels
+        eng.finalize()
+
+    for _ in range(args.warmup):
+        step()
+    eng.synchronize()
+    s0 = eng.stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.synchronize()
+    elapsed = time.perf_counter() - t0
+    s1 = eng.stats()
+    info = eng.multi_info()
+    digest = eng.counts_digest()
+    key = digest_key(args.config, N, L, g, m, ncomb)
+    want = committed_digest(key)
+    # engine 0's share: its stats carry the HIP-event times
+    n0 = info["combos_per_engine"][0]
+    e0, s0e = dict(s1), dict(s0)
+    # (cell_updates / dense_macs in a group's stats are sums over the engines: bring them back to engine 0's share)
+    for k in ("cell_updates", "dense_macs"):
+        e0[k] = s1[k] * n0 / max(1, ncomb)
+        s0e[k] = s0[k] * n0 / max(1, ncomb)
+    roofline, phases, dtype = roofline_of(args, s0e, e0, dense, args.gpus, n0 * args.steps, 1.0, offsets, n0)
+    out = {
+        "metric": "gkm kernel build: mismatch-combos/s", "value": ncomb * args.steps / elapsed, "unit": "combos/s",
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": data,
+        "config": {"workload": workload, "n_seq": N, "seq_len": L, "g": g, "m": m, "combos": int(ncomb),
+                   "parallelism": "in-process x%d: one engine per GPU behind one handle (fsk_create_multi / FastSK(devices=...)), combos c = "
+                                  "engine (mod %d), one logical all-reduce issued in %d row bands on exchange streams under the next band's kernels"
+                                  % (args.gpus, args.gpus, info["bands"]),
+                   "path": "dense" if dense else "sparse"},
+        "roofline": roofline, "load_seconds_untimed": t_load, "phases_ms_per_step": phases,
+        "comm": {"backend": "%s called from the host C++ (no torch in this process)" % ("RCCL" if info["collective"] == "rccl" else "engine P2P kernels"),
+                 "rccl_ranks": info["comm_ranks"] if info["collective"] == "rccl" else 0, "ranks": info["comm_ranks"],
+                 "allreduce_payload_bytes": info["reduce_bytes"], "allreduce_dtype": "int32" if info["narrow"] else "uint64",
+                 "bands": info["bands"], "combos_per_engine": info["combos_per_engine"],
+                 "latency_bound": not dense},
+        "k_digest": dict(digest_hex(digest), key=key, committed=want),
+        "bit_identical_to_1gpu": None if want is None else (digest_hex(digest) == {"sum": want["sum"], "xor": want["xor"]}),
+    }
+    eng.close()
+    finish(out, args, N, L, g, m, _native)
 
 
 def main():
     args = parse_args()
+    if args.inproc:
+        return main_inproc(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # No launcher around us: start one fresh process per GPU and hand back their exit code. Nothing
         # in THIS process has touched the GPU (torch is not even imported yet), and nothing is exec'd.
@@ -284,20 +546,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    # ---- workload
-    if args.config == 4:
-        z = np.load(os.path.join(ROOT, "tests", "golden", "tokens_2.19.npz"))
-        tokens, offsets = z["tokens"].astype(np.int32), z["offsets"].astype(np.int64)
-        N, L, X = len(offsets) - 1, None, None
-        g, m = args.g or 14, args.m or 10
-        workload = "config4: protein 2.19, %d sequences (mean length %d), g=%d m=%d exact" % (N, int(offsets[-1] // N), g, m)
-        data = "real (data/2.19 FASTA tokens, tests/golden/tokens_2.19.npz)"
-    else:
-        N, L = args.n_seq, args.seq_len
-        g, m = args.g or 12, args.m or 8
-        tokens, offsets, X = synthetic(N, L)
-        workload = "config5: synthetic DNA %d x %d bp, g=%d m=%d exact" % (N, L, g, m)
-        data = "synthetic"
+    tokens, offsets, N, L, g, m, workload, data = workload_of(args)
     eng = _native.Engine(g, m, device=local_rank, profile=True)
     ncomb = eng.lib.num_combos(g, m)
     workload += ", %d combos" % ncomb
@@ -342,6 +591,27 @@ def main():
             eng.synchronize()
         eng.finalize()
 
+    def gather_digest(how):
+        """The digest of the job's triangle after a step of decomposition `how`, and whether every rank agrees:
+        combos (and replicated rows): every rank holds all of K and folds all of it; rows: a rank folds the
+        rows it owns and the words are combined (sum: +, xor: ^)."""
+        owned = use_dist and how == "rows" and not args.replicate
+        d = eng.counts_digest(*edges[rank:rank + 2]) if owned else eng.counts_digest()
+        if not use_dist:
+            return d, True
+        words = np.array(d, dtype=np.uint64).view(np.int64)
+        t = torch.from_numpy(words.copy()).to("cuda" if backend == "nccl" else "cpu")
+        allw = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allw, t)
+        allw = [w.cpu().numpy().view(np.uint64) for w in allw]
+        if owned:
+            total, x = 0, 0
+            for w in allw:
+                total = (total + int(w[0])) % (1 << 64)
+                x ^= int(w[1])
+            return (total, x), True
+        return (int(allw[0][0]), int(allw[0][1])), all(int(w[0]) == int(allw[0][0]) and int(w[1]) == int(allw[0][1]) for w in allw)
+
     def timed(how, warmup, steps):
         eng.reset_counts()  # whatever the other decomposition left in K (untimed)
         for _ in range(warmup):
@@ -358,15 +628,33 @@ def main():
             tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
-        return dt, a, b
+        return dt, a, b, gather_digest(how)
 
-    elapsed, s0, s1 = timed(mode, args.warmup, args.steps)
+    key = digest_key(args.config, N, L, g, m, ncomb)
+    want = committed_digest(key)
+
+    def verdict(dg, agree):
+        """(the `k_digest` object, bit_identical_to_1gpu): False when the ranks disagree or the digest is not the
+        committed single-GPU one; None when no single-GPU digest of this workload is committed."""
+        obj = dict(digest_hex(dg), key=key, committed=want, ranks_agree=agree)
+        if not agree:
+            return obj, False
+        if want is None:
+            return obj, None
+        return obj, digest_hex(dg) == {"sum": want["sum"], "xor": want["xor"]}
+
+    elapsed, s0, s1, (dg, agree) = timed(mode, args.warmup, args.steps)
+    k_digest, identical = verdict(dg, agree)
     alt = None
     if world > 1 and not args.no_alt and edges is not None:
         other = "combos" if mode == "rows" else "rows"
-        dt, _, _ = timed(other, args.warmup, args.steps)
+        dt, _, _, (adg, aagree) = timed(other, args.warmup, args.steps)
+        akd, aid = verdict(adg, aagree)
         alt = {"parallelism": describe(other, world, args.replicate), "value": ncomb * args.steps / dt, "unit": "combos/s",
-               "ms_per_step": 1e3 * dt / args.steps, "steps": args.steps, "warmup": args.warmup}
+               "ms_per_step": 1e3 * dt / args.steps, "steps": args.steps, "warmup": args.warmup, "k_digest": akd,
+               "bit_identical_to_1gpu": aid}
+        if aid is False:
+            identical = False
 
     # ---- the exchange by itself: the same band-wise all-reduce, nothing overlapping it (untimed extras;
     # K is garbage afterwards and is reset by whatever runs next)
@@ -392,7 +680,10 @@ def main():
                 "allreduce_ms_per_step_not_overlapped": 1e3 * t_ar, "allreduce_payload_bytes": payload,
                 "allreduce_dtype": "int32" if narrow else "int64", "bands": len(segs),
                 "algbw_GBs": payload / t_ar / 1e9,
-                "busbw_GBs": payload / t_ar / 1e9 * 2 * (world - 1) / max(1, world)}
+                "busbw_GBs": payload / t_ar / 1e9 * 2 * (world - 1) / max(1, world),
+                # a small triangle (the sparse workloads: 26 MB at config 4) is exchanged in one piece after a few
+                # milliseconds of kernels: its latency, not the links' bandwidth, is what a step pays
+                "latency_bound": bool(not dense or payload < (64 << 20))}
 
     # ---- SURVEY 8(d)'s metric boundary: load + one step + a normalised block (single GPU only)
     end_to_end = None
@@ -413,95 +704,10 @@ def main():
 
     out = None
     if rank == 0:
-        combos_rank = len(mine) * args.steps
-        d = lambda k: s1[k] - s0[k]
-        value = ncomb * args.steps / elapsed
-        nfeat = s1["n_feat"]
-        b_in = (int(offsets[-1]) * s1["bits_per_symbol"] + 7) // 8
-        keybits = max(1, int(np.ceil(np.log2(max(2, s1["key_space"])))))
-        P = (keybits + 7) // 8  # 8-bit LSD passes SURVEY 8(d) prices the sort with
-        if dense:
-            # ---- roofline of the dominant kernel (tile accumulate), per launch
-            launches = max(1, d("n_tile_launches"))
-            tile_ms = d("ms_tile") / launches
-            # exact, from the count panels (whole triangle); a row-band launch owns its share of the cells
-            share_rows = ((my_rows[1] * (my_rows[1] + 1) - my_rows[0] * (my_rows[0] + 1)) // 2) / pairs
-            U = d("cell_updates") / launches * share_rows
-            combos_per_launch = combos_rank / launches
-            alg_bytes = 16.0 * U + combos_per_launch * (b_in + 16.0 * P * nfeat)
-            secs = tile_ms * 1e-3
-            alg_gbs = alg_bytes / secs / 1e9 if secs > 0 else 0.0
-            macs = d("dense_macs") / launches
-            tmacs = macs / secs / 1e12 if secs > 0 else 0.0
-            traffic, traffic_note = None, "no profiles/traffic.json for this launch shape"
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if world == 1 and os.path.exists(tpath):  # (measured on the single-GPU launch: does not describe a rank's band)
-                try:
-                    tj = json.load(open(tpath))
-                    if tj.get("n_seq") != N or tj.get("combos_per_launch") != int(combos_per_launch):
-                        traffic_note = "profiles/traffic.json describes another launch shape"
-                    elif tj.get("kernel_files") != kernel_hashes():
-                        traffic_note = "profiles/traffic.json was measured on other kernel sources (blob hashes differ): refused"
-                    else:
-                        traffic = tj.get("hbm_bytes_per_launch")
-                        traffic_note = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, NOT this run), commit %s" % tj.get("commit", "?")
-                except Exception as exc:
-                    traffic_note = "profiles/traffic.json unreadable: %r" % exc
-            roofline = {
-                "bound": "valu", "kernel": "k_dense_tile_dma" if os.environ.get("FSK_TILE_DMA", "1") != "0" else "k_dense_tile",
-                "achieved": tmacs, "peak": VALU_DOT8_PEAK_TMACS, "unit": "T count-MAC/s (v_dot8_u32_u4: 64 lanes/clk/CU x 8 MACs, 256 CUs, 2.4 GHz)",
-                "frac": tmacs / VALU_DOT8_PEAK_TMACS, "traffic": traffic, "traffic_source": traffic_note,
-                "hbm_measured_frac": (traffic / secs / 1e9 / HBM_PEAK_GBS) if (traffic and secs > 0) else None,
-                "hbm_peak_GBs": HBM_PEAK_GBS,
-                "useful_update_frac": (U / secs / 1e12) / VALU_DOT8_PEAK_TMACS if secs > 0 else 0.0,
-                "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_equiv_GBs": alg_gbs,
-                "algorithmic_x_hbm_peak": alg_gbs / HBM_PEAK_GBS,
-                "launch_ms": tile_ms, "launches": int(launches), "combos_per_launch": combos_per_launch,
-                "cell_updates_per_launch": U, "count_macs_per_launch": macs,
-                "note": "the tile kernel computes K += sum_v cnt_i(v) cnt_j(v) as on-chip integer dot products, so the binding ceiling is "
-                        "the v_dot8 issue rate (frac); useful_update_frac = the reference's `+=` count U per second over the same peak "
-                        "(the rest of the MACs multiply by a zero count); algorithmic_* = SURVEY 8(d) bytes of the direct-atomic dataflow "
-                        "(16*U + sort + input per combo), which this kernel does NOT move through HBM — not a fraction of anything",
-            }
-            phases = {"count": d("ms_count") / args.steps, "tile": d("ms_tile") / args.steps, "accumulate_total": d("ms_total") / args.steps}
-            dtype = "u4 count planes (v_dot8_u32_u4), u32 accumulate, u64 atomics"
-        else:
-            # ---- sparse pipeline: SURVEY 8(d) algorithmic bytes over the GPU time of the pipeline
-            U = d("cell_updates") / max(1, args.steps)
-            alg_bytes = 16.0 * U + len(mine) * (b_in + 16.0 * P * nfeat)
-            gpu_ms = (d("ms_extract") + d("ms_sort") + d("ms_segment") + d("ms_pairs")) / args.steps
-            alg_gbs = alg_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0
-            fam = {"extract": d("ms_extract"), "sort": d("ms_sort"), "segment": d("ms_segment"), "pairs": d("ms_pairs")}
-            # measured HBM bytes of one config-4 pass: the sum over the pipeline's kernels of the rocprofv3 --pmc passes in
-            # profiles/ (FETCH_SIZE x2 + WRITE_SIZE), accepted only for this workload and these sources
-            traffic, traffic_note = None, "not collected in this run (profiles/ holds the rocprofv3 --pmc passes of the sparse kernels)"
-            tpath = os.path.join(ROOT, "profiles", "traffic_config4.json")
-            if args.config == 4 and world == 1 and os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))
-                    if tj.get("combos") != len(mine):
-                        traffic_note = "profiles/traffic_config4.json describes another combo count"
-                    elif tj.get("kernel_files") != kernel_hashes(SPARSE_FILES):
-                        traffic_note = "profiles/traffic_config4.json was measured on other sources (blob hashes differ): refused"
-                    else:
-                        traffic = tj.get("hbm_bytes_per_step")
-                        traffic_note = "profiles/traffic_config4.json (sum over the pipeline's kernels of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, NOT this run), commit %s" % tj.get("commit", "?")
-                except Exception as exc:
-                    traffic_note = "profiles/traffic_config4.json unreadable: %r" % exc
-            roofline = {
-                "bound": "hbm", "kernel": "sparse pipeline (k_sx_extract, k_sx_hist/scan_slot/scatter, k_sx_seg_*, k_sx_emit + k_sx_consume); largest family: %s" % max(fam, key=fam.get),
-                "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": traffic_note,
-                "hbm_measured_frac": (traffic / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and gpu_ms > 0) else None,
-                "algorithmic_bytes_per_step": alg_bytes, "cell_updates_per_step": U, "gpu_ms_per_step": gpu_ms,
-                "sort_passes_priced": P, "sort_passes_run": s1["sort_passes"],
-                "note": "algorithmic bytes = 16*U + 16*P*nfeat + input per combo (SURVEY 8d) over the HIP-event time of the pipeline's kernels",
-            }
-            phases = {k: v / args.steps for k, v in fam.items()}
-            phases["accumulate_total"] = d("ms_total") / args.steps
-            dtype = "u32/u64 packed k-mer keys, u32 LDS sums, u64 atomics"
+        share_rows = ((my_rows[1] * (my_rows[1] + 1) - my_rows[0] * (my_rows[0] + 1)) // 2) / pairs
+        roofline, phases, dtype = roofline_of(args, s0, s1, dense, world, len(mine) * args.steps, share_rows, offsets, len(mine))
         out = {
-            "metric": "gkm kernel build: mismatch-combos/s", "value": value, "unit": "combos/s",
+            "metric": "gkm kernel build: mismatch-combos/s", "value": ncomb * args.steps / elapsed, "unit": "combos/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": dtype, "data": data,
@@ -511,6 +717,8 @@ def main():
             "roofline": roofline,
             "load_seconds_untimed": t_load,
             "phases_ms_per_step": phases,
+            "k_digest": k_digest,
+            "bit_identical_to_1gpu": identical,
         }
         if alt is not None:
             out["alt"] = alt
@@ -522,23 +730,47 @@ def main():
         dist.barrier()
     eng.close()
     del K
-    if rank == 0:
-        if world == 1 and not args.no_also:
-            out["also"] = other_configs(_native)
-        if world == 1 and not args.no_cpu_baseline:
-            full_n, full_L = (N, L) if args.config == 5 else (100000, 300)
-            bg, bm = (g, m) if args.config == 5 else (12, 8)
-            out["cpu_baseline"] = cpu_baseline(bg, bm, full_L, full_n, args.cpu_seconds)
-            if args.config != 5:
-                out["cpu_baseline"]["sample"] += " [config-5 generator: this run's own workload is --config %d]" % args.config
+    torch.cuda.empty_cache()
+    # ---- the same job from ONE process (FastSK(devices=[...])'s engine), measured once the ranks have let go of
+    # their GPUs: rank 0 starts a fresh child (it has touched the GPU itself: a child process, never an exec)
+    # and the others wait on the rendezvous store, not on a collective that would spin on their GPUs.
+    if world > 1 and backend == "nccl" and not args.no_inproc_leg:
+        import datetime
+        store = dist.distributed_c10d._get_default_store()
+        torch.cuda.synchronize()
+        dist.barrier()
+        if rank == 0:
+            leg = {"cmd": "bench.py --gpus %d --inproc" % world}
+            try:
+                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--inproc", "--steps", str(args.steps), "--warmup",
+                       str(args.warmup), "--config", str(args.config), "--n-seq", str(args.n_seq), "--seq-len", str(args.seq_len),
+                       "--no-also", "--no-cpu-baseline"] + (["--bands", str(args.bands)] if args.bands else [])
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                                         "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.inproc_timeout, env=env)
+                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                if lines:
+                    leg.update(json.loads(lines[-1]))
+                    for k in ("roofline", "phases_ms_per_step", "dtype", "data", "metric", "unit", "higher_is_better", "vs_baseline"):
+                        leg.pop(k, None)
+                if r.returncode != 0 or not lines:
+                    leg["error"] = "exit code %d: %s" % (r.returncode, (r.stderr or r.stdout)[-600:])
+                if leg.get("bit_identical_to_1gpu") is False:
+                    out["bit_identical_to_1gpu"] = False
+            except subprocess.TimeoutExpired:
+                leg["error"] = "no result within %.0f s (child stopped)" % args.inproc_timeout
+            except Exception as exc:
+                leg["error"] = repr(exc)
+            out["inproc"] = leg
+            store.set("fsk_inproc_leg_done", "1")
+        else:
+            store.wait(["fsk_inproc_leg_done"], datetime.timedelta(seconds=args.inproc_timeout + 120))
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
-        # RCCL prints a version banner through C stdio; flush it first so the JSON line is last
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        finish(out, args, N, L, g, m, _native)
+    elif identical is False:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -8,7 +8,8 @@ first-seen order starting at 1 with id 0 reserved (``utils.py:13``), one vocabul
 
 The work is done by the native reader ``fsk_read_fasta`` (``csrc/fsk_fasta.cpp``) behind
 ``read_packed``, which returns flat arrays ready for the C ABI; ``read_data`` only reshapes them
-into the reference's nested lists. Pinned against the reference's own reader by
+into the reference's nested lists; without the built library the same arrays come from a numpy pass
+over the text (``_read_text``). Pinned against the reference's own reader by
 ``tests/golden/tokens_*.npz`` (``tests/test_tokeniser.py``).
 """
 import ctypes as C
@@ -69,7 +70,12 @@ class FastaUtility:
         flat form the C ABI and ``FastSK.compute_kernel_flat`` take — with the tokenisation of
         ``read_data`` and this object's shared vocabulary."""
         from . import _native
-        L = _native.library().L
+        try:
+            L = _native.library().L
+        except (ImportError, OSError):
+            # no hipcc-built library on this host: the tokeniser (host code, no GPU involved) stays usable
+            # through the whole-file numpy pass below — same tokens, same errors
+            return self._read_text(data_file)
         lut = self._vocab._table()
         nxt = C.c_int32(self._vocab.size())
         n_seq, n_tok = C.c_int64(0), C.c_int64(0)

@@ -495,14 +495,18 @@ def test_bench_two_ranks_sharing_the_gpu(native, shard):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--n-seq", "6000", "--shard", shard], env=env, capture_output=True, text=True, timeout=900)
+                        "--n-seq", "8000", "--shard", shard], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])   # the JSON line is the last thing printed
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "comm"):
         assert key in d
     assert d["n_gpus"] == 2 and d["unit"] == "combos/s" and d["value"] > 0 and d["scaling"] == "strong"
-    assert d["config"]["combos"] == 495 and d["config"]["n_seq"] == 6000
+    assert d["config"]["combos"] == 495 and d["config"]["n_seq"] == 8000
+    # BASELINE.md's gate "result identical at 1/2/4/8 GPUs": the digest of the reduced triangle, folded on the
+    # device by every rank, equals the committed single-GPU digest of this workload (profiles/k_digests.json)
+    assert d["bit_identical_to_1gpu"] is True and d["k_digest"]["ranks_agree"] and d["k_digest"]["committed"] is not None
+    assert d["alt"]["bit_identical_to_1gpu"] is True and d["alt"]["k_digest"]["sum"] == d["k_digest"]["sum"]
     assert ("row-band" in d["config"]["parallelism"]) == (shard == "rows")
     assert ("combo-sharded" in d["config"]["parallelism"]) == (shard == "combos")
     assert d["alt"]["value"] > 0 and ("row-band" in d["alt"]["parallelism"]) == (shard == "combos")
@@ -523,15 +527,41 @@ def test_bench_rccl_leg_on_one_rank(native):
     env = dict(os.environ, FSK_BENCH_FORCE_DIST="1", MASTER_PORT="29741")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    for extra, path in ((["--n-seq", "9000"], "dense"), (["--config", "4"], "sparse")):
+    for extra, path in ((["--n-seq", "8000"], "dense"), (["--config", "4"], "sparse")):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
                             "--no-cpu-baseline", "--no-also"] + extra, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         d = json.loads(r.stdout.strip().splitlines()[-1])
         assert d["comm"]["rccl_ranks"] == 1 and "RCCL" in d["comm"]["backend"] and d["comm"]["allreduce_dtype"] == "int32"
         assert d["config"]["path"] == path and d["value"] > 0
+        assert d["bit_identical_to_1gpu"] is True   # int32 narrowing + RCCL left every cell what one engine computes
         if path == "sparse":
             assert d["config"]["combos"] == 1001 and d["roofline"]["bound"] == "hbm" and d["roofline"]["cell_updates_per_step"] > 1e9
+
+
+@pytest.mark.parametrize("gpus,share", [(1, False), (3, True)])
+def test_bench_inproc(native, gpus, share):
+    """`bench.py --gpus N --inproc`: the job from ONE process through fsk_create_multi (no torch in it). One
+    GPU: RCCL from the host C++ over a world of one; three engines sharing the GPU: the P2P kernels."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FSK_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    if share:
+        env["FSK_BENCH_SHARE_GPU"] = "1"
+    for extra, path in ((["--n-seq", "8000"], "dense"), (["--config", "4"], "sparse")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--inproc", "--steps", "2", "--warmup", "1",
+                            "--no-cpu-baseline", "--no-also"] + extra, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["n_gpus"] == gpus and d["value"] > 0 and "in-process" in d["config"]["parallelism"] and d["config"]["path"] == path
+        assert d["bit_identical_to_1gpu"] is True
+        assert d["comm"]["ranks"] == gpus and d["comm"]["rccl_ranks"] == (0 if share else 1)
+        assert d["comm"]["allreduce_dtype"] == "int32" and sum(d["comm"]["combos_per_engine"]) == d["config"]["combos"]
+        assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
 
 
 @pytest.mark.parametrize("surface", ["ctypes", "pybind"])

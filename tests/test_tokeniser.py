@@ -95,3 +95,21 @@ def test_regression_labels_and_non_ascii(tmp_path):
     assert X == [[1, 2, 1, 3], [2, 3]] and Y == [1, 0]
     toks, off, lab = rd.read_packed(str(q))  # same object: ids stay
     assert toks.tolist() == [1, 2, 1, 3, 2, 3] and off.tolist() == [0, 4, 6] and lab.tolist() == [1, 0]
+
+
+def test_reader_without_the_native_library(monkeypatch):
+    """On a host where libfastsk_amd.so is not built the tokeniser falls back to its numpy pass over the
+    text: same tokens, offsets, labels and vocabulary as the native reader."""
+    from fastsk_amd import _native
+    from fastsk_amd.utils import FastaUtility
+    want = np.load(os.path.join(FASTA, "expected.npz"))
+
+    def missing():
+        raise ImportError("libfastsk_amd.so not found")
+    monkeypatch.setattr(_native, "library", missing)
+    rd = FastaUtility()
+    for name in ("messy.train.fasta", "messy.test.fasta"):
+        toks, off, labels = rd.read_packed(os.path.join(FASTA, name))
+        assert np.array_equal(toks, want[name + ":tokens"]) and np.array_equal(np.diff(off), want[name + ":lengths"])
+        assert np.array_equal(labels, want[name + ":labels"])
+    assert rd._vocab.size() == 12  # id 0 + the eleven symbols of the two messy files
