@@ -60,8 +60,9 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     while (keybits < 62 && ((u64)1 << keybits) < (u64)e->V) ++keybits;
     const int sb = e->sx_sb;
     const int passes = (keybits + 7) / 8;
-    const int nbits = (keybits + passes - 1) / passes;  // the k-mer bits split evenly: 19 bits sort as 7 + 6 + 6, not 8 + 8 + 3
-    const uint32_t dmask = (1u << nbits) - 1u;
+    // the k-mer bits split evenly over the passes: 19 bits sort as 7 + 6 + 6, not 8 + 8 + 3 (a ballot per bit and record)
+    auto pass_bits = [&](int p) { return keybits / passes + (p < keybits % passes ? 1 : 0); };
+    const uint32_t dmask = (1u << pass_bits(0)) - 1u;  // (the extraction counts the first pass's digits)
     const uint32_t tps = (nfeat + fsk::SX_TILE - 1) / fsk::SX_TILE;   // sort tiles per slot
     const uint32_t tpg = (nfeat + fsk::SG_TILE - 1) / fsk::SG_TILE;   // segment tiles per slot
     const uint32_t ntiles = tpg * (uint32_t)nb;
@@ -127,14 +128,19 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
 
     e->tic();
     int cur = 0;
-    for (int p = 0; p < passes; ++p) {
-        const int shift = sb + nbits * p;
+    for (int p = 0, shift = sb; p < passes; shift += pass_bits(p), ++p) {
+        const int nbits = pass_bits(p);
         if (p > 0)  // (the extraction counted the first pass's digits)
-            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_hist<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tps, shift, dmask,
-                       e->d_blockhist.p);
+            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_hist<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tps, shift,
+                       (1u << nbits) - 1u, e->d_blockhist.p);
         FSK_LAUNCH(fsk::k_sx_scan_slot, dim3(nb), dim3(1024), 0, e->stream, e->d_blockhist.p, tps, e->d_totals.p);
-        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_scatter<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, rec[cur], rec[cur ^ 1], nfeat,
-                   tps, shift, nbits, e->d_blockhist.p, e->d_totals.p);
+        {   // (function pointers: a template-id with a comma cannot pass through the launch macro)
+            auto k_scatter = nbits <= 4 ? fsk::k_sx_scatter<RecT, 4> : nbits == 5 ? fsk::k_sx_scatter<RecT, 5>
+                             : nbits == 6 ? fsk::k_sx_scatter<RecT, 6> : nbits == 7 ? fsk::k_sx_scatter<RecT, 7>
+                                                                                     : fsk::k_sx_scatter<RecT, 8>;
+            FSK_LAUNCH(k_scatter, dim3(tps, nb), dim3(256), 0, e->stream, (const RecT*)rec[cur], rec[cur ^ 1], nfeat, tps, shift, nbits,
+                       (const uint32_t*)e->d_blockhist.p, (const uint32_t*)e->d_totals.p);
+        }
         cur ^= 1;
         e->st.launches += 3;
     }
