@@ -181,10 +181,22 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             e->st.launches += 2;
         }
     }
-    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_seg_write<RecT>), dim3(tpg, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tpg, sb,
-               e->d_ebase.p, e->d_tile_rs.p, e->d_E.p, e->d_Pk.p, e->sx_own_shift, O,
-               lists ? e->d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->d_tile_stat.p,
-               skip_from, skipping ? (const int*)e->d_tile_ts.p : (const int*)nullptr, skipping ? e->d_Tk.p : (uint32_t*)nullptr);
+    // entries in the packed format (4 + 2 + 2 bytes) when sequence ids, multiplicities and ranks fit 16 bits
+    const bool packed = e->N < 65535 && e->maxW < 65536u;
+    if (packed) {
+        auto k_seg = fsk::k_sx_seg_write<RecT, true>;
+        FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, e->stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)e->d_ebase.p,
+                   (const int*)e->d_tile_rs.p, reinterpret_cast<uint32_t*>(e->d_E.p), reinterpret_cast<uint16_t*>(e->d_Pk.p), e->sx_own_shift, O,
+                   lists ? e->d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->d_tile_stat.p,
+                   skip_from, skipping ? (const int*)e->d_tile_ts.p : (const int*)nullptr,
+                   skipping ? reinterpret_cast<uint16_t*>(e->d_Tk.p) : (uint16_t*)nullptr);
+    } else {
+        auto k_seg = fsk::k_sx_seg_write<RecT, false>;
+        FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, e->stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)e->d_ebase.p,
+                   (const int*)e->d_tile_rs.p, e->d_E.p, e->d_Pk.p, e->sx_own_shift, O,
+                   lists ? e->d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->d_tile_stat.p,
+                   skip_from, skipping ? (const int*)e->d_tile_ts.p : (const int*)nullptr, skipping ? e->d_Tk.p : (uint32_t*)nullptr);
+    }
     stat_pin[0] = stat_pin[1] = 0;
     e->st.launches += 3;
     u64 words = 0;
@@ -220,11 +232,20 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             if (!guarded && (size_t)words > e->d_ulist.cap)  // (grown with headroom: the batches of a pass differ by a few percent)
                 FSK_HIP(e->d_ulist.reserve((size_t)std::max<u64>(1, words + words / 4)));
             // (function pointers: a template-id with a comma cannot pass through the launch macro)
-            auto k_emit = skipping ? fsk::k_sx_emit<false, true> : fsk::k_sx_emit<false, false>;
-            FSK_LAUNCH(k_emit, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
-                       (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)e->d_list_off.p,
-                       (const uint32_t*)e->d_ucount.p, e->d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
-                       slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr, (const u64*)e->d_sxstat.p, cap_words);
+            if (packed) {
+                auto k_emit = skipping ? fsk::k_sx_emit<false, true, true> : fsk::k_sx_emit<false, false, true>;
+                FSK_LAUNCH(k_emit, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, reinterpret_cast<const uint32_t*>(e->d_E.p),
+                           reinterpret_cast<const uint16_t*>(e->d_Pk.p), (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p,
+                           e->sx_own_shift, O, (const uint32_t*)e->d_list_off.p, (const uint32_t*)e->d_ucount.p, e->d_ulist.p, (uint32_t)row0,
+                           (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg, slot_stride,
+                           skipping ? reinterpret_cast<const uint16_t*>(e->d_Tk.p) : (const uint16_t*)nullptr, (const u64*)e->d_sxstat.p, cap_words);
+            } else {
+                auto k_emit = skipping ? fsk::k_sx_emit<false, true, false> : fsk::k_sx_emit<false, false, false>;
+                FSK_LAUNCH(k_emit, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
+                           (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)e->d_list_off.p,
+                           (const uint32_t*)e->d_ucount.p, e->d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
+                           slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr, (const u64*)e->d_sxstat.p, cap_words);
+            }
             const size_t lds = (size_t)e->sx_cap * sizeof(uint32_t);
 #ifndef FSK_EMU
             FSK_HIP(hipFuncSetAttribute((const void*)fsk::k_sx_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -248,11 +269,20 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             e->st.launches += 2;
         }
     } else {
-        auto k_emit = skipping ? fsk::k_sx_emit<true, true> : fsk::k_sx_emit<true, false>;
-        FSK_LAUNCH(k_emit, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
-                   (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)nullptr,
-                   (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
-                   slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr, (const u64*)nullptr, ~(u64)0);
+        if (packed) {
+            auto k_emit = skipping ? fsk::k_sx_emit<true, true, true> : fsk::k_sx_emit<true, false, true>;
+            FSK_LAUNCH(k_emit, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, reinterpret_cast<const uint32_t*>(e->d_E.p),
+                       reinterpret_cast<const uint16_t*>(e->d_Pk.p), (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift,
+                       O, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod,
+                       cmax, e->sx_pb, K, tpg, slot_stride, skipping ? reinterpret_cast<const uint16_t*>(e->d_Tk.p) : (const uint16_t*)nullptr,
+                       (const u64*)nullptr, ~(u64)0);
+        } else {
+            auto k_emit = skipping ? fsk::k_sx_emit<true, true, false> : fsk::k_sx_emit<true, false, false>;
+            FSK_LAUNCH(k_emit, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
+                       (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
+                       slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr, (const u64*)nullptr, ~(u64)0);
+        }
         e->st.launches += 1;
     }
     e->toc(&e->st.ms_pairs);

@@ -40,11 +40,13 @@ __device__ __forceinline__ unsigned fsk_mbcnt(unsigned lo, unsigned hi) {
 // flat_load_dword sc0 sc1 + s_waitcnt vmcnt(0))
 #ifdef FSK_EMU
 #define FSK_LDS_LOAD_U64(ptr) (*reinterpret_cast<const unsigned long long*>(ptr))
+#define FSK_LDS_LOAD_U32(ptr) (*reinterpret_cast<const unsigned int*>(ptr))
 #define FSK_LDS_VOLATILE_U32(ptr) (*reinterpret_cast<volatile unsigned int*>(ptr))
 #define FSK_LDS_LOAD_U8(ptr) (*reinterpret_cast<const unsigned char*>(ptr))
 #else
 #define FSK_LDS_LOAD_U8(ptr) (*(const __attribute__((address_space(3))) unsigned char*)(ptr))
 #define FSK_LDS_LOAD_U64(ptr) (*(const __attribute__((address_space(3))) unsigned long long*)(ptr))
+#define FSK_LDS_LOAD_U32(ptr) (*(const __attribute__((address_space(3))) unsigned int*)(ptr))
 #define FSK_LDS_VOLATILE_U32(ptr) (*(volatile __attribute__((address_space(3))) unsigned int*)(ptr))
 #endif
 
