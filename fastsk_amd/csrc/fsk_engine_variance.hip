@@ -45,7 +45,7 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     // stopping iteration is dropped.
     // (two batches in flight: the sums of one run on the second stream under the kernels of the next;
     // a third would only add iterations that are thrown away when the stop test fires)
-    constexpr int AHEAD = 4, MAX_DEPTH = 2;
+    constexpr int AHEAD = 8, MAX_DEPTH = 2;
     const int DEPTH = MAX_DEPTH;
     const int RING = DEPTH * AHEAD + 1;
     const bool trace = getenv("FSK_TRACE") != nullptr;  // stderr: where the wall time of this mode goes

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_welford(const SrcT* Ks, const double* K
 // host asks for them by running a prefix of the batch again (it does when its stop test fires inside
 // the batch). Per cell and iteration the same IEEE operations in the same order as k_welford.
 // prod / bsum of slot q: prod + q * prod_stride, bsum + q * nblk; write_prod = 0: only K_hat_out.
-constexpr int WF_SLOTS = 4;
+constexpr int WF_SLOTS = 8;
 template <typename SrcT>
 __global__ __launch_bounds__(256) void k_welford_batch(const SrcT* Ks, int nslots, const double* K_hat_in, double* K_hat_out, double* prod,
                                                        u64 prod_stride, u64 pairs, u64 train_pairs, double first_iter, double* bsum,
