@@ -176,8 +176,12 @@ def config_roofline(st, wall_s):
     dataflow's tile kernel is priced against the v_dot8 issue peak (count-MACs / tile-kernel time)."""
     keybits = max(1, int(np.ceil(np.log2(max(2, st["key_space"])))))
     P = (keybits + 7) // 8
-    alg = 16.0 * st["cell_updates"] + st["combos_done"] * (16.0 * P * st["n_feat"] + st["n_feat"] * st["bits_per_symbol"] / 8.0)
-    out = {"path": "dense" if st["path_used"] == 1 else "sparse", "cell_updates_U": int(st["cell_updates"]),
+    # (variance mode runs batches of iterations ahead of its stop test and drops what lies beyond the stop: the
+    # update count of the combos that make up the result is the issued combos' pro rata)
+    useful = st["combos_done"] / st["combos_issued"] if st.get("combos_issued") else 1.0
+    alg = 16.0 * st["cell_updates"] * useful + st["combos_done"] * (16.0 * P * st["n_feat"] + st["n_feat"] * st["bits_per_symbol"] / 8.0)
+    out = {"path": "dense" if st["path_used"] == 1 else "sparse", "cell_updates_U": int(st["cell_updates"] * useful),
+           "combos_issued": int(st.get("combos_issued", st["combos_done"])),
            "algorithmic_GB": alg / 1e9, "algorithmic_GBs": alg / 1e9 / wall_s, "gpu_ms": 1e3 * wall_s,
            "frac_of_hbm_peak": alg / 1e9 / wall_s / HBM_PEAK_GBS,
            "kernel_ms": {k[3:]: round(st[k], 3) for k in ("ms_count", "ms_tile", "ms_extract", "ms_sort", "ms_segment", "ms_pairs") if st[k]}}

@@ -181,7 +181,10 @@ int do_accumulate(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t r
         (void)hipEventDestroy(a);
         (void)hipEventDestroy(b);
     }
-    if (rc == FSK_OK && row1 >= e->N) e->st.combos_done += n;  // a combo is done when its last row band is
+    if (rc == FSK_OK && row1 >= e->N) {  // a combo is done when its last row band is
+        e->st.combos_done += n;
+        e->st.combos_issued += (double)n;
+    }
     return rc;
 }
 

@@ -219,7 +219,7 @@ namespace fsk_detail {
 
 constexpr size_t LDS_BUDGET = 150 * 1024;       // of 160 KiB per CU
 constexpr u64 DENSE_MAX_KEYS = 16384;           // count panels: alphabet^k <= this (DNA up to k = 7)
-constexpr size_t SPARSE_MAX_RECORDS = 1u << 25; // records per sort batch
+constexpr size_t SPARSE_MAX_RECORDS = 1u << 27; // records per sort batch (0.5 GB of 4-byte records; each batch pays ~20 launches)
 constexpr u64 SX_MAX_LIST_WORDS = (u64)1 << 31;  // update words of one sparse batch beyond which its pairs go to K with atomics
 constexpr int FSK_RETRY_UNGROUPED = 1;  // internal: a per-slot sparse batch has to be redone one combo at a time
 

@@ -523,6 +523,7 @@ int group_get_stats(fsk_engine* lead, fsk_stats* out) {
         out->launches += s.launches;
         out->dense_macs += s.dense_macs;
         out->panel_bytes += s.panel_bytes;
+        out->combos_issued += s.combos_issued;
     }
     // integer modes: engines 1.. start every accumulate from a reset triangle (and a reset counter)
     if (!lead->result_f64) out->combos_done = g->combos_since_reset;

@@ -114,7 +114,8 @@ typedef struct fsk_stats {
     double count_launches;   /* launches of the segment-count kernel (panel cache misses)        */
     double compact_keys_avg; /* key compaction on: mean keys per combo that really occur (else 0) */
     double batches_redone;   /* sparse: batches enqueued ahead of their word count that did not fit */
-    double reserved[1];
+    double combos_issued;    /* combos whose kernels ran: combos_done + the iterations variance mode ran ahead of
+                                its stop test and dropped (cell_updates and the ms_* cover all of them)      */
 } fsk_stats;
 
 /* ---- lifecycle: replaces FastSK::FastSK (fastsk.cpp:19-28) and ~nothing (the reference leaks) */

@@ -43,7 +43,8 @@ def main():
                 wall = dt
         # algorithmic bytes of the direct-atomic dataflow, 16*U + 16*P*nfeat + packed input per combo
         P = (max(1, int(np.ceil(np.log2(max(2, st["key_space"]))))) + 7) // 8  # 8-bit LSD passes over the packed k-mer
-        alg = 16.0 * st["cell_updates"] + st["combos_done"] * (16.0 * P * st["n_feat"] + st["n_feat"] * st["bits_per_symbol"] / 8.0)
+        useful = st["combos_done"] / st["combos_issued"] if st.get("combos_issued") else 1.0  # (variance mode drops what it ran ahead of its stop)
+        alg = 16.0 * st["cell_updates"] * useful + st["combos_done"] * (16.0 * P * st["n_feat"] + st["n_feat"] * st["bits_per_symbol"] / 8.0)
         rows.append(dict(case=name, N=ntr + nte, combos=int(st["combos_done"]), gpu_seconds=wall,
                          algorithmic_GB=round(alg / 1e9, 2), algorithmic_GB_per_s=round(alg / 1e9 / wall, 1),
                          frac_of_8TBps=round(alg / 1e9 / wall / 8000.0, 3),
