@@ -28,9 +28,11 @@ __device__ __forceinline__ void count_windows(const uint8_t* symT, uint32_t* his
         // sequence's end are zero padding inside symT (the trip condition keeps them in range);
         // their updates are predicated off.
         constexpr int WPT = 4;
-        const uint8_t* p[K > 0 ? K : 1];
+        // (byte offsets into symT, read with explicit LDS loads: as an array of `const uint8_t*` the columns are
+        // generic pointers and every symbol read becomes a flat_load_ubyte)
+        uint32_t p[K > 0 ? K : 1];
 #pragma unroll
-        for (int c = 0; c < K; ++c) p[c] = symT + (j0 - cb + pr[c]) * PANEL + r;
+        for (int c = 0; c < K; ++c) p[c] = (j0 - cb + pr[c]) * PANEL + r;
         uint32_t j = j0;
         for (; j + 4u * (WPT - 1) < hi; j += 4u * WPT) {
             uint32_t kk[WPT];
@@ -39,7 +41,7 @@ __device__ __forceinline__ void count_windows(const uint8_t* symT, uint32_t* his
 #pragma unroll
             for (int c = 0; c < K; ++c) {
 #pragma unroll
-                for (int u = 0; u < WPT; ++u) kk[u] = mad24(kk[u], sigma, p[c][u * 4 * PANEL]);
+                for (int u = 0; u < WPT; ++u) kk[u] = mad24(kk[u], sigma, FSK_LDS_LOAD_U8(symT + p[c] + u * 4 * PANEL));
                 p[c] += 4 * WPT * PANEL;
             }
 #pragma unroll
@@ -52,7 +54,7 @@ __device__ __forceinline__ void count_windows(const uint8_t* symT, uint32_t* his
             uint32_t k0 = 0;
 #pragma unroll
             for (int c = 0; c < K; ++c) {
-                k0 = mad24(k0, sigma, p[c][0]);
+                k0 = mad24(k0, sigma, FSK_LDS_LOAD_U8(symT + p[c]));
                 p[c] += 4 * PANEL;
             }
             k0 -= key_lo;
