@@ -298,7 +298,7 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     { const char* f = getenv("FSK_LIST_MAX_WORDS"); if (f && atoll(f) > 0) e->sx_max_words = std::min<u64>(SX_MAX_LIST_WORDS, (u64)atoll(f)); }
     { const char* f = getenv("FSK_TILE_SPLITS"); e->force_splits = f ? atoi(f) : 0; }
     { const char* f = getenv("FSK_TILE_DMA"); e->tile_dma = f ? atoi(f) : 1; }
-    { const char* f = getenv("FSK_COMPACT_DMA"); e->compact_dma = f ? atoi(f) : 0; }
+    { const char* f = getenv("FSK_COMPACT_DMA"); e->compact_dma = f ? atoi(f) : 1; }
     { const char* f = getenv("FSK_DENSE_CHUNK"); e->force_chunk = f ? (uint32_t)atoi(f) : 0u; }
     if (hipStreamCreate(&e->stream) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
         hipEventCreate(&e->ev1) != hipSuccess) {
