@@ -138,7 +138,8 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             auto k_scatter = nbits <= 4 ? fsk::k_sx_scatter<RecT, 4> : nbits == 5 ? fsk::k_sx_scatter<RecT, 5>
                              : nbits == 6 ? fsk::k_sx_scatter<RecT, 6> : nbits == 7 ? fsk::k_sx_scatter<RecT, 7>
                                                                                      : fsk::k_sx_scatter<RecT, 8>;
-            FSK_LAUNCH(k_scatter, dim3(tps, nb), dim3(256), 0, e->stream, (const RecT*)rec[cur], rec[cur ^ 1], nfeat, tps, shift, nbits,
+            FSK_LAUNCH(k_scatter, dim3(fsk::xcd_grid(tps * (uint32_t)nb)), dim3(256), 0, e->stream, (const RecT*)rec[cur], rec[cur ^ 1], nfeat, tps,
+                       (uint32_t)nb, shift, nbits,
                        (const uint32_t*)e->d_blockhist.p, (const uint32_t*)e->d_totals.p);
         }
         cur ^= 1;
@@ -234,17 +235,17 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             // (function pointers: a template-id with a comma cannot pass through the launch macro)
             if (packed) {
                 auto k_emit = skipping ? fsk::k_sx_emit<false, true, true> : fsk::k_sx_emit<false, false, true>;
-                FSK_LAUNCH(k_emit, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, reinterpret_cast<const uint32_t*>(e->d_E.p),
+                FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, e->stream, reinterpret_cast<const uint32_t*>(e->d_E.p),
                            reinterpret_cast<const uint16_t*>(e->d_Pk.p), (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p,
                            e->sx_own_shift, O, (const uint32_t*)e->d_list_off.p, (const uint32_t*)e->d_ucount.p, e->d_ulist.p, (uint32_t)row0,
                            (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg, slot_stride,
-                           skipping ? reinterpret_cast<const uint16_t*>(e->d_Tk.p) : (const uint16_t*)nullptr, (const u64*)e->d_sxstat.p, cap_words);
+                           skipping ? reinterpret_cast<const uint16_t*>(e->d_Tk.p) : (const uint16_t*)nullptr, (const u64*)e->d_sxstat.p, cap_words, ntiles);
             } else {
                 auto k_emit = skipping ? fsk::k_sx_emit<false, true, false> : fsk::k_sx_emit<false, false, false>;
-                FSK_LAUNCH(k_emit, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
+                FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
                            (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)e->d_list_off.p,
                            (const uint32_t*)e->d_ucount.p, e->d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
-                           slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr, (const u64*)e->d_sxstat.p, cap_words);
+                           slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr, (const u64*)e->d_sxstat.p, cap_words, ntiles);
             }
             const size_t lds = (size_t)e->sx_cap * sizeof(uint32_t);
 #ifndef FSK_EMU
@@ -271,17 +272,17 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     } else {
         if (packed) {
             auto k_emit = skipping ? fsk::k_sx_emit<true, true, true> : fsk::k_sx_emit<true, false, true>;
-            FSK_LAUNCH(k_emit, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, reinterpret_cast<const uint32_t*>(e->d_E.p),
+            FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, e->stream, reinterpret_cast<const uint32_t*>(e->d_E.p),
                        reinterpret_cast<const uint16_t*>(e->d_Pk.p), (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift,
                        O, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod,
                        cmax, e->sx_pb, K, tpg, slot_stride, skipping ? reinterpret_cast<const uint16_t*>(e->d_Tk.p) : (const uint16_t*)nullptr,
-                       (const u64*)nullptr, ~(u64)0);
+                       (const u64*)nullptr, ~(u64)0, ntiles);
         } else {
             auto k_emit = skipping ? fsk::k_sx_emit<true, true, false> : fsk::k_sx_emit<true, false, false>;
-            FSK_LAUNCH(k_emit, dim3(ntiles), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
+            FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
                        (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)nullptr,
                        (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
-                       slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr, (const u64*)nullptr, ~(u64)0);
+                       slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr, (const u64*)nullptr, ~(u64)0, ntiles);
         }
         e->st.launches += 1;
     }
