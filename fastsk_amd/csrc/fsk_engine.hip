@@ -298,6 +298,7 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     { const char* f = getenv("FSK_LIST_MAX_WORDS"); if (f && atoll(f) > 0) e->sx_max_words = std::min<u64>(SX_MAX_LIST_WORDS, (u64)atoll(f)); }
     { const char* f = getenv("FSK_TILE_SPLITS"); e->force_splits = f ? atoi(f) : 0; }
     { const char* f = getenv("FSK_TILE_DMA"); e->tile_dma = f ? atoi(f) : 1; }
+    { const char* f = getenv("FSK_SPARSE_LANES"); if (f) e->sx_two_lanes = atoi(f) >= 2; }
     { const char* f = getenv("FSK_COMPACT_DMA"); e->compact_dma = f ? atoi(f) : 1; }
     { const char* f = getenv("FSK_DENSE_CHUNK"); e->force_chunk = f ? (uint32_t)atoi(f) : 0u; }
     if (hipStreamCreate(&e->stream) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
@@ -325,10 +326,9 @@ void fsk_detail::one_destroy(fsk_engine* e) {
     e->d_words.release(); e->d_wstart.release(); e->d_len.release(); e->d_fstart.release(); e->d_featseq.release();
     e->d_pos.release(); e->d_allpos.release(); e->d_bsum.release(); e->d_seqblk.release(); e->K_store.release(); e->d_Kf64.release(); e->d_Khat.release(); e->d_prod.release();
     e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_Kslots.release(); e->d_cell_idx.release(); e->d_C4.release(); e->d_C4H.release(); e->d_rowmask.release(); e->d_flag.release(); e->d_tiletab.release(); e->d_keybits.release(); e->d_lut.release(); e->d_vc.release();
-    for (int b = 0; b < 2; ++b) e->d_keys[b].release();
-    e->d_blockhist.release(); e->d_totals.release(); e->d_tile_ent.release(); e->d_ebase.release(); e->d_Pk.release();
-    e->d_owner_r0.release(); e->d_ucount.release(); e->d_uchunk.release(); e->d_part_base.release(); e->d_tile_stat.release(); e->d_utot.release(); e->d_list_off.release(); e->d_ulist.release();
-    e->d_tile_lrh.release(); e->d_tile_rs.release(); e->d_tile_lth.release(); e->d_tile_ts.release(); e->d_Tk.release(); e->d_E.release(); e->d_sxstat.release(); e->d_segc.release(); e->d_U.release(); e->d_U2.release();
+    if (e->lane_stream) { (void)hipStreamSynchronize(e->lane_stream); (void)hipStreamDestroy(e->lane_stream); }
+    for (auto& lane : e->sxs) lane.release();
+    e->d_owner_r0.release(); e->d_U.release(); e->d_U2.release();
     if (e->h_prod) (void)hipHostFree(e->h_prod);
     if (e->h_sx_pos) (void)hipHostFree(e->h_sx_pos);
     if (e->h_sx_stat) (void)hipHostFree(e->h_sx_stat);

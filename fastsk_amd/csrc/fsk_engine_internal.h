@@ -81,6 +81,26 @@ struct DeviceScope {
 
 using fsk_detail::DevBuf;
 
+// What one batch of the sparse dataflow works in: sort records, tile records, entries, update streams. Two sets
+// ("lanes"): variance mode keeps two batches in flight and runs them on two streams, so that the many short
+// kernels of one batch's sort and segmentation fill the gaps of the other's emit / consume / Welford kernels.
+struct SxScratch {
+    DevBuf<unsigned char> d_keys[2];      // packed sort records (u32 or u64), double-buffered
+    DevBuf<uint32_t> d_blockhist, d_totals, d_tile_ent, d_ebase, d_Pk, d_Tk, d_ucount, d_uchunk, d_utot, d_list_off, d_ulist, d_part_base;
+    DevBuf<u64> d_tile_stat;
+    DevBuf<uint32_t> d_segc;              // chunk records of the segment scan (batches of many tiles)
+    DevBuf<int> d_tile_lrh, d_tile_rs, d_tile_lth, d_tile_ts;
+    DevBuf<uint2> d_E;                    // entries: {sequence, multiplicity} (or the packed format)
+    DevBuf<u64> d_sxstat;
+    void release() {
+        for (auto& k : d_keys) k.release();
+        d_blockhist.release(); d_totals.release(); d_tile_ent.release(); d_ebase.release(); d_Pk.release(); d_Tk.release();
+        d_ucount.release(); d_uchunk.release(); d_utot.release(); d_list_off.release(); d_ulist.release(); d_part_base.release();
+        d_tile_stat.release(); d_segc.release(); d_tile_lrh.release(); d_tile_rs.release(); d_tile_lth.release(); d_tile_ts.release();
+        d_E.release(); d_sxstat.release();
+    }
+};
+
 struct fsk_engine {
     fsk_config cfg{};
     std::string err;
@@ -148,13 +168,11 @@ struct fsk_engine {
     std::vector<int32_t> prep_combos;              // combos whose count panels are resident
     bool prep_valid = false, prep_overflow = false;
     // sparse scratch
-    DevBuf<unsigned char> d_keys[2];      // packed sort records (u32 or u64), double-buffered
-    DevBuf<uint32_t> d_blockhist, d_totals, d_tile_ent, d_ebase, d_Pk, d_Tk, d_owner_r0, d_ucount, d_uchunk, d_utot, d_list_off, d_ulist, d_part_base;
-    DevBuf<u64> d_tile_stat;
-    DevBuf<uint32_t> d_segc;              // chunk records of the segment scan (batches of many tiles)
-    DevBuf<int> d_tile_lrh, d_tile_rs, d_tile_lth, d_tile_ts;
-    DevBuf<uint2> d_E;                    // entries: {sequence, multiplicity}
-    DevBuf<u64> d_sxstat, d_U;
+    SxScratch sxs[2];                     // lane 0: every exact accumulate; lanes 0 and 1: variance mode's batches in flight
+    hipStream_t lane_stream = nullptr;    // lane 1's stream (lane 0 runs on `stream`)
+    int sx_two_lanes = 1;                 // FSK_SPARSE_LANES=1: variance mode on one stream (testing)
+    DevBuf<uint32_t> d_owner_r0;
+    DevBuf<u64> d_U;
     std::vector<uint32_t> h_owner_r0;     // owner bands of K: rows [r0[o], r0[o+1])
     uint32_t n_owners = 0, sx_rounds = 1, sx_cap = 0;
     int sx_pb = 16, sx_sb = 1, sx_keybits = 1, sx_own_shift = 13;
@@ -240,6 +258,8 @@ int fetch_pending_u(fsk_engine* e);
 int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0, int64_t row1);
 
 // fsk_engine_sparse.hip
+// which lane (scratch set + stream) the deferred batch `defer` of variance mode runs in
+inline int sx_lane_of(const fsk_engine* e, int defer) { return (defer >= 0 && e->sx_two_lanes && !e->cfg.profile) ? (defer & 1) : 0; }
 void plan_owner_bands(fsk_engine* e);
 bool sx_harvest(fsk_engine* e, int slot);
 int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0, int64_t row1, u64 slot_stride = 0,

@@ -50,7 +50,9 @@ void plan_owner_bands(fsk_engine* e) {
 // counts and sizes the streams exactly; else it only enqueues, for streams of at most guard_cap words.
 template <typename RecT>
 int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t row0, int64_t row1, u64 slot_stride,
-                 unsigned char* pos_pin, u64* stat_pin, u64 guard_cap) {
+                 unsigned char* pos_pin, u64* stat_pin, u64 guard_cap, int lane) {
+    SxScratch& S = e->sxs[lane];
+    hipStream_t stream = lane ? e->lane_stream : e->stream;
     const uint32_t nfeat = (uint32_t)e->nfeat;
     const size_t nrec = (size_t)nb * nfeat;
     if (nrec == 0) return FSK_OK;
@@ -68,38 +70,39 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     const uint32_t ntiles = tpg * (uint32_t)nb;
     const bool lists = e->sx_lists && !e->force_global_pairs;
     const uint32_t O = e->n_owners;
-    for (int b = 0; b < 2; ++b) FSK_HIP(e->d_keys[b].reserve(nrec * sizeof(RecT)));
-    FSK_HIP(e->d_blockhist.reserve((size_t)256 * tps * nb));
-    FSK_HIP(e->d_totals.reserve((size_t)256 * nb));
-    FSK_HIP(e->d_tile_ent.reserve(ntiles));
-    FSK_HIP(e->d_tile_lrh.reserve(ntiles));
-    FSK_HIP(e->d_tile_rs.reserve(ntiles));
-    FSK_HIP(e->d_ebase.reserve((size_t)ntiles + 1));
-    FSK_HIP(e->d_E.reserve(nrec));
-    FSK_HIP(e->d_Pk.reserve(nrec));
+    for (int b = 0; b < 2; ++b) FSK_HIP(S.d_keys[b].reserve(nrec * sizeof(RecT)));
+    FSK_HIP(S.d_blockhist.reserve((size_t)256 * tps * nb));
+    FSK_HIP(S.d_totals.reserve((size_t)256 * nb));
+    FSK_HIP(S.d_tile_ent.reserve(ntiles));
+    FSK_HIP(S.d_tile_lrh.reserve(ntiles));
+    FSK_HIP(S.d_tile_rs.reserve(ntiles));
+    FSK_HIP(S.d_ebase.reserve((size_t)ntiles + 1));
+    FSK_HIP(S.d_E.reserve(nrec));
+    FSK_HIP(S.d_Pk.reserve(nrec));
     // skip_test_block: test rows pair only with the train entries of their runs (and themselves)
     const uint32_t skip_from = e->cfg.skip_test_block && e->n_test > 0 ? (uint32_t)e->n_train : 0xffffffffu;
     const bool skipping = skip_from != 0xffffffffu;
     if (skipping) {
-        FSK_HIP(e->d_Tk.reserve(nrec));
-        FSK_HIP(e->d_tile_lth.reserve(ntiles));
-        FSK_HIP(e->d_tile_ts.reserve(ntiles));
+        FSK_HIP(S.d_Tk.reserve(nrec));
+        FSK_HIP(S.d_tile_lth.reserve(ntiles));
+        FSK_HIP(S.d_tile_ts.reserve(ntiles));
     }
-    FSK_HIP(e->d_sxstat.reserve(3));
-    FSK_HIP(e->d_tile_stat.reserve((size_t)2 * ntiles));
+    FSK_HIP(S.d_sxstat.reserve(3));
+    FSK_HIP(S.d_tile_stat.reserve((size_t)2 * ntiles));
     FSK_HIP(e->d_pos.reserve((size_t)nb * e->k));
     if (!e->owner_ready) {
         FSK_HIP(e->d_owner_r0.reserve(e->h_owner_r0.size()));
-        FSK_HIP(hipMemcpyAsync(e->d_owner_r0.p, e->h_owner_r0.data(), e->h_owner_r0.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-        e->owner_ready = true;  // (h_owner_r0 lives as long as the engine: no wait needed)
+        // (once per set of sequences, and every lane's kernels read it: a synchronous copy)
+        FSK_HIP(hipMemcpy(e->d_owner_r0.p, e->h_owner_r0.data(), e->h_owner_r0.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        e->owner_ready = true;
     }
     const uint32_t nchunks = (ntiles + fsk::UC_CHUNK - 1) / fsk::UC_CHUNK;
     if (lists) {
-        FSK_HIP(e->d_ucount.reserve((size_t)O * ntiles));
-        FSK_HIP(e->d_uchunk.reserve((size_t)O * nchunks));
-        FSK_HIP(e->d_utot.reserve(O));
-        FSK_HIP(e->d_list_off.reserve((size_t)O + 1));
-        FSK_HIP(e->d_part_base.reserve((size_t)O + 1));
+        FSK_HIP(S.d_ucount.reserve((size_t)O * ntiles));
+        FSK_HIP(S.d_uchunk.reserve((size_t)O * nchunks));
+        FSK_HIP(S.d_utot.reserve(O));
+        FSK_HIP(S.d_list_off.reserve((size_t)O + 1));
+        FSK_HIP(S.d_part_base.reserve((size_t)O + 1));
     }
     fsk::SxIds ids{};
     const bool by_id = nb <= 16;  // (variance mode: a handful of combos per batch) positions from the resident table
@@ -113,16 +116,16 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     } else {
         for (int s = 0; s < nb; ++s)
             memcpy(pos_pin + (size_t)s * e->k, &e->all_pos[(size_t)combos[s] * e->k], e->k);
-        FSK_HIP(hipMemcpyAsync(e->d_pos.p, pos_pin, (size_t)nb * e->k, hipMemcpyHostToDevice, e->stream));
-        FSK_HIP(hipMemsetAsync(e->d_sxstat.p, 0, 3 * sizeof(u64), e->stream));
+        FSK_HIP(hipMemcpyAsync(e->d_pos.p, pos_pin, (size_t)nb * e->k, hipMemcpyHostToDevice, stream));
+        FSK_HIP(hipMemsetAsync(S.d_sxstat.p, 0, 3 * sizeof(u64), stream));
     }
 
-    RecT* rec[2] = {(RecT*)e->d_keys[0].p, (RecT*)e->d_keys[1].p};
+    RecT* rec[2] = {(RecT*)S.d_keys[0].p, (RecT*)S.d_keys[1].p};
 
     e->tic();
-    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_extract<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, e->view(), e->d_featseq.p,
+    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_extract<RecT>), dim3(tps, nb), dim3(256), 0, stream, e->view(), e->d_featseq.p,
                e->d_fstart.p, nfeat, tps, e->k, e->sigma, sb, by_id ? (const uint8_t*)e->d_allpos.p : (const uint8_t*)e->d_pos.p, rec[0],
-               e->d_blockhist.p, dmask, ids, by_id ? e->d_sxstat.p : (u64*)nullptr);
+               S.d_blockhist.p, dmask, ids, by_id ? S.d_sxstat.p : (u64*)nullptr);
     e->toc(&e->st.ms_extract);
     e->st.launches += 1;
 
@@ -131,16 +134,16 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     for (int p = 0, shift = sb; p < passes; shift += pass_bits(p), ++p) {
         const int nbits = pass_bits(p);
         if (p > 0)  // (the extraction counted the first pass's digits)
-            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_hist<RecT>), dim3(tps, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tps, shift,
-                       (1u << nbits) - 1u, e->d_blockhist.p);
-        FSK_LAUNCH(fsk::k_sx_scan_slot, dim3(nb), dim3(1024), 0, e->stream, e->d_blockhist.p, tps, e->d_totals.p);
+            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_hist<RecT>), dim3(tps, nb), dim3(256), 0, stream, rec[cur], nfeat, tps, shift,
+                       (1u << nbits) - 1u, S.d_blockhist.p);
+        FSK_LAUNCH(fsk::k_sx_scan_slot, dim3(nb), dim3(1024), 0, stream, S.d_blockhist.p, tps, S.d_totals.p);
         {   // (function pointers: a template-id with a comma cannot pass through the launch macro)
             auto k_scatter = nbits <= 4 ? fsk::k_sx_scatter<RecT, 4> : nbits == 5 ? fsk::k_sx_scatter<RecT, 5>
                              : nbits == 6 ? fsk::k_sx_scatter<RecT, 6> : nbits == 7 ? fsk::k_sx_scatter<RecT, 7>
                                                                                      : fsk::k_sx_scatter<RecT, 8>;
-            FSK_LAUNCH(k_scatter, dim3(fsk::xcd_grid(tps * (uint32_t)nb)), dim3(256), 0, e->stream, (const RecT*)rec[cur], rec[cur ^ 1], nfeat, tps,
+            FSK_LAUNCH(k_scatter, dim3(fsk::xcd_grid(tps * (uint32_t)nb)), dim3(256), 0, stream, (const RecT*)rec[cur], rec[cur ^ 1], nfeat, tps,
                        (uint32_t)nb, shift, nbits,
-                       (const uint32_t*)e->d_blockhist.p, (const uint32_t*)e->d_totals.p);
+                       (const uint32_t*)S.d_blockhist.p, (const uint32_t*)S.d_totals.p);
         }
         cur ^= 1;
         e->st.launches += 3;
@@ -152,32 +155,32 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     e->tic();
     const uint32_t maxprod = (1u << e->sx_pb) - 1u;
     const uint32_t cmax = maxprod / std::max<uint32_t>(1u, e->maxW);  // multiplicities up to here: one word per pair
-    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_seg_count<RecT>), dim3(tpg, nb), dim3(256), 0, e->stream, rec[cur], nfeat, tpg, sb,
-               e->d_tile_ent.p, e->d_tile_lrh.p, skip_from, skipping ? e->d_tile_lth.p : (int*)nullptr);
+    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_seg_count<RecT>), dim3(tpg, nb), dim3(256), 0, stream, rec[cur], nfeat, tpg, sb,
+               S.d_tile_ent.p, S.d_tile_lrh.p, skip_from, skipping ? S.d_tile_lth.p : (int*)nullptr);
     {
-        const int* lth = skipping ? (const int*)e->d_tile_lth.p : (const int*)nullptr;
-        int* ts = skipping ? e->d_tile_ts.p : (int*)nullptr;
+        const int* lth = skipping ? (const int*)S.d_tile_lth.p : (const int*)nullptr;
+        int* ts = skipping ? S.d_tile_ts.p : (int*)nullptr;
         if (ntiles <= 4096u && !e->force_seg_chunks) {  // one workgroup walks the tile records
-            FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(1), dim3(1024), 0, e->stream, (const uint32_t*)e->d_tile_ent.p, (const int*)e->d_tile_lrh.p, ntiles,
-                       e->d_ebase.p, e->d_tile_rs.p, lth, ts, (const uint32_t*)nullptr, (const int*)nullptr, (const int*)nullptr,
+            FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(1), dim3(1024), 0, stream, (const uint32_t*)S.d_tile_ent.p, (const int*)S.d_tile_lrh.p, ntiles,
+                       S.d_ebase.p, S.d_tile_rs.p, lth, ts, (const uint32_t*)nullptr, (const int*)nullptr, (const int*)nullptr,
                        (uint32_t*)nullptr, (int*)nullptr, (int*)nullptr);
         } else {  // chunk totals, the same scan over the chunk records, the chunks with their carries
             const uint32_t nch = (ntiles + 1023u) / 1024u;
-            FSK_HIP(e->d_segc.reserve((size_t)6 * (nch + 1)));
-            uint32_t* c_tot = e->d_segc.p;
+            FSK_HIP(S.d_segc.reserve((size_t)6 * (nch + 1)));
+            uint32_t* c_tot = S.d_segc.p;
             int* c_lrh = reinterpret_cast<int*>(c_tot + (nch + 1));
             int* c_lth = c_lrh + (nch + 1);
             uint32_t* c_ex = reinterpret_cast<uint32_t*>(c_lth + (nch + 1));
             int* c_h = reinterpret_cast<int*>(c_ex + (nch + 1));
             int* c_t = c_h + (nch + 1);
-            FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(nch), dim3(1024), 0, e->stream, (const uint32_t*)e->d_tile_ent.p, (const int*)e->d_tile_lrh.p, ntiles,
+            FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(nch), dim3(1024), 0, stream, (const uint32_t*)S.d_tile_ent.p, (const int*)S.d_tile_lrh.p, ntiles,
                        (uint32_t*)nullptr, (int*)nullptr, lth, (int*)nullptr, (const uint32_t*)nullptr, (const int*)nullptr, (const int*)nullptr,
                        c_tot, c_lrh, c_lth);
-            FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(1), dim3(1024), 0, e->stream, (const uint32_t*)c_tot, (const int*)c_lrh, nch, c_ex, c_h,
+            FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(1), dim3(1024), 0, stream, (const uint32_t*)c_tot, (const int*)c_lrh, nch, c_ex, c_h,
                        skipping ? (const int*)c_lth : (const int*)nullptr, skipping ? c_t : (int*)nullptr, (const uint32_t*)nullptr,
                        (const int*)nullptr, (const int*)nullptr, (uint32_t*)nullptr, (int*)nullptr, (int*)nullptr);
-            FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(nch), dim3(1024), 0, e->stream, (const uint32_t*)e->d_tile_ent.p, (const int*)e->d_tile_lrh.p, ntiles,
-                       e->d_ebase.p, e->d_tile_rs.p, lth, ts, (const uint32_t*)c_ex, (const int*)c_h, (const int*)c_t, (uint32_t*)nullptr,
+            FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(nch), dim3(1024), 0, stream, (const uint32_t*)S.d_tile_ent.p, (const int*)S.d_tile_lrh.p, ntiles,
+                       S.d_ebase.p, S.d_tile_rs.p, lth, ts, (const uint32_t*)c_ex, (const int*)c_h, (const int*)c_t, (uint32_t*)nullptr,
                        (int*)nullptr, (int*)nullptr);
             e->st.launches += 2;
         }
@@ -186,30 +189,30 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     const bool packed = e->N < 65535 && e->maxW < 65536u;
     if (packed) {
         auto k_seg = fsk::k_sx_seg_write<RecT, true>;
-        FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, e->stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)e->d_ebase.p,
-                   (const int*)e->d_tile_rs.p, reinterpret_cast<uint32_t*>(e->d_E.p), reinterpret_cast<uint16_t*>(e->d_Pk.p), e->sx_own_shift, O,
-                   lists ? e->d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->d_tile_stat.p,
-                   skip_from, skipping ? (const int*)e->d_tile_ts.p : (const int*)nullptr,
-                   skipping ? reinterpret_cast<uint16_t*>(e->d_Tk.p) : (uint16_t*)nullptr);
+        FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)S.d_ebase.p,
+                   (const int*)S.d_tile_rs.p, reinterpret_cast<uint32_t*>(S.d_E.p), reinterpret_cast<uint16_t*>(S.d_Pk.p), e->sx_own_shift, O,
+                   lists ? S.d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, S.d_tile_stat.p,
+                   skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr,
+                   skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr);
     } else {
         auto k_seg = fsk::k_sx_seg_write<RecT, false>;
-        FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, e->stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)e->d_ebase.p,
-                   (const int*)e->d_tile_rs.p, e->d_E.p, e->d_Pk.p, e->sx_own_shift, O,
-                   lists ? e->d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->d_tile_stat.p,
-                   skip_from, skipping ? (const int*)e->d_tile_ts.p : (const int*)nullptr, skipping ? e->d_Tk.p : (uint32_t*)nullptr);
+        FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)S.d_ebase.p,
+                   (const int*)S.d_tile_rs.p, S.d_E.p, S.d_Pk.p, e->sx_own_shift, O,
+                   lists ? S.d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, S.d_tile_stat.p,
+                   skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr, skipping ? S.d_Tk.p : (uint32_t*)nullptr);
     }
     stat_pin[0] = stat_pin[1] = 0;
     e->st.launches += 3;
     u64 words = 0;
     if (lists) {  // where every (tile, owner) share of the update streams starts (+ the batch's pair and word totals)
-        FSK_LAUNCH(fsk::k_sx_ucol_sum, dim3(nchunks), dim3(256), 0, e->stream, (const uint32_t*)e->d_ucount.p, ntiles, O, e->d_uchunk.p,
-                   (const u64*)e->d_tile_stat.p, e->d_sxstat.p, stat_pin);
-        FSK_LAUNCH(fsk::k_sx_ucol_scan, dim3(O), dim3(256), 0, e->stream, e->d_uchunk.p, nchunks, O, e->d_utot.p);
-        FSK_LAUNCH(fsk::k_sx_ucol_apply, dim3(nchunks), dim3(256), 0, e->stream, e->d_ucount.p, ntiles, O, (const uint32_t*)e->d_uchunk.p,
-                   (const uint32_t*)e->d_utot.p, e->d_list_off.p);
+        FSK_LAUNCH(fsk::k_sx_ucol_sum, dim3(nchunks), dim3(256), 0, stream, (const uint32_t*)S.d_ucount.p, ntiles, O, S.d_uchunk.p,
+                   (const u64*)S.d_tile_stat.p, S.d_sxstat.p, stat_pin);
+        FSK_LAUNCH(fsk::k_sx_ucol_scan, dim3(O), dim3(256), 0, stream, S.d_uchunk.p, nchunks, O, S.d_utot.p);
+        FSK_LAUNCH(fsk::k_sx_ucol_apply, dim3(nchunks), dim3(256), 0, stream, S.d_ucount.p, ntiles, O, (const uint32_t*)S.d_uchunk.p,
+                   (const uint32_t*)S.d_utot.p, S.d_list_off.p);
         e->st.launches += 3;
     } else {
-        FSK_LAUNCH(fsk::k_sx_stat_sum, dim3(32), dim3(256), 0, e->stream, (const u64*)e->d_tile_stat.p, ntiles, e->d_sxstat.p, stat_pin);
+        FSK_LAUNCH(fsk::k_sx_stat_sum, dim3(32), dim3(256), 0, stream, (const u64*)S.d_tile_stat.p, ntiles, S.d_sxstat.p, stat_pin);
         e->st.launches += 1;
     }
     const bool guarded = guard_cap != 0;
@@ -218,7 +221,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         words = lists ? std::max<u64>(1, std::min(e->sx_words_seen, guard_cap)) : 0;  // (sizes the parts; the kernels read the true offsets)
         cap_words = guard_cap;
     } else {
-        FSK_HIP(hipStreamSynchronize(e->stream));  // the update streams are sized exactly
+        FSK_HIP(hipStreamSynchronize(stream));  // the update streams are sized exactly
         e->u_extra += stat_pin[0];
         words = stat_pin[1];
         e->sx_words_seen = std::max(e->sx_words_seen, words);
@@ -230,22 +233,22 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     if (slot_stride != 0 && !use_lists) return FSK_RETRY_UNGROUPED;  // (nothing of this batch has touched K yet)
     if (use_lists) {
         if (words > 0 || slot_stride != 0) {
-            if (!guarded && (size_t)words > e->d_ulist.cap)  // (grown with headroom: the batches of a pass differ by a few percent)
-                FSK_HIP(e->d_ulist.reserve((size_t)std::max<u64>(1, words + words / 4)));
+            if (!guarded && (size_t)words > S.d_ulist.cap)  // (grown with headroom: the batches of a pass differ by a few percent)
+                FSK_HIP(S.d_ulist.reserve((size_t)std::max<u64>(1, words + words / 4)));
             // (function pointers: a template-id with a comma cannot pass through the launch macro)
             if (packed) {
                 auto k_emit = skipping ? fsk::k_sx_emit<false, true, true> : fsk::k_sx_emit<false, false, true>;
-                FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, e->stream, reinterpret_cast<const uint32_t*>(e->d_E.p),
-                           reinterpret_cast<const uint16_t*>(e->d_Pk.p), (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p,
-                           e->sx_own_shift, O, (const uint32_t*)e->d_list_off.p, (const uint32_t*)e->d_ucount.p, e->d_ulist.p, (uint32_t)row0,
+                FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, reinterpret_cast<const uint32_t*>(S.d_E.p),
+                           reinterpret_cast<const uint16_t*>(S.d_Pk.p), (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p,
+                           e->sx_own_shift, O, (const uint32_t*)S.d_list_off.p, (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)row0,
                            (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg, slot_stride,
-                           skipping ? reinterpret_cast<const uint16_t*>(e->d_Tk.p) : (const uint16_t*)nullptr, (const u64*)e->d_sxstat.p, cap_words, ntiles);
+                           skipping ? reinterpret_cast<const uint16_t*>(S.d_Tk.p) : (const uint16_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles);
             } else {
                 auto k_emit = skipping ? fsk::k_sx_emit<false, true, false> : fsk::k_sx_emit<false, false, false>;
-                FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
-                           (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)e->d_list_off.p,
-                           (const uint32_t*)e->d_ucount.p, e->d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
-                           slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr, (const u64*)e->d_sxstat.p, cap_words, ntiles);
+                FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, (const uint2*)S.d_E.p, (const uint32_t*)S.d_Pk.p,
+                           (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)S.d_list_off.p,
+                           (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
+                           slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles);
             }
             const size_t lds = (size_t)e->sx_cap * sizeof(uint32_t);
 #ifndef FSK_EMU
@@ -256,15 +259,15 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             const uint32_t target = (uint32_t)std::max<u64>((u64)4 * e->sx_cap, (words + 1023) / 1024);
             const uint32_t max_parts = O + (uint32_t)(((guarded ? guard_cap : words) + target - 1) / target);
             if (slot_stride != 0) {  // one triangle per slot: a slot's words of a stream are one contiguous piece
-                FSK_LAUNCH(fsk::k_sx_consume, dim3(O, e->sx_rounds, nb), dim3(fsk::CS_THREADS), lds, e->stream, (const uint32_t*)e->d_ulist.p,
-                           (const uint32_t*)e->d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)nullptr, O, target,
-                           e->sx_cap, e->sx_pb, K, (const uint32_t*)e->d_ucount.p, tpg, slot_stride, (const u64*)e->d_sxstat.p, cap_words);
+                FSK_LAUNCH(fsk::k_sx_consume, dim3(O, e->sx_rounds, nb), dim3(fsk::CS_THREADS), lds, stream, (const uint32_t*)S.d_ulist.p,
+                           (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)nullptr, O, target,
+                           e->sx_cap, e->sx_pb, K, (const uint32_t*)S.d_ucount.p, tpg, slot_stride, (const u64*)S.d_sxstat.p, cap_words);
             } else {
-                FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, e->stream, (const uint32_t*)e->d_list_off.p, O, target, e->d_part_base.p,
-                           (const u64*)e->d_sxstat.p, cap_words);
-                FSK_LAUNCH(fsk::k_sx_consume, dim3(max_parts, e->sx_rounds), dim3(fsk::CS_THREADS), lds, e->stream, (const uint32_t*)e->d_ulist.p,
-                           (const uint32_t*)e->d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)e->d_part_base.p, O, target,
-                           e->sx_cap, e->sx_pb, K, (const uint32_t*)nullptr, tpg, (u64)0, (const u64*)e->d_sxstat.p, cap_words);
+                FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, stream, (const uint32_t*)S.d_list_off.p, O, target, S.d_part_base.p,
+                           (const u64*)S.d_sxstat.p, cap_words);
+                FSK_LAUNCH(fsk::k_sx_consume, dim3(max_parts, e->sx_rounds), dim3(fsk::CS_THREADS), lds, stream, (const uint32_t*)S.d_ulist.p,
+                           (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)S.d_part_base.p, O, target,
+                           e->sx_cap, e->sx_pb, K, (const uint32_t*)nullptr, tpg, (u64)0, (const u64*)S.d_sxstat.p, cap_words);
                 e->st.launches += 1;
             }
             e->st.launches += 2;
@@ -272,17 +275,17 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     } else {
         if (packed) {
             auto k_emit = skipping ? fsk::k_sx_emit<true, true, true> : fsk::k_sx_emit<true, false, true>;
-            FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, e->stream, reinterpret_cast<const uint32_t*>(e->d_E.p),
-                       reinterpret_cast<const uint16_t*>(e->d_Pk.p), (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift,
+            FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, reinterpret_cast<const uint32_t*>(S.d_E.p),
+                       reinterpret_cast<const uint16_t*>(S.d_Pk.p), (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift,
                        O, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod,
-                       cmax, e->sx_pb, K, tpg, slot_stride, skipping ? reinterpret_cast<const uint16_t*>(e->d_Tk.p) : (const uint16_t*)nullptr,
+                       cmax, e->sx_pb, K, tpg, slot_stride, skipping ? reinterpret_cast<const uint16_t*>(S.d_Tk.p) : (const uint16_t*)nullptr,
                        (const u64*)nullptr, ~(u64)0, ntiles);
         } else {
             auto k_emit = skipping ? fsk::k_sx_emit<true, true, false> : fsk::k_sx_emit<true, false, false>;
-            FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, e->stream, (const uint2*)e->d_E.p, (const uint32_t*)e->d_Pk.p,
-                       (const uint32_t*)e->d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)nullptr,
+            FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, (const uint2*)S.d_E.p, (const uint32_t*)S.d_Pk.p,
+                       (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)nullptr,
                        (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
-                       slot_stride, skipping ? (const uint32_t*)e->d_Tk.p : (const uint32_t*)nullptr, (const u64*)nullptr, ~(u64)0, ntiles);
+                       slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)nullptr, ~(u64)0, ntiles);
         }
         e->st.launches += 1;
     }
@@ -322,15 +325,17 @@ int sx_pinned(fsk_engine* e, size_t pos_bytes, size_t stat_words) {
 }
 
 // how many words a batch may hold when it is enqueued before its count is known (0: size it exactly)
-u64 sx_guard_for(fsk_engine* e) {
+u64 sx_guard_for(fsk_engine* e, int lane) {
+    DevBuf<uint32_t>& ulist = e->sxs[lane].d_ulist;
     if (e->sx_sync || e->cfg.profile) return 0;
     if (!e->sx_lists || e->force_global_pairs) return ~(u64)0;       // no streams: nothing to size
     if (e->sx_words_seen == 0) return 0;                                // (the first batch of these sequences)
-    if (e->sx_guard_cap) return std::min<u64>(e->sx_guard_cap, (u64)e->d_ulist.cap);
+    if (e->sx_guard_cap)  // (testing: pretend the stream buffer holds this many words)
+        return ulist.reserve((size_t)e->sx_guard_cap) == hipSuccess ? e->sx_guard_cap : 0;
     const u64 want = e->sx_words_seen + e->sx_words_seen / 2;
     if (want >= e->sx_max_words) return 0;
-    if ((u64)e->d_ulist.cap < want && e->d_ulist.reserve((size_t)want) != hipSuccess) return 0;
-    return std::min<u64>((u64)e->d_ulist.cap, e->sx_max_words - 1);
+    if ((u64)ulist.cap < want && ulist.reserve((size_t)want) != hipSuccess) return 0;
+    return std::min<u64>((u64)ulist.cap, e->sx_max_words - 1);
 }
 
 // the counts of deferred batch `slot` (its kernels have finished): false when it has to be redone
@@ -362,18 +367,21 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     const int recbits = e->sx_keybits + e->sx_sb;  // (<= 62 + 31: a 128-bit record always holds it)
     const int nbatches = (n + B - 1) / B;
     if (defer >= 0 && (defer >= SX_DEFER || nbatches != 1 || n > SX_DEFER_COMBOS)) defer = -1;
+    // variance mode's batches in flight alternate between two lanes of scratch and two streams
+    const int lane = sx_lane_of(e, defer);
+    if (lane && !e->lane_stream) FSK_HIP(hipStreamCreateWithFlags(&e->lane_stream, hipStreamNonBlocking));
     const size_t pos_head = (size_t)SX_DEFER * SX_DEFER_COMBOS * e->k, stat_head = (size_t)2 * SX_DEFER;
     rc = sx_pinned(e, pos_head + (size_t)n * e->k, stat_head + (size_t)2 * nbatches);
     if (rc) return rc;
     auto one = [&](int s, int nb, unsigned char* pos_pin, u64* stat_pin, u64 guard) {
         // (slot triangles are u32 arrays, slot_stride cells apart)
         u64* Kb = slot_stride ? reinterpret_cast<u64*>(reinterpret_cast<uint32_t*>(K) + (u64)s * slot_stride) : K;
-        return recbits <= 32   ? sparse_batch<uint32_t>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard)
-               : recbits <= 64 ? sparse_batch<u64>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard)
-                               : sparse_batch<u128>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard);
+        return recbits <= 32   ? sparse_batch<uint32_t>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard, lane)
+               : recbits <= 64 ? sparse_batch<u64>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard, lane)
+                               : sparse_batch<u128>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard, lane);
     };
     if (defer >= 0) {
-        const u64 guard = sx_guard_for(e);
+        const u64 guard = sx_guard_for(e, lane);
         e->sx_defer[defer].active = guard != 0;
         e->sx_defer[defer].cap = guard;
         rc = one(0, n, e->h_sx_pos + (size_t)defer * SX_DEFER_COMBOS * e->k, e->h_sx_stat + 2 * defer, guard);
@@ -384,7 +392,7 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     bool waiting = false;
     for (int s = 0, q = 0; s < n; s += B, ++q) {
         const int nb = std::min(B, n - s);
-        caps[q] = sx_guard_for(e);
+        caps[q] = sx_guard_for(e, 0);
         waiting |= caps[q] != 0;
         rc = one(s, nb, e->h_sx_pos + pos_head + (size_t)s * e->k, e->h_sx_stat + stat_head + 2 * q, caps[q]);
         if (rc) return rc;

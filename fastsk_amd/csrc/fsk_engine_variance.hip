@@ -14,13 +14,15 @@ namespace fsk_detail {
 // follow each other); the chains run on `chain_stream`
 // grp: 2 * SQ_GROUPS group records per block, laid out like blk
 int enqueue_sequential_sum(fsk_engine* e, const double* d_vals, u64 n, double* bsum, fsk::SeqBlk* blk, fsk::SeqGrp* grp, double* out,
-                           int count = 1, u64 stride = 0, hipStream_t chain_stream = nullptr, hipEvent_t handoff = nullptr) {
+                           int count = 1, u64 stride = 0, hipStream_t chain_stream = nullptr, hipEvent_t handoff = nullptr,
+                           hipStream_t main = nullptr) {
+    if (!main) main = e->stream;  // (the stream the values were produced on)
     const uint32_t nblocks = (uint32_t)((n + fsk::SQ_BLOCK - 1) / fsk::SQ_BLOCK);
     if (nblocks > 0)
-        FSK_LAUNCH(fsk::k_seq_prep, dim3(nblocks, count), dim3(256), 0, e->stream, d_vals, n, (const double*)bsum, blk, stride, nblocks);
-    hipStream_t cs = chain_stream ? chain_stream : e->stream;
+        FSK_LAUNCH(fsk::k_seq_prep, dim3(nblocks, count), dim3(256), 0, main, d_vals, n, (const double*)bsum, blk, stride, nblocks);
+    hipStream_t cs = chain_stream ? chain_stream : main;
     if (chain_stream) {
-        FSK_HIP(hipEventRecord(handoff, e->stream));
+        FSK_HIP(hipEventRecord(handoff, main));
         FSK_HIP(hipStreamWaitEvent(chain_stream, handoff, 0));
     }
     if (nblocks > 0)  // (the few blocks that need group records: on the chains' stream, beside the next batch's kernels)
@@ -71,17 +73,33 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     }
     double* h_avg = e->h_prod;  // pinned
     if (!e->chain_stream) FSK_HIP(hipStreamCreateWithFlags(&e->chain_stream, hipStreamNonBlocking));
-    hipEvent_t ev_done[MAX_DEPTH], ev_hand[MAX_DEPTH];
+    hipEvent_t ev_done[MAX_DEPTH], ev_hand[MAX_DEPTH], ev_wf[MAX_DEPTH];
     for (auto& ev : ev_done) FSK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     for (auto& ev : ev_hand) FSK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (auto& ev : ev_wf) FSK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    // Sparse batches in flight alternate between two lanes (scratch + stream, sx_lane_of): the short kernels of one
+    // batch's sort and segmentation run in the gaps of the other's emit / consume / Welford. What orders them: a
+    // batch's Welford pass waits for the previous batch's (K_hat is handed from one to the next) through ev_wf.
+    if (e->sx_two_lanes && !e->cfg.profile && !e->lane_stream) FSK_HIP(hipStreamCreateWithFlags(&e->lane_stream, hipStreamNonBlocking));
+    auto sync_all = [e]() {
+        (void)hipStreamSynchronize(e->stream);
+        if (e->lane_stream) (void)hipStreamSynchronize(e->lane_stream);
+        (void)hipStreamSynchronize(e->chain_stream);
+    };
     struct Cleanup {
-        hipEvent_t* a; hipEvent_t* b; fsk_engine* e;
+        hipEvent_t* a; hipEvent_t* b; hipEvent_t* c; fsk_engine* e;
         ~Cleanup() {
             (void)hipStreamSynchronize(e->stream);  // nothing of this call may still be in flight
+            if (e->lane_stream) (void)hipStreamSynchronize(e->lane_stream);
             (void)hipStreamSynchronize(e->chain_stream);
-            for (int i = 0; i < MAX_DEPTH; ++i) { (void)hipEventDestroy(a[i]); (void)hipEventDestroy(b[i]); }
+            for (int i = 0; i < MAX_DEPTH; ++i) { (void)hipEventDestroy(a[i]); (void)hipEventDestroy(b[i]); (void)hipEventDestroy(c[i]); }
         }
-    } cleanup{ev_done, ev_hand, e};
+    } cleanup{ev_done, ev_hand, ev_wf, e};
+    if (e->lane_stream) {  // lane 1 starts after the uploads and fills enqueued on the engine's stream so far
+        FSK_HIP(hipEventRecord(ev_wf[0], e->stream));
+        FSK_HIP(hipStreamWaitEvent(e->lane_stream, ev_wf[0], 0));
+    }
+    bool wf_set[MAX_DEPTH] = {false, false};  // ev_wf[lane] holds a Welford pass of the chain at hand
     const double t_alloc = ms_since(t_begin);
     const uint32_t blocks = (uint32_t)((pairs + 255) / 256);                                       // one cell per thread
     const uint32_t wblocks = (uint32_t)((pairs + 256 * fsk::WF_ITEMS - 1) / (256 * fsk::WF_ITEMS)); // k_welford
@@ -121,6 +139,7 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     auto slots64_of = [&](int part) { return e->d_Kslots.p + (size_t)part * AHEAD * (size_t)pairs; };
     static_assert(AHEAD <= fsk::WF_SLOTS, "k_welford_batch carries a batch's iterations in registers");
     auto issue = [&](Batch& B) -> int {
+        const bool was_grouped = grouped;
         if (grouped) {
             int32_t combos[AHEAD];
             for (int b = 0; b < B.n; ++b) combos[b] = e->order[B.first_item + b * T];
@@ -129,9 +148,15 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
             else if (rc) return rc;
         }
         B.grouped = grouped || dense_slots;  // (the batch's counts sit in slot triangles, its Welford update is one pass)
+        // the stream this batch's passes over the triangle run on: its lane's (sparse batches), else the engine's
+        const int lane = grouped ? sx_lane_of(e, B.part) : 0;
+        hipStream_t bs = lane ? e->lane_stream : e->stream;
+        if (was_grouped && !grouped) sync_all();  // (leaving the two-lane form: everything drains first, once)
+        for (int l = 0; l < MAX_DEPTH; ++l)  // K_hat comes from the previous batch's Welford pass, wherever that ran
+            if (l != lane && wf_set[l]) FSK_HIP(hipStreamWaitEvent(bs, ev_wf[l], 0));
         if (grouped) {  // K_hat through the batch's iterations in one pass; only the state after the batch is written
             const size_t slot0 = (size_t)B.part * AHEAD;
-            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<uint32_t>), dim3(wblocks), dim3(256), 0, e->stream, (const uint32_t*)slots_of(B.part), B.n,
+            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<uint32_t>), dim3(wblocks), dim3(256), 0, bs, (const uint32_t*)slots_of(B.part), B.n,
                        (const double*)khat(B.base), khat(B.base + B.n), e->d_prod.p + slot0 * tp, (u64)tp, (u64)pairs, (u64)train_pairs,
                        (double)B.first_iter, e->d_bsum.p + slot0 * nblk, (uint32_t)nblk, 1);
         } else if (dense_slots) {
@@ -160,10 +185,12 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
         // the batch's sums: block totals on all CUs, then one wave per iteration walks its blocks — on a
         // second stream, under the kernels of the batches that follow
         const size_t slot0 = (size_t)B.part * AHEAD;
+        FSK_HIP(hipEventRecord(ev_wf[lane], bs));  // the state after this batch is on its way
+        wf_set[lane] = true;
         int rc = enqueue_sequential_sum(e, e->d_prod.p + slot0 * tp, (u64)train_pairs, e->d_bsum.p + slot0 * nblk,
                                         reinterpret_cast<fsk::SeqBlk*>(e->d_seqblk.p) + slot0 * nblk,
                                         seq_grp + slot0 * nblk * (2 * fsk::SQ_GROUPS), h_avg + slot0, B.n, (u64)tp,
-                                        e->chain_stream, ev_hand[B.part]);  // (the sums land in pinned host memory)
+                                        e->chain_stream, ev_hand[B.part], bs);  // (the sums land in pinned host memory)
         if (rc) return rc;
         FSK_HIP(hipEventRecord(ev_done[B.part], e->chain_stream));
         return FSK_OK;
@@ -199,8 +226,7 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
                 // A was enqueued ahead of its word count and did not fit the update streams: its slot
                 // triangles were not written. Everything issued after it started from A's state: drop
                 // it all and run A again, sized exactly.
-                FSK_HIP(hipStreamSynchronize(e->stream));
-                FSK_HIP(hipStreamSynchronize(e->chain_stream));
+                sync_all();
                 for (const Batch& B : q) { e->st.combos_done -= B.n; e->sx_defer[B.part].active = false; }
                 q.clear();
                 const int was = e->sx_sync;
@@ -231,10 +257,7 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
             q.erase(q.begin());
             if (!working) {
                 for (const Batch& B : q) e->st.combos_done -= B.n;
-                if (!q.empty()) {  // dropped batches drain before their buffers are reused
-                    FSK_HIP(hipStreamSynchronize(e->stream));
-                    FSK_HIP(hipStreamSynchronize(e->chain_stream));
-                }
+                if (!q.empty()) sync_all();  // dropped batches drain before their buffers are reused
                 for (const Batch& B : q) (void)sx_harvest(e, B.part);
                 if (A.grouped && accepted < A.n) {  // the stop fell inside the batch: the state after its accepted prefix
                     if (dense_slots)
@@ -250,6 +273,9 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
             }
             // (working implies more items and iterations: the queue is not empty)
         }
+        // (the chain's last state may have been written in lane 1; the next chain starts over on the engine's stream)
+        if (e->lane_stream) FSK_HIP(hipStreamSynchronize(e->lane_stream));
+        for (bool& w : wf_set) w = false;
         FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_add_nonzero<double>), dim3(blocks), dim3(256), 0, e->stream, e->d_Kf64.p, (const double*)khat(cur), (u64)pairs);
     }
     e->result_f64 = true;
