@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def newest(pattern):
@@ -70,7 +70,9 @@ def main():
                          "WRITE_SIZE KiB x1024" % TAG}, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
     for src, dst in (("configs.jsonl", TAG + "_configs1-4_gpu_timings.jsonl"), ("large_g.jsonl", TAG + "_large_g_regime.jsonl"),
                      ("n_series.jsonl", TAG + "_n_series.jsonl"), ("bench_config4.json", TAG + "_bench_config4.json"),
-                     ("bench_rccl_world1.json", TAG + "_bench_rccl_world1.json")):
+                     ("bench_rccl_world1.json", TAG + "_bench_rccl_world1.json"), ("bench_inproc1.json", TAG + "_bench_inproc_1gpu.json"),
+                     ("bench_inproc3_shared.json", TAG + "_bench_inproc_3engines_one_gpu_p2p.json"),
+                     ("bench_inproc1_config4.json", TAG + "_bench_inproc_1gpu_config4.json")):
         if not os.path.exists(os.path.join(SRC, src)):
             continue
         lines = [l for l in open(os.path.join(SRC, src)) if l.startswith("{")]
@@ -95,6 +97,12 @@ def main():
                    "source": "profiles/%s_pmc_sparse_config4.json: sum over the pipeline's kernels of FETCH_SIZE KiB x1024 x2 (gfx950 "
                              "correction) + WRITE_SIZE KiB x1024, one fsk_compute of all 1001 combos" % TAG},
                   open(os.path.join(DST, "traffic_config4.json"), "w"), indent=1)
+    for src, dst in (("config1_timeline.txt", TAG + "_config1_timeline.txt"), ("kprof_cfg4/kstats.txt", TAG + "_kernel_times_config4.txt"),
+                     ("kprof_cfg1/kstats.txt", TAG + "_kernel_times_config1.txt"), ("ep300_approx.txt", TAG + "_ep300_approx_ms.txt")):
+        if os.path.exists(os.path.join(SRC, src)):
+            shutil.copy(os.path.join(SRC, src), os.path.join(DST, dst))
+    if os.path.exists(os.path.join(SRC, "k_digests.json")):
+        shutil.copy(os.path.join(SRC, "k_digests.json"), os.path.join(DST, "k_digests.json"))
     if os.path.exists(os.path.join(SRC, "ubench_mfma_i8.txt")):
         shutil.copy(os.path.join(SRC, "ubench_mfma_i8.txt"), os.path.join(DST, TAG + "_ubench_mfma_i8_vs_dot8.txt"))
     print("profiles/ refreshed from", SRC)

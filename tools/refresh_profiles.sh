@@ -5,6 +5,7 @@
 # and the micro-benchmarks. Raw output lands in gpurun_out/prof/ and gpurun_out/pmc/;
 # tools/collect_profiles.py turns it into the files under profiles/.
 set -u
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
 rm -rf "$O"; mkdir -p "$O"
@@ -16,15 +17,25 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/pmc_$c" -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-also > /dev/null 2> "$O/pmc_$c.err"
 done
 # the sparse pipeline's counter passes at config 4 (traffic_config4.json is built from them)
-(cd "$R" && tools/pmc_passes.sh r02_cfg4 "$R/tools/profile_one.py" f7_cfg4_prot219_exact > "$O/pmc_cfg4.log" 2>&1)
+(cd "$R" && tools/pmc_passes.sh ${TAG}_cfg4 "$R/tools/profile_one.py" f7_cfg4_prot219_exact > "$O/pmc_cfg4.log" 2>&1)
 # traffic.json / traffic_config4.json from the passes above (needs bench.json, stats, pmc_*), then the headline
 # line once more and the config-4 line: they now carry the measured HBM traffic of exactly these sources
-(cd "$R" && python3 tools/collect_profiles.py r02 > "$O/collect_on_box.log" 2>&1 && python3 bench.py --steps 2 --warmup 1 > "$O/bench_final.json" 2> "$O/bench_final.err";
+(cd "$R" && python3 tools/collect_profiles.py $TAG > "$O/collect_on_box.log" 2>&1 && python3 bench.py --steps 2 --warmup 1 > "$O/bench_final.json" 2> "$O/bench_final.err";
  python3 bench.py --config 4 --steps 5 --warmup 2 --no-cpu-baseline --no-also > "$O/bench_config4.json" 2> "$O/bench_config4.err")
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_configs" -- python3 "$R/tools/bench_configs.py" > /dev/null 2> "$O/stats_configs.err"
 cd "$R" && python3 tools/bench_configs.py > "$O/configs.jsonl" 2> "$O/configs.err"
 python3 tools/bench_large_g.py > "$O/large_g.jsonl" 2> "$O/large_g.err"
-tools/pmc_passes.sh r02_cfg1 "$R/tools/profile_one.py" f7_cfg1_prot11_approx_t1 > "$O/pmc_cfg1.log" 2>&1
+tools/pmc_passes.sh ${TAG}_cfg1 "$R/tools/profile_one.py" f7_cfg1_prot11_approx_t1 > "$O/pmc_cfg1.log" 2>&1
 tools/bench_n_series.sh > /dev/null 2>&1; cp "$R/gpurun_out/n_series.jsonl" "$O/n_series.jsonl"
 [ -x tools/ubench_mfma_i8 ] && tools/ubench_mfma_i8 > "$O/ubench_mfma_i8.txt" 2>&1
+# the in-process multi-GPU engine (FastSK(devices=[...])) on this box: RCCL from the host C++ over a world of one at full
+# size, and three engines sharing the GPU over the peer-to-peer kernels at N = 32000 (a smoke test of the group, not a measurement)
+python3 bench.py --gpus 1 --inproc --steps 3 --warmup 1 --no-cpu-baseline --no-also > "$O/bench_inproc1.json" 2> "$O/bench_inproc1.err"
+FSK_BENCH_SHARE_GPU=1 python3 bench.py --gpus 3 --inproc --n-seq 32000 --steps 3 --warmup 1 --no-cpu-baseline --no-also > "$O/bench_inproc3_shared.json" 2> "$O/bench_inproc3_shared.err"
+python3 bench.py --gpus 1 --inproc --config 4 --steps 5 --warmup 2 --no-cpu-baseline --no-also > "$O/bench_inproc1_config4.json" 2> "$O/bench_inproc1_config4.err"
+python3 tools/make_digests.py > "$O/digests.log" 2>&1; cp profiles/k_digests.json "$O/k_digests.json"
+tools/trace_cfg1.sh > "$O/config1_timeline.txt" 2>&1
+tools/kprof.sh f7_cfg4_prot219_exact prof/kprof_cfg4 > /dev/null 2>&1
+tools/kprof.sh f7_cfg1_prot11_approx_t1 prof/kprof_cfg1 > /dev/null 2>&1
+python3 tools/time_ep300_approx.py > "$O/ep300_approx.txt" 2>&1
 ls -R "$O" | head -60
