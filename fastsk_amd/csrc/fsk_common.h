@@ -120,14 +120,6 @@ __device__ __forceinline__ uint32_t tile_index(uint32_t t, uint32_t e) { return 
 // a * b + c with 24-bit operands: v_mad_u32_u24 issues at full rate, a 32-bit multiply-add does
 // not (the compiler turns __umul24 of small known ranges back into one, hence the asm).
 // b is wave-uniform.
-__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
-#ifdef FSK_EMU
-    return (a & 0xffffffu) * (b & 0xffffffu) + c;
-#else
-    uint32_t d;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
-    return d;
-#endif
-}
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return fsk_hw::mad24(a, b, c); }
 
 }  // namespace fsk

@@ -591,7 +591,7 @@ int fsk_detail::one_load_sequences(fsk_engine* e, const int32_t* tokens, const i
     e->prep_valid = false; e->tab_n = 0; e->vc_sum = 0; e->vc_n = 0;
     e->lazy_lo = e->lazy_hi = -1;  // (the triangle is zeroed, or promised to be, below)
     e->u_known = false; e->u_pending = false; e->u_extra = 0; e->u_value = 0;
-    e->sx_words_seen = 0;
+    e->sx_wpr = 0;
     for (auto& d : e->sx_defer) d.active = false;
     if (e->V > DENSE_MAX_KEYS) e->Vq = 1;  // unused on the sparse path
     {   // sparse dataflow: sort record = (k-mer << sx_sb) | sequence id; owner bands of K

@@ -141,16 +141,14 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
             lds = plan.lds;
         }
     }
-#ifndef FSK_EMU
     {
         auto k0 = fsk::k_dense_count<false, false>;
         auto k1 = fsk::k_dense_count<false, true>;
         auto k2 = fsk::k_dense_count<true, false>;
-        FSK_HIP(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FSK_HIP(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FSK_HIP(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FSK_HIP(fsk_hw::allow_dynamic_lds(k0, lds));
+        FSK_HIP(fsk_hw::allow_dynamic_lds(k1, lds));
+        FSK_HIP(fsk_hw::allow_dynamic_lds(k2, lds));
     }
-#endif
     if (compact) {
         FSK_HIP(e->d_keybits.reserve((size_t)chunk * Vw));
         FSK_HIP(e->d_lut.reserve((size_t)chunk * Vkeys));

@@ -193,8 +193,10 @@ struct fsk_engine {
     size_t h_sx_pos_cap = 0;
     u64* h_sx_stat = nullptr;            // pinned: {pairs, words} of the batches in flight (same layout)
     size_t h_sx_stat_cap = 0;
-    u64 sx_words_seen = 0;               // largest word count of a batch since the sequences were loaded
-    struct SxDefer { bool active = false; u64 cap = 0; } sx_defer[8];
+    double sx_wpr = 0;                   // most update words per sort record of a batch since the sequences were loaded (0: none seen)
+    u64 sx_words_of(u64 nrec) const { return (u64)(sx_wpr * (double)nrec) + 1; }  // what a batch of nrec records is expected to emit
+    void sx_saw(u64 words, u64 nrec) { if (nrec) sx_wpr = std::max(sx_wpr, std::max(1e-9, (double)words / (double)nrec)); }
+    struct SxDefer { bool active = false; u64 cap = 0, nrec = 0; } sx_defer[8];
     int force_seg_chunks = 0;            // FSK_SEG_SCAN_CHUNKED=1: the three-launch segment scan whatever the tile count (testing)
     int sx_sync = 0;                     // FSK_SPARSE_SYNC=1: size every batch exactly (testing); also while redoing a batch
     u64 sx_guard_cap = 0;                // FSK_SPARSE_GUARD_CAP=n: pretend the stream buffer holds n words (testing the redo)

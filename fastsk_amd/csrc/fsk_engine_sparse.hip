@@ -218,13 +218,13 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     const bool guarded = guard_cap != 0;
     u64 cap_words = ~(u64)0;
     if (guarded) {
-        words = lists ? std::max<u64>(1, std::min(e->sx_words_seen, guard_cap)) : 0;  // (sizes the parts; the kernels read the true offsets)
+        words = lists ? std::max<u64>(1, std::min(e->sx_words_of(nrec), guard_cap)) : 0;  // (sizes the parts; the kernels read the true offsets)
         cap_words = guard_cap;
     } else {
         FSK_HIP(hipStreamSynchronize(stream));  // the update streams are sized exactly
         e->u_extra += stat_pin[0];
         words = stat_pin[1];
-        e->sx_words_seen = std::max(e->sx_words_seen, words);
+        e->sx_saw(words, nrec);
     }
     e->toc(&e->st.ms_segment);
 
@@ -251,9 +251,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                            slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles);
             }
             const size_t lds = (size_t)e->sx_cap * sizeof(uint32_t);
-#ifndef FSK_EMU
-            FSK_HIP(hipFuncSetAttribute((const void*)fsk::k_sx_consume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-#endif
+            FSK_HIP(fsk_hw::allow_dynamic_lds(fsk::k_sx_consume, lds));
             // parts of about `target` words: ~1024 workgroups, and never so short that the flush of a
             // part (up to sx_cap cells) outweighs the words it summed
             const uint32_t target = (uint32_t)std::max<u64>((u64)4 * e->sx_cap, (words + 1023) / 1024);
@@ -325,14 +323,14 @@ int sx_pinned(fsk_engine* e, size_t pos_bytes, size_t stat_words) {
 }
 
 // how many words a batch may hold when it is enqueued before its count is known (0: size it exactly)
-u64 sx_guard_for(fsk_engine* e, int lane) {
+u64 sx_guard_for(fsk_engine* e, int lane, u64 nrec) {
     DevBuf<uint32_t>& ulist = e->sxs[lane].d_ulist;
     if (e->sx_sync || e->cfg.profile) return 0;
     if (!e->sx_lists || e->force_global_pairs) return ~(u64)0;       // no streams: nothing to size
-    if (e->sx_words_seen == 0) return 0;                                // (the first batch of these sequences)
+    if (e->sx_wpr == 0) return 0;                                       // (the first batch of these sequences)
     if (e->sx_guard_cap)  // (testing: pretend the stream buffer holds this many words)
         return ulist.reserve((size_t)e->sx_guard_cap) == hipSuccess ? e->sx_guard_cap : 0;
-    const u64 want = e->sx_words_seen + e->sx_words_seen / 2;
+    const u64 expect = e->sx_words_of(nrec), want = expect + expect / 2;  // (words per record differ by a few percent between batches)
     if (want >= e->sx_max_words) return 0;
     if ((u64)ulist.cap < want && ulist.reserve((size_t)want) != hipSuccess) return 0;
     return std::min<u64>((u64)ulist.cap, e->sx_max_words - 1);
@@ -343,7 +341,7 @@ bool sx_harvest(fsk_engine* e, int slot) {
     if (slot < 0 || !e->sx_defer[slot].active) return true;
     e->sx_defer[slot].active = false;
     const u64 pairs = e->h_sx_stat[2 * slot], words = e->h_sx_stat[2 * slot + 1];
-    e->sx_words_seen = std::max(e->sx_words_seen, words);
+    e->sx_saw(words, e->sx_defer[slot].nrec);
     if (words > e->sx_defer[slot].cap) { e->sx_redone += 1; return false; }
     e->u_extra += pairs;
     return true;
@@ -358,20 +356,26 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     { int rcz = materialise_zero(e); if (rcz) return rcz; }
     int rc = ensure_featseq(e);
     if (rc) return rc;
-    // batch so that the record count stays below the cap ...
-    size_t per = SPARSE_MAX_RECORDS / (size_t)std::max<int64_t>(1, e->nfeat);
-    int B = (int)std::max<size_t>(1, std::min<size_t>(per, (size_t)n));
-    // ... and the owner bands can sum a batch in u32 LDS cells: per cell and combo <= maxW^2
-    B = (int)std::max<u64>(1, std::min<u64>((u64)B, 0xffffffffull / std::max<u64>(1, (u64)e->maxW * e->maxW)));
-    B = std::min(B, 65535);  // grid.y
+    // Batch so that (i) the record count stays below the cap, (ii) the owner bands can sum a batch in u32 LDS cells
+    // (per cell and combo <= maxW^2), (iii) a batch's update words stay well inside what one stream addresses
+    // (2^31: beyond it the pairs go to K with atomics, an order of magnitude slower) — judged by the most words per
+    // record seen so far on these sequences; while none has been seen, a first batch of at most 2^25 records.
+    const size_t nfeat = (size_t)std::max<int64_t>(1, e->nfeat);
+    const u64 by_cells = std::max<u64>(1, 0xffffffffull / std::max<u64>(1, (u64)e->maxW * e->maxW));
+    auto batch_combos = [&](int left) {
+        size_t recs = SPARSE_MAX_RECORDS;
+        if (e->sx_wpr == 0) recs = std::min<size_t>(recs, (size_t)1 << 25);
+        else recs = std::min<size_t>(recs, (size_t)std::max(1.0, (double)(e->sx_max_words / 2) / e->sx_wpr));
+        const u64 B = std::max<u64>(1, std::min<u64>({(u64)(recs / nfeat), (u64)left, by_cells, (u64)65535}));  // (65535: grid.y)
+        return (int)B;
+    };
     const int recbits = e->sx_keybits + e->sx_sb;  // (<= 62 + 31: a 128-bit record always holds it)
-    const int nbatches = (n + B - 1) / B;
-    if (defer >= 0 && (defer >= SX_DEFER || nbatches != 1 || n > SX_DEFER_COMBOS)) defer = -1;
+    if (defer >= 0 && (defer >= SX_DEFER || batch_combos(n) != n || n > SX_DEFER_COMBOS)) defer = -1;
     // variance mode's batches in flight alternate between two lanes of scratch and two streams
     const int lane = sx_lane_of(e, defer);
     if (lane && !e->lane_stream) FSK_HIP(hipStreamCreateWithFlags(&e->lane_stream, hipStreamNonBlocking));
     const size_t pos_head = (size_t)SX_DEFER * SX_DEFER_COMBOS * e->k, stat_head = (size_t)2 * SX_DEFER;
-    rc = sx_pinned(e, pos_head + (size_t)n * e->k, stat_head + (size_t)2 * nbatches);
+    rc = sx_pinned(e, pos_head + (size_t)n * e->k, stat_head + (size_t)2 * n);  // (at most one batch per combo)
     if (rc) return rc;
     auto one = [&](int s, int nb, unsigned char* pos_pin, u64* stat_pin, u64 guard) {
         // (slot triangles are u32 arrays, slot_stride cells apart)
@@ -381,34 +385,40 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
                                : sparse_batch<u128>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard, lane);
     };
     if (defer >= 0) {
-        const u64 guard = sx_guard_for(e, lane);
+        const u64 guard = sx_guard_for(e, lane, (u64)n * nfeat);
         e->sx_defer[defer].active = guard != 0;
         e->sx_defer[defer].cap = guard;
+        e->sx_defer[defer].nrec = (u64)n * nfeat;
         rc = one(0, n, e->h_sx_pos + (size_t)defer * SX_DEFER_COMBOS * e->k, e->h_sx_stat + 2 * defer, guard);
         if (rc) e->sx_defer[defer].active = false;
         return rc;
     }
-    std::vector<u64> caps((size_t)nbatches, 0);  // per batch: the guard it was enqueued under (0: sized exactly)
-    bool waiting = false;
-    for (int s = 0, q = 0; s < n; s += B, ++q) {
-        const int nb = std::min(B, n - s);
-        caps[q] = sx_guard_for(e, 0);
-        waiting |= caps[q] != 0;
-        rc = one(s, nb, e->h_sx_pos + pos_head + (size_t)s * e->k, e->h_sx_stat + stat_head + 2 * q, caps[q]);
+    struct Enq { int s, nb; u64 cap; };  // batches enqueued under a guard (not sized exactly): checked below
+    std::vector<Enq> enq;
+    int q = 0;
+    for (int s = 0; s < n; ++q) {
+        const int nb = batch_combos(n - s);  // (grows after the first batch of a set of sequences has been sized)
+        const u64 cap = sx_guard_for(e, 0, (u64)nb * nfeat);
+        rc = one(s, nb, e->h_sx_pos + pos_head + (size_t)s * e->k, e->h_sx_stat + stat_head + 2 * q, cap);
         if (rc) return rc;
+        enq.push_back(Enq{s, nb, cap});
+        s += nb;
     }
+    bool waiting = false;
+    for (const Enq& b : enq) waiting |= b.cap != 0;
     if (!waiting) return FSK_OK;
     FSK_HIP(hipStreamSynchronize(e->stream));
-    for (int s = 0, q = 0; s < n; s += B, ++q) {
-        if (!caps[q]) continue;
-        const u64 pairs = e->h_sx_stat[stat_head + 2 * q], words = e->h_sx_stat[stat_head + 2 * q + 1];
-        e->sx_words_seen = std::max(e->sx_words_seen, words);
-        if (words <= caps[q]) { e->u_extra += pairs; continue; }
+    for (size_t i = 0; i < enq.size(); ++i) {
+        const Enq& b = enq[i];
+        if (!b.cap) continue;
+        const u64 pairs = e->h_sx_stat[stat_head + 2 * i], words = e->h_sx_stat[stat_head + 2 * i + 1];
+        e->sx_saw(words, (u64)b.nb * nfeat);
+        if (words <= b.cap) { e->u_extra += pairs; continue; }
         // the batch did not fit and has left K alone: once more, sized exactly
         e->sx_redone += 1;
         const int was = e->sx_sync;
         e->sx_sync = 1;
-        rc = one(s, std::min(B, n - s), e->h_sx_pos + pos_head + (size_t)s * e->k, e->h_sx_stat + stat_head + 2 * q, 0);
+        rc = one(b.s, b.nb, e->h_sx_pos + pos_head + (size_t)b.s * e->k, e->h_sx_stat + stat_head + 2 * i, 0);
         e->sx_sync = was;
         if (rc) return rc;
     }

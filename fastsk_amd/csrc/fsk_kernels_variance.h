@@ -277,13 +277,7 @@ __global__ __launch_bounds__(256) void k_seq_prep_groups(const double* p, u64 n,
 }
 
 // value of lane `src` (wave-uniform index) in every lane: a scalar read, not an LDS permute
-__device__ __forceinline__ uint32_t wave_bcast_u32(uint32_t x, uint32_t src) {
-#ifdef FSK_EMU
-    return __shfl(x, (int)src);
-#else
-    return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)src);
-#endif
-}
+__device__ __forceinline__ uint32_t wave_bcast_u32(uint32_t x, uint32_t src) { return fsk_hw::readlane(x, src); }
 __device__ __forceinline__ u64 wave_bcast_u64(u64 x, uint32_t src) {
     return ((u64)wave_bcast_u32((uint32_t)(x >> 32), src) << 32) | wave_bcast_u32((uint32_t)x, src);
 }
@@ -293,30 +287,9 @@ __device__ __forceinline__ double wave_bcast_f64(double x, uint32_t src) {
     return b.d;
 }
 
-// sum of x over the 64 lanes, in every lane. On the critical path of k_seq_chain (one wave, nothing to
-// overlap with), so through the DPP row shifts / broadcasts of the VALU rather than six dependent LDS
-// permutes per 32-bit half: rows of 16 lanes first, then row 0 -> 1 and 2 -> 3, then lane 31 -> rows 2-3.
-__device__ __forceinline__ u64 wave_sum_u64(u64 x) {
-#ifdef FSK_EMU
-    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
-    return x;
-#else
-#define FSK_DPP_ADD64(ctrl, rows)                                                                                   \
-    {                                                                                                               \
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, ctrl, rows, 0xf, true);      \
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), ctrl, rows, 0xf, true); \
-        x += ((u64)hi << 32) | lo;                                                                                  \
-    }
-    FSK_DPP_ADD64(0x111, 0xf)  // row_shr:1
-    FSK_DPP_ADD64(0x112, 0xf)  // row_shr:2
-    FSK_DPP_ADD64(0x114, 0xf)  // row_shr:4
-    FSK_DPP_ADD64(0x118, 0xf)  // row_shr:8  -> lane 15 of every row holds the row's sum
-    FSK_DPP_ADD64(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
-    FSK_DPP_ADD64(0x143, 0xc)  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-#undef FSK_DPP_ADD64
-    return wave_bcast_u64(x, 63u);
-#endif
-}
+// sum of x over the 64 lanes, in every lane. On the critical path of k_seq_chain (one wave, nothing to overlap
+// with): DPP row shifts / broadcasts (fsk_hw::wave_sum_u64), not six dependent LDS permutes per 32-bit half.
+__device__ __forceinline__ u64 wave_sum_u64(u64 x) { return fsk_hw::wave_sum_u64(x); }
 
 // PER values per lane (held in registers; 0.0 where the range ended) added to s as one integer total,
 // if the conditions hold

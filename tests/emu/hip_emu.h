@@ -307,3 +307,40 @@ static inline hipError_t hipMemGetInfo(size_t* fr, size_t* tot) { *fr = *tot = (
 
 #define FSK_LAUNCH(kernel, grid, block, shmem, stream, ...) \
     emu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })
+
+// ---- what fastsk_amd/csrc/fsk_gfx950.h gives the product build: the same names, plain C++ ---------------
+namespace fsk_hw {
+static inline unsigned mad24(unsigned a, unsigned b, unsigned c) { return (a & 0xffffffu) * (b & 0xffffffu) + c; }
+static inline unsigned readlane(unsigned x, unsigned src) { return __shfl(x, (int)src); }
+static inline unsigned long long wave_sum_u64(unsigned long long x) {
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+    return x;
+}
+static inline unsigned vgpr_copy(unsigned x) { return x; }
+// rows past `bytes` read as zero (the buffer descriptor's bounds check)
+static inline uint4 rows16(const unsigned* rows, unsigned bytes, unsigned byte_off) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (byte_off + 16u <= bytes) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(rows) + byte_off);
+    return v;
+}
+static inline void panel_rows_2x16(const unsigned* rows, unsigned bytes, unsigned lane_off, uint4& lo, uint4& hi) {
+    lo = rows16(rows, bytes, lane_off * 4u);
+    hi = rows16(rows, bytes, lane_off * 4u + 16u * 64u * 4u);
+}
+typedef uintptr_t lds_addr_t;
+static inline lds_addr_t lds_address(const void* p) { return reinterpret_cast<uintptr_t>(p); }
+// (a wave's 64 lanes land 16 bytes each, consecutively, at lds_dst)
+static inline void panel_rows_to_lds(const unsigned* rows, unsigned bytes, lds_addr_t lds_dst, unsigned lane_off_b) {
+    *reinterpret_cast<uint4*>(lds_dst + (uintptr_t)emu::lane_id() * 16u) = rows16(rows, bytes, lane_off_b);
+}
+static inline void wait_panel_rows() {}
+template <typename F> static inline hipError_t allow_dynamic_lds(F, size_t) { return 0; }
+}  // namespace fsk_hw
+static inline unsigned fsk_mbcnt(unsigned lo, unsigned hi) {
+    const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+    return (unsigned)__builtin_popcountll(m & ((1ull << emu::lane_id()) - 1ull));
+}
+#define FSK_LDS_LOAD_U8(ptr) (*reinterpret_cast<const unsigned char*>(ptr))
+#define FSK_LDS_LOAD_U32(ptr) (*reinterpret_cast<const unsigned int*>(ptr))
+#define FSK_LDS_LOAD_U64(ptr) (*reinterpret_cast<const unsigned long long*>(ptr))
+#define FSK_LDS_VOLATILE_U32(ptr) (*reinterpret_cast<volatile unsigned int*>(ptr))

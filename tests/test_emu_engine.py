@@ -560,6 +560,33 @@ def test_emu_sparse_batches_enqueued_ahead_of_their_size(emu_lib, port, monkeypa
     e.close()
 
 
+@pytest.mark.parametrize("max_words", ["3000", "40000"])
+def test_emu_sparse_batches_sized_by_words_per_record(emu_lib, port, monkeypatch, max_words):
+    """Sparse dataflow: once a batch of a set of sequences has been counted, later batches take as many
+    combos as keep their update words (judged by the most words per record seen) inside one stream, so
+    that they do not fall back to atomics on K; a stream limit far below a call's words makes every call
+    after the first split into several batches."""
+    from fastsk_amd import _native
+    d = load_golden("f5_prot11_exact")
+    combos = np.arange(0, 210, 5, dtype=np.int32)
+    want, _, U = port.raw_counts(d["tokens"], d["offsets"], d["g"], d["m"], combos)
+    launches = {}
+    for limit in (None, max_words):
+        if limit:
+            monkeypatch.setenv("FSK_LIST_MAX_WORDS", limit)
+        e = _native.Engine(d["g"], d["m"], path=2, lib=emu_lib)
+        e.load_sequences(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+        for part in np.array_split(combos, 3):
+            e.accumulate(part)
+        e.finalize()
+        assert np.array_equal(e.get_counts(), want), limit
+        st = e.stats()
+        assert st["cell_updates"] == U and st["combos_done"] == combos.size
+        launches[limit] = st["launches"]
+        e.close()
+    assert launches[max_words] > launches[None]
+
+
 @pytest.mark.parametrize("env", [{"FSK_SPARSE_GLOBAL": "1"}, {"FSK_LIST_MAX_WORDS": "2000"}, {}, {"FSK_SPARSE_SYNC": "1"},
                                  {"FSK_SPARSE_GUARD_CAP": "100"}])
 def test_emu_variance_mode_sparse_fallbacks(emu_lib, monkeypatch, env):
