@@ -287,6 +287,12 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         }
         e->st.launches += 1;
     }
+    // the diagonal's combo-independent part (the streams and the atomics above carry the rest)
+    if (row1 > row0)
+        FSK_LAUNCH(fsk::k_sx_diag_windows, dim3((uint32_t)((row1 - row0 + 255) / 256), slot_stride ? nb : 1), dim3(256), 0, stream,
+                   (const uint32_t*)e->d_fstart.p, (uint32_t)row0, (uint32_t)row1, (uint32_t)nb, K, slot_stride,
+                   use_lists ? (const u64*)S.d_sxstat.p : (const u64*)nullptr, cap_words);
+    e->st.launches += 1;
     e->toc(&e->st.ms_pairs);
     FSK_HIP(hipGetLastError());
     return FSK_OK;
