@@ -123,9 +123,24 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     RecT* rec[2] = {(RecT*)S.d_keys[0].p, (RecT*)S.d_keys[1].p};
 
     e->tic();
-    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_extract<RecT>), dim3(tps, nb), dim3(256), 0, stream, e->view(), e->d_featseq.p,
-               e->d_fstart.p, nfeat, tps, e->k, e->sigma, sb, by_id ? (const uint8_t*)e->d_allpos.p : (const uint8_t*)e->d_pos.p, rec[0],
-               S.d_blockhist.p, dmask, ids, by_id ? S.d_sxstat.p : (u64*)nullptr);
+    const uint8_t* const pos_tab = by_id ? (const uint8_t*)e->d_allpos.p : (const uint8_t*)e->d_pos.p;
+    u64* const zeroed_stats = by_id ? S.d_sxstat.p : (u64*)nullptr;
+    // With the window array the records are never written in generation order: the "extraction" only counts the
+    // first pass's digits, and the first scatter pass builds each record where it reads it.
+    const int ww = e->win_words;
+    constexpr bool R32 = sizeof(RecT) == 4;
+    const bool small = R32 && e->V <= ((u64)1 << 24) && e->sigma < (1u << 24);  // (the k-mer and every prefix of it fit 24 bits)
+    fsk::SxSrc src{};
+    src.win = e->d_win.p; src.feat_seq = e->d_featseq.p; src.combo_pos = pos_tab;
+    src.k = e->k; src.sb = sb; src.bits = e->bits; src.by_id = by_id ? 1 : 0; src.sigma = e->sigma; src.ids = ids;
+    if (ww) {
+        auto k_ex = ww == 2 ? (small ? fsk::k_sx_extract_win<RecT, 2, R32, false> : fsk::k_sx_extract_win<RecT, 2, false, false>)
+                            : (small ? fsk::k_sx_extract_win<RecT, 4, R32, false> : fsk::k_sx_extract_win<RecT, 4, false, false>);
+        FSK_LAUNCH(k_ex, dim3(tps, nb), dim3(256), 0, stream, src, nfeat, tps, rec[0], S.d_blockhist.p, dmask, zeroed_stats);
+    } else {
+        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_extract<RecT>), dim3(tps, nb), dim3(256), 0, stream, e->view(), e->d_featseq.p,
+                   e->d_fstart.p, nfeat, tps, e->k, e->sigma, sb, pos_tab, rec[0], S.d_blockhist.p, dmask, ids, zeroed_stats);
+    }
     e->toc(&e->st.ms_extract);
     e->st.launches += 1;
 
@@ -138,12 +153,19 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                        (1u << nbits) - 1u, S.d_blockhist.p);
         FSK_LAUNCH(fsk::k_sx_scan_slot, dim3(nb), dim3(1024), 0, stream, S.d_blockhist.p, tps, S.d_totals.p);
         {   // (function pointers: a template-id with a comma cannot pass through the launch macro)
-            auto k_scatter = nbits <= 4 ? fsk::k_sx_scatter<RecT, 4> : nbits == 5 ? fsk::k_sx_scatter<RecT, 5>
-                             : nbits == 6 ? fsk::k_sx_scatter<RecT, 6> : nbits == 7 ? fsk::k_sx_scatter<RecT, 7>
-                                                                                     : fsk::k_sx_scatter<RecT, 8>;
+            auto k_scatter = nbits <= 4 ? fsk::k_sx_scatter<RecT, 4, 0, false> : nbits == 5 ? fsk::k_sx_scatter<RecT, 5, 0, false>
+                             : nbits == 6 ? fsk::k_sx_scatter<RecT, 6, 0, false> : nbits == 7 ? fsk::k_sx_scatter<RecT, 7, 0, false>
+                                                                                             : fsk::k_sx_scatter<RecT, 8, 0, false>;
+            if (p == 0 && ww) {  // from the windows (ballot counts 4, 6, 7, 8 only: fewer instantiations)
+#define FSK_SCATTER_WIN(NB)                                                                                       \
+    (ww == 2 ? (small ? fsk::k_sx_scatter<RecT, NB, 2, R32> : fsk::k_sx_scatter<RecT, NB, 2, false>)                \
+             : (small ? fsk::k_sx_scatter<RecT, NB, 4, R32> : fsk::k_sx_scatter<RecT, NB, 4, false>))
+                k_scatter = nbits <= 4 ? FSK_SCATTER_WIN(4) : nbits <= 6 ? FSK_SCATTER_WIN(6) : nbits == 7 ? FSK_SCATTER_WIN(7) : FSK_SCATTER_WIN(8);
+#undef FSK_SCATTER_WIN
+            }
             FSK_LAUNCH(k_scatter, dim3(fsk::xcd_grid(tps * (uint32_t)nb)), dim3(256), 0, stream, (const RecT*)rec[cur], rec[cur ^ 1], nfeat, tps,
                        (uint32_t)nb, shift, nbits,
-                       (const uint32_t*)S.d_blockhist.p, (const uint32_t*)S.d_totals.p);
+                       (const uint32_t*)S.d_blockhist.p, (const uint32_t*)S.d_totals.p, src);
         }
         cur ^= 1;
         e->st.launches += 3;
@@ -305,6 +327,20 @@ int ensure_featseq(fsk_engine* e) {
         for (uint32_t f = e->h_fstart[i]; f < e->h_fstart[i + 1]; ++f) fs[f] = (uint32_t)i;
     FSK_HIP(e->d_featseq.reserve((size_t)e->nfeat));
     FSK_HIP(hipMemcpy(e->d_featseq.p, fs.data(), fs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // the g-mer windows, packed once: every record of every slot is then one 8- or 16-byte load (k_sx_extract_win)
+    const int wbits = e->cfg.g * e->bits;
+    e->win_words = wbits <= 64 ? 2 : wbits <= 128 ? 4 : 0;
+    if (e->win_words && e->nfeat > 0) {
+        FSK_HIP(e->d_win.reserve((size_t)e->nfeat * e->win_words));
+        const dim3 grid((uint32_t)((e->nfeat + 255) / 256));
+        if (e->win_words == 2)
+            FSK_LAUNCH(fsk::k_sx_windows<2>, grid, dim3(256), 0, e->stream, e->view(), (const uint32_t*)e->d_featseq.p,
+                       (const uint32_t*)e->d_fstart.p, (uint32_t)e->nfeat, e->cfg.g, e->d_win.p);
+        else
+            FSK_LAUNCH(fsk::k_sx_windows<4>, grid, dim3(256), 0, e->stream, e->view(), (const uint32_t*)e->d_featseq.p,
+                       (const uint32_t*)e->d_fstart.p, (uint32_t)e->nfeat, e->cfg.g, e->d_win.p);
+        FSK_HIP(hipStreamSynchronize(e->stream));  // (every lane's kernels read it)
+    }
     e->featseq_ready = true;
     return FSK_OK;
 }

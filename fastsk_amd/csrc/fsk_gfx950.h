@@ -17,6 +17,9 @@ __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
     return d;
 }
 
+// bits [off, off + width) of x (v_bfe_u32: one instruction for a shift and a mask that are not compile-time constants)
+__device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(x, off, width); }
+
 // value of lane `src` (wave-uniform index) in every lane: a scalar read, not an LDS permute
 __device__ __forceinline__ uint32_t readlane(uint32_t x, uint32_t src) {
     return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)src);

@@ -2,6 +2,7 @@
 // Included by fsk_engine_sparse.hip only.
 #pragma once
 #include "fsk_common.h"
+#include <type_traits>
 
 namespace fsk {
 

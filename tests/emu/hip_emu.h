@@ -311,6 +311,7 @@ static inline hipError_t hipMemGetInfo(size_t* fr, size_t* tot) { *fr = *tot = (
 // ---- what fastsk_amd/csrc/fsk_gfx950.h gives the product build: the same names, plain C++ ---------------
 namespace fsk_hw {
 static inline unsigned mad24(unsigned a, unsigned b, unsigned c) { return (a & 0xffffffu) * (b & 0xffffffu) + c; }
+static inline unsigned bfe(unsigned x, unsigned off, unsigned width) { return (x >> off) & (width >= 32u ? 0xffffffffu : (1u << width) - 1u); }
 static inline unsigned readlane(unsigned x, unsigned src) { return __shfl(x, (int)src); }
 static inline unsigned long long wave_sum_u64(unsigned long long x) {
     for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);

@@ -382,6 +382,19 @@ def test_emu_relabelled_and_wide_alphabets(emu_lib, port):
     assert np.array_equal(e.get_triangle(), port.normalise(want.astype(np.float64), 20))
     assert e.stats()["path_used"] == 2 and e.stats()["key_space"] == 20 ** 14
     e.close()
+    # g = 17 symbols of 8 bits pass the 128-bit window array: the records' symbols are gathered from the sequences
+    X = [rng.integers(1, 21, size=int(L)) for L in rng.integers(18, 40, size=12)]
+    for x in X[:5]:
+        x[0:18] = X[7][0:18]
+    tok, off = _native.flatten(X)
+    combos = np.arange(0, port.num_combos(17, 13), 90, dtype=np.int32)
+    e = _native.Engine(17, 13, path=2, lib=emu_lib)
+    e.load_sequences(tok, off, 8, 4)
+    e.accumulate(combos)
+    e.finalize()
+    want, _, _ = port.raw_counts(tok, off, 17, 13, combos)
+    assert np.array_equal(e.get_counts(), want) and want[1] > 0
+    e.close()
 
 
 def test_emu_mixed_4bit_and_8bit_panels(emu_lib, port):

@@ -167,7 +167,7 @@ def test_wide_kmers_128_bit_sort_records(native, port):
     """k = 14 over 20 symbols (61 k-mer bits) and enough sequences that k-mer + sequence id pass 64 bits:
     the sparse dataflow sorts 128-bit records (and 64-bit ones for k = 9) — against the oracle."""
     rng = np.random.default_rng(31)
-    for g, m, n in ((16, 2, 40), (12, 3, 300)):
+    for g, m, n in ((16, 2, 40), (12, 3, 300), (18, 4, 40)):  # (g = 18 x 8 bits: beyond the 128-bit window array)
         X = [rng.integers(1, 21, size=int(L)).astype(np.int32) for L in rng.integers(g + 1, 60, size=n)]
         for x in X[: n // 3]:
             x[1:g + 1] = X[n // 2][1:g + 1]
