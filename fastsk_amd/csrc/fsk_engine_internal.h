@@ -133,6 +133,7 @@ struct fsk_engine {
     DevBuf<uint32_t> d_words, d_wstart, d_len, d_fstart, d_featseq;
     DevBuf<uint32_t> d_win;  // sparse dataflow: the g-mer windows, win_words 32-bit words each (0: g * bits > 128, symbols are gathered)
     int win_words = 0;
+    int extract_slots = 0;  // FSK_EXTRACT_SLOTS=1|4: slots per k_sx_extract_win workgroup (0: by the size of the launch)
     std::vector<uint32_t> h_len, h_fstart;
     bool featseq_ready = false;
     int force_splits = 0;      // FSK_TILE_SPLITS=n: combo splits per tile (tuning)

@@ -125,8 +125,6 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     e->tic();
     const uint8_t* const pos_tab = by_id ? (const uint8_t*)e->d_allpos.p : (const uint8_t*)e->d_pos.p;
     u64* const zeroed_stats = by_id ? S.d_sxstat.p : (u64*)nullptr;
-    // With the window array the records are never written in generation order: the "extraction" only counts the
-    // first pass's digits, and the first scatter pass builds each record where it reads it.
     const int ww = e->win_words;
     constexpr bool R32 = sizeof(RecT) == 4;
     const bool small = R32 && e->V <= ((u64)1 << 24) && e->sigma < (1u << 24);  // (the k-mer and every prefix of it fit 24 bits)
@@ -134,9 +132,15 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     src.win = e->d_win.p; src.feat_seq = e->d_featseq.p; src.combo_pos = pos_tab;
     src.k = e->k; src.sb = sb; src.bits = e->bits; src.by_id = by_id ? 1 : 0; src.sigma = e->sigma; src.ids = ids;
     if (ww) {
-        auto k_ex = ww == 2 ? (small ? fsk::k_sx_extract_win<RecT, 2, R32, false> : fsk::k_sx_extract_win<RecT, 2, false, false>)
-                            : (small ? fsk::k_sx_extract_win<RecT, 4, R32, false> : fsk::k_sx_extract_win<RecT, 4, false, false>);
-        FSK_LAUNCH(k_ex, dim3(tps, nb), dim3(256), 0, stream, src, nfeat, tps, rec[0], S.d_blockhist.p, dmask, zeroed_stats);
+        // (four slots per workgroup share the window loads when that still leaves a few thousand workgroups)
+        const bool four = e->extract_slots ? e->extract_slots == 4 : (u64)tps * (u64)nb >= 8192;
+#define FSK_EXTRACT_WIN(SPW)                                                                                          \
+    (ww == 2 ? (small ? fsk::k_sx_extract_win<RecT, 2, R32, SPW> : fsk::k_sx_extract_win<RecT, 2, false, SPW>)         \
+             : (small ? fsk::k_sx_extract_win<RecT, 4, R32, SPW> : fsk::k_sx_extract_win<RecT, 4, false, SPW>))
+        auto k_ex = four ? FSK_EXTRACT_WIN(4) : FSK_EXTRACT_WIN(1);
+#undef FSK_EXTRACT_WIN
+        FSK_LAUNCH(k_ex, dim3(tps, four ? ((uint32_t)nb + 3u) / 4u : (uint32_t)nb), dim3(256), 0, stream, src, nfeat, tps, (uint32_t)nb, rec[0],
+                   S.d_blockhist.p, dmask, zeroed_stats);
     } else {
         FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_extract<RecT>), dim3(tps, nb), dim3(256), 0, stream, e->view(), e->d_featseq.p,
                    e->d_fstart.p, nfeat, tps, e->k, e->sigma, sb, pos_tab, rec[0], S.d_blockhist.p, dmask, ids, zeroed_stats);
@@ -153,19 +157,12 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                        (1u << nbits) - 1u, S.d_blockhist.p);
         FSK_LAUNCH(fsk::k_sx_scan_slot, dim3(nb), dim3(1024), 0, stream, S.d_blockhist.p, tps, S.d_totals.p);
         {   // (function pointers: a template-id with a comma cannot pass through the launch macro)
-            auto k_scatter = nbits <= 4 ? fsk::k_sx_scatter<RecT, 4, 0, false> : nbits == 5 ? fsk::k_sx_scatter<RecT, 5, 0, false>
-                             : nbits == 6 ? fsk::k_sx_scatter<RecT, 6, 0, false> : nbits == 7 ? fsk::k_sx_scatter<RecT, 7, 0, false>
-                                                                                             : fsk::k_sx_scatter<RecT, 8, 0, false>;
-            if (p == 0 && ww) {  // from the windows (ballot counts 4, 6, 7, 8 only: fewer instantiations)
-#define FSK_SCATTER_WIN(NB)                                                                                       \
-    (ww == 2 ? (small ? fsk::k_sx_scatter<RecT, NB, 2, R32> : fsk::k_sx_scatter<RecT, NB, 2, false>)                \
-             : (small ? fsk::k_sx_scatter<RecT, NB, 4, R32> : fsk::k_sx_scatter<RecT, NB, 4, false>))
-                k_scatter = nbits <= 4 ? FSK_SCATTER_WIN(4) : nbits <= 6 ? FSK_SCATTER_WIN(6) : nbits == 7 ? FSK_SCATTER_WIN(7) : FSK_SCATTER_WIN(8);
-#undef FSK_SCATTER_WIN
-            }
+            auto k_scatter = nbits <= 4 ? fsk::k_sx_scatter<RecT, 4> : nbits == 5 ? fsk::k_sx_scatter<RecT, 5>
+                             : nbits == 6 ? fsk::k_sx_scatter<RecT, 6> : nbits == 7 ? fsk::k_sx_scatter<RecT, 7>
+                                                                                     : fsk::k_sx_scatter<RecT, 8>;
             FSK_LAUNCH(k_scatter, dim3(fsk::xcd_grid(tps * (uint32_t)nb)), dim3(256), 0, stream, (const RecT*)rec[cur], rec[cur ^ 1], nfeat, tps,
                        (uint32_t)nb, shift, nbits,
-                       (const uint32_t*)S.d_blockhist.p, (const uint32_t*)S.d_totals.p, src);
+                       (const uint32_t*)S.d_blockhist.p, (const uint32_t*)S.d_totals.p);
         }
         cur ^= 1;
         e->st.launches += 3;

@@ -17,6 +17,13 @@ __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
     return d;
 }
 
+// low 32 bits of a * b for a, b < 2^24: v_mul_u32_u24 issues at full rate, v_mul_lo_u32 at a quarter of it
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 // bits [off, off + width) of x (v_bfe_u32: one instruction for a shift and a mask that are not compile-time constants)
 __device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(x, off, width); }
 
@@ -42,6 +49,24 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long x)
     FSK_DPP_ADD64(0x143, 0xc)  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
 #undef FSK_DPP_ADD64
     return ((unsigned long long)readlane((uint32_t)(x >> 32), 63u) << 32) | readlane((uint32_t)x, 63u);
+}
+
+// running maximum over the lanes (lane l gets the maximum of lanes 0..l), values >= -1: DPP row shifts inside the rows
+// of 16 lanes, then row 0 -> 1 and 2 -> 3, then lane 31 -> rows 2-3; six VALU instructions, no LDS permute
+__device__ __forceinline__ int wave_incl_max_i32(int x) {
+#define FSK_DPP_MAX(ctrl, rows)                                                        \
+    {                                                                                  \
+        const int y = __builtin_amdgcn_update_dpp(-1, x, ctrl, rows, 0xf, false);      \
+        x = y > x ? y : x;                                                             \
+    }
+    FSK_DPP_MAX(0x111, 0xf)  // row_shr:1
+    FSK_DPP_MAX(0x112, 0xf)  // row_shr:2
+    FSK_DPP_MAX(0x114, 0xf)  // row_shr:4
+    FSK_DPP_MAX(0x118, 0xf)  // row_shr:8
+    FSK_DPP_MAX(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+    FSK_DPP_MAX(0x143, 0xc)  // row_bcast:31 into rows 2 and 3
+#undef FSK_DPP_MAX
+    return x;
 }
 
 // a copy of a VGPR the compiler cannot see through (see the flush of the tile kernels: a 64-bit operand built from

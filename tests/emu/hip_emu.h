@@ -311,6 +311,14 @@ static inline hipError_t hipMemGetInfo(size_t* fr, size_t* tot) { *fr = *tot = (
 // ---- what fastsk_amd/csrc/fsk_gfx950.h gives the product build: the same names, plain C++ ---------------
 namespace fsk_hw {
 static inline unsigned mad24(unsigned a, unsigned b, unsigned c) { return (a & 0xffffffu) * (b & 0xffffffu) + c; }
+static inline unsigned mul24(unsigned a, unsigned b) { return (unsigned)((unsigned long long)(a & 0xffffffu) * (b & 0xffffffu)); }
+static inline int wave_incl_max_i32(int x) {
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if ((int)emu::lane_id() >= d && y > x) x = y;
+    }
+    return x;
+}
 static inline unsigned bfe(unsigned x, unsigned off, unsigned width) { return (x >> off) & (width >= 32u ? 0xffffffffu : (1u << width) - 1u); }
 static inline unsigned readlane(unsigned x, unsigned src) { return __shfl(x, (int)src); }
 static inline unsigned long long wave_sum_u64(unsigned long long x) {

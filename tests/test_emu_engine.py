@@ -490,6 +490,25 @@ def test_emu_dense_large_key_space_sweeps(emu_lib, port, sigma, g, m):
     assert np.array_equal(e.get_counts(), want)
 
 
+def test_emu_extract_four_slots_per_workgroup(emu_lib, port, monkeypatch):
+    """Large sparse launches take a tile of windows through four slots per workgroup (FSK_EXTRACT_SLOTS forces it
+    here); a batch whose slot count is not a multiple of four leaves the last workgroup row short."""
+    from fastsk_amd import _native
+    monkeypatch.setenv("FSK_EXTRACT_SLOTS", "4")
+    for name in ("f5_prot11_exact", "f3_ragged_sigma7_g6m3"):
+        d = load_golden(name)
+        nc = port.num_combos(d["g"], d["m"])
+        combos = np.arange(0, nc, max(1, nc // 13), dtype=np.int32)[:13]
+        want, _, _ = port.raw_counts(d["tokens"], d["offsets"], d["g"], d["m"], combos)
+        e = _native.Engine(d["g"], d["m"], path=2, lib=emu_lib)
+        e.load_sequences(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+        e.accumulate(combos[:6])
+        e.accumulate(combos[6:])
+        e.finalize()
+        assert np.array_equal(e.get_counts(), want), name
+        e.close()
+
+
 @pytest.mark.parametrize("global_pairs", ["0", "1"])
 def test_emu_sparse_pair_accumulation_variants(emu_lib, port, monkeypatch, global_pairs):
     """Sparse dataflow: owner-slice LDS accumulation (default when a row band of K fits in LDS)
