@@ -45,10 +45,12 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     // of its stop test: iterations are issued in batches of AHEAD with up to DEPTH batches in flight,
     // the Welford state of every untested iteration is kept in a ring, and whatever lies beyond the
     // stopping iteration is dropped.
-    // (two batches in flight: the sums of one run on the second stream under the kernels of the next;
-    // a third would only add iterations that are thrown away when the stop test fires)
-    constexpr int AHEAD = 8, MAX_DEPTH = 2;
-    const int DEPTH = MAX_DEPTH;
+    // (the sums of a batch run on a stream of their own under the kernels of the batches that follow)
+    // (two batches in flight, one per lane. Measured with three and four — the issue of a batch waits for the sums
+    // of the oldest one in flight, a latency a third batch would cover —: config 1 6.4 -> 6.8 -> 7.4 ms; the GPU is
+    // busy as it is, and what the extra batches add are iterations beyond the stop.)
+    constexpr int AHEAD = 8, MAX_DEPTH = 2, LANES = 2;
+    const int DEPTH = MAX_DEPTH, INFLIGHT = MAX_DEPTH;
     const int RING = DEPTH * AHEAD + 1;
     const bool trace = getenv("FSK_TRACE") != nullptr;  // stderr: where the wall time of this mode goes
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -73,7 +75,7 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     }
     double* h_avg = e->h_prod;  // pinned
     if (!e->chain_stream) FSK_HIP(hipStreamCreateWithFlags(&e->chain_stream, hipStreamNonBlocking));
-    hipEvent_t ev_done[MAX_DEPTH], ev_hand[MAX_DEPTH], ev_wf[MAX_DEPTH];
+    hipEvent_t ev_done[MAX_DEPTH], ev_hand[MAX_DEPTH], ev_wf[MAX_DEPTH];  // (ev_wf: one per lane)
     for (auto& ev : ev_done) FSK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     for (auto& ev : ev_hand) FSK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     for (auto& ev : ev_wf) FSK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -99,16 +101,26 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
         FSK_HIP(hipEventRecord(ev_wf[0], e->stream));
         FSK_HIP(hipStreamWaitEvent(e->lane_stream, ev_wf[0], 0));
     }
-    bool wf_set[MAX_DEPTH] = {false, false};  // ev_wf[lane] holds a Welford pass of the chain at hand
+    bool wf_set[LANES] = {false, false};  // ev_wf[lane] holds a Welford pass of the chain at hand
     const double t_alloc = ms_since(t_begin);
     const uint32_t blocks = (uint32_t)((pairs + 255) / 256);                                       // one cell per thread
     const uint32_t wblocks = (uint32_t)((pairs + 256 * fsk::WF_ITEMS - 1) / (256 * fsk::WF_ITEMS)); // k_welford
     const int n_order = (int)e->order.size();
     auto khat = [&](int i) { return e->d_Khat.p + (size_t)(i % RING) * (size_t)pairs; };
     struct Batch { int n = 0, first_iter = 0, first_item = 0, base = 0, part = 0; bool grouped = false; };
+    // Where the stop test is expected to fire: the variance estimate settles, so sd falls like 1 / sqrt(iter) and
+    // delta / sd > 1.96 is reached near iter * (1.96 sd / delta)^2. Only the SIZE of the batches issued ahead follows
+    // from it (what lies beyond the stop is thrown away: a full batch there is an eighth of config 1's work); a
+    // wrong guess costs small batches, never a result.
+    int pred_stop = INT32_MAX;
+    constexpr int HEDGE = 2;  // iterations issued ahead once the stop is expected to have fired already
     // how many iterations can still follow (end of the work list, max_iters)
     auto plan = [&](int first_iter, int first_item) {
         int n = AHEAD;
+        if (pred_stop != INT32_MAX) {
+            const int64_t left = (int64_t)pred_stop + 1 - first_iter;  // (one to spare)
+            n = left >= AHEAD ? AHEAD : left > 0 ? (int)left : HEDGE;
+        }
         n = std::min(n, first_item < n_order ? (n_order - first_item + T - 1) / T : 0);
         if (e->cfg.max_iters != -1) n = std::min(n, e->cfg.max_iters - first_iter + 1);
         return std::max(n, 0);
@@ -152,7 +164,7 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
         const int lane = grouped ? sx_lane_of(e, B.part) : 0;
         hipStream_t bs = lane ? e->lane_stream : e->stream;
         if (was_grouped && !grouped) sync_all();  // (leaving the two-lane form: everything drains first, once)
-        for (int l = 0; l < MAX_DEPTH; ++l)  // K_hat comes from the previous batch's Welford pass, wherever that ran
+        for (int l = 0; l < LANES; ++l)  // K_hat comes from the previous batch's Welford pass, wherever that ran
             if (l != lane && wf_set[l]) FSK_HIP(hipStreamWaitEvent(bs, ev_wf[l], 0));
         if (grouped) {  // K_hat through the batch's iterations in one pass; only the state after the batch is written
             const size_t slot0 = (size_t)B.part * AHEAD;
@@ -198,9 +210,10 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     e->stdevs.clear();
     for (int tid = chain_first; tid < T; tid += chain_step) {
         int cur = 0;  // ring position of the state after the last accepted iteration
+        pred_stop = INT32_MAX;
         FSK_HIP(hipMemsetAsync(khat(cur), 0, (size_t)pairs * sizeof(double), e->stream));
         int iter = 1, item = tid;
-        std::vector<Batch> q;  // issued, untested batches, oldest first (at most DEPTH)
+        std::vector<Batch> q;  // issued, untested batches, oldest first (at most INFLIGHT)
         {
             Batch A;
             A.first_iter = iter; A.first_item = item; A.base = cur; A.part = 0;
@@ -211,7 +224,7 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
         }
         bool working = true;
         while (working) {
-            while ((int)q.size() < DEPTH) {  // keep the device DEPTH batches ahead of the stop test
+            while ((int)q.size() < INFLIGHT) {  // keep the device INFLIGHT batches ahead of the stop test
                 Batch N = after(q.back());
                 if (N.n == 0) break;
                 int rc = issue(N);
@@ -246,6 +259,10 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
                 const double sd = std::sqrt(v / iter);
                 if (tid == 0) e->stdevs.push_back(sd);
                 if (e->cfg.delta / sd > 1.96) working = false;
+                if (iter >= 2 && sd > 0.0 && e->cfg.delta > 0.0) {
+                    const double at = (double)iter * (1.96 * sd / e->cfg.delta) * (1.96 * sd / e->cfg.delta);
+                    pred_stop = at < 1e9 ? std::max(iter, (int)std::ceil(at)) : INT32_MAX;
+                }
                 if (e->cfg.max_iters != -1 && iter >= e->cfg.max_iters) working = false;
                 item += T;
                 if (item >= n_order) working = false;
@@ -282,7 +299,7 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     FSK_HIP(hipStreamSynchronize(e->stream));
     if (trace)
         fprintf(stderr, "[fsk] variance mode: setup %.2f ms, waiting for the GPU %.2f ms, total %.2f ms (%lld cells/iteration, %d batches in flight)\n",
-                t_alloc, t_wait, ms_since(t_begin), (long long)train_pairs, DEPTH);
+                t_alloc, t_wait, ms_since(t_begin), (long long)train_pairs, INFLIGHT);
     return FSK_OK;
 }
 

@@ -18,6 +18,6 @@ for i in range(1, len(rows)):
 run = rows[cut:]
 t0 = run[0][0]
 print("kernels", len(run), "span %.3f ms" % ((max(r[1] for r in run) - t0) / 1e6))
-for a, b, n, q in run[:140]:
+for a, b, n, q in run[:400]:
     print("%9.1f %9.1f %7.1f  q%-4s %s" % ((a - t0) / 1e3, (b - t0) / 1e3, (b - a) / 1e3, q, n))
 PY
