@@ -150,6 +150,11 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     auto slots_of = [&](int part) { return reinterpret_cast<uint32_t*>(e->d_Kslots.p) + (size_t)part * AHEAD * (size_t)pairs; };
     auto slots64_of = [&](int part) { return e->d_Kslots.p + (size_t)part * AHEAD * (size_t)pairs; };
     static_assert(AHEAD <= fsk::WF_SLOTS, "k_welford_batch carries a batch's iterations in registers");
+    // (Tried: the Welford pass INSIDE the by-slot pass over the update streams — one workgroup per owner band goes
+    // through the batch's slots in order, K_hat in registers, no slot triangles written and read back (2 x 204 MB
+    // of a config-1 batch's 1.3 GB). The slots then come one after the other inside a workgroup, a few tens of words
+    // per thread each, and every memory latency is paid eight times: 390 us a batch against 190 + 130 us for
+    // k_sx_consume over (band, slot) in parallel + k_welford_batch.)
     auto issue = [&](Batch& B) -> int {
         const bool was_grouped = grouped;
         if (grouped) {

@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void k_welford(const SrcT* Ks, const double* K
     __shared__ double part[4];
     const u64 base = (u64)blockIdx.x * (256 * WF_ITEMS);
     double pr = 0.0;
+    const double r_iter = __ddiv_rn(1.0, iter);
 #pragma unroll
     for (int q = 0; q < WF_ITEMS; ++q) {
         const u64 i = base + (u64)q * 256 + threadIdx.x;
@@ -29,7 +30,7 @@ __global__ __launch_bounds__(256) void k_welford(const SrcT* Ks, const double* K
             const double x = (double)Ks[i];
             const double old = K_hat_in[i];
             const double delta = __dsub_rn(x, old);
-            const double kh = __dadd_rn(old, __ddiv_rn(delta, iter));
+            const double kh = __dadd_rn(old, div_by_shared(delta, iter, r_iter));
             K_hat_out[i] = kh;
             if (i < train_pairs) {
                 const double v = __dmul_rn(delta, __dsub_rn(x, kh));
@@ -66,6 +67,9 @@ __global__ __launch_bounds__(256) void k_welford_batch(const SrcT* Ks, int nslot
     double pr[WF_SLOTS];
 #pragma unroll
     for (int s = 0; s < WF_SLOTS; ++s) pr[s] = 0.0;
+    double r_iter[WF_SLOTS];  // 1 / iteration number: see div_by_shared
+#pragma unroll
+    for (int s = 0; s < WF_SLOTS; ++s) r_iter[s] = __ddiv_rn(1.0, first_iter + (double)s);
 #pragma unroll
     for (int q = 0; q < WF_ITEMS; ++q) {
         const u64 i = base + (u64)q * 256 + threadIdx.x;
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(256) void k_welford_batch(const SrcT* Ks, int nslot
                 if (s < nslots) {
                     const double x = (double)xs[s];
                     const double delta = __dsub_rn(x, kh);
-                    kh = __dadd_rn(kh, __ddiv_rn(delta, first_iter + (double)s));
+                    kh = __dadd_rn(kh, div_by_shared(delta, first_iter + (double)s, r_iter[s]));
                     if (write_prod && i < train_pairs) {
                         const double v = __dmul_rn(delta, __dsub_rn(x, kh));
                         prod[(u64)s * prod_stride + i] = v;

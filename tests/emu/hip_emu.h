@@ -258,6 +258,7 @@ static inline unsigned __builtin_amdgcn_udot8(unsigned a, unsigned b, unsigned c
 }
 static inline double __dsqrt_rn(double x) { return __builtin_sqrt(x); }
 static inline double __dmul_rn(double a, double b) { return a * b; }
+static inline double __fma_rn(double a, double b, double c) { return std::fma(a, b, c); }
 static inline double __ddiv_rn(double a, double b) { return a / b; }
 static inline double __dadd_rn(double a, double b) { return a + b; }
 static inline double __dsub_rn(double a, double b) { return a - b; }
