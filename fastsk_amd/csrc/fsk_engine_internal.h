@@ -178,6 +178,7 @@ struct fsk_engine {
     DevBuf<u64> d_U;
     std::vector<uint32_t> h_owner_r0;     // owner bands of K: rows [r0[o], r0[o+1])
     uint32_t n_owners = 0, sx_rounds = 1, sx_cap = 0;
+    uint32_t sx_rounds_slot = 1, sx_cap_slot = 0;  // the same for the by-slot form of k_sx_consume (variance mode)
     int sx_pb = 16, sx_sb = 1, sx_keybits = 1, sx_own_shift = 13;
     bool sx_lists = false, owner_ready = false;
     // profile mode, dense dataflow: U of the last single-chunk combo list is kept, so that repeating

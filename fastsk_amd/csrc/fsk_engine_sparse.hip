@@ -15,6 +15,7 @@ namespace fsk_detail {
 // it: SX_CAP cells per round, at most SX_MAX_ROUNDS rounds over the band's stream).
 constexpr uint32_t SX_CAP = 16384;        // u32 cells of K one k_sx_consume workgroup holds in LDS (64 KiB)
 constexpr uint32_t SX_MAX_ROUNDS = 16;
+constexpr uint32_t SX_CAP_SLOT = 20480;   // by-slot form (no parts table in LDS): 80 KiB, two workgroups per CU
 
 void plan_owner_bands(fsk_engine* e) {
     // band o = the rows whose first cell index lies in [o << t, (o + 1) << t): a row's band is a shift
@@ -41,6 +42,8 @@ void plan_owner_bands(fsk_engine* e) {
     e->sx_pb = 32 - L;
     e->sx_rounds = (uint32_t)std::max<u64>(1, (largest + SX_CAP - 1) / SX_CAP);
     e->sx_cap = (uint32_t)std::max<u64>(1, std::min<u64>(SX_CAP, largest));
+    e->sx_rounds_slot = (uint32_t)std::max<u64>(1, (largest + SX_CAP_SLOT - 1) / SX_CAP_SLOT);
+    e->sx_cap_slot = (uint32_t)std::max<u64>(1, std::min<u64>(SX_CAP_SLOT, largest));
     e->sx_lists = e->n_owners <= (uint32_t)fsk::SX_MAX_OWNERS && e->sx_rounds <= SX_MAX_ROUNDS && e->sx_pb >= 8;
     e->owner_ready = false;
 }
@@ -269,20 +272,21 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                            (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
                            slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles);
             }
-            const size_t lds = (size_t)e->sx_cap * sizeof(uint32_t);
-            FSK_HIP(fsk_hw::allow_dynamic_lds(fsk::k_sx_consume, lds));
+            const size_t lds = (size_t)e->sx_cap * sizeof(uint32_t), lds_slot = (size_t)e->sx_cap_slot * sizeof(uint32_t);
+            FSK_HIP(fsk_hw::allow_dynamic_lds(fsk::k_sx_consume<false>, lds));
+            FSK_HIP(fsk_hw::allow_dynamic_lds(fsk::k_sx_consume<true>, lds_slot));
             // parts of about `target` words: ~1024 workgroups, and never so short that the flush of a
             // part (up to sx_cap cells) outweighs the words it summed
             const uint32_t target = (uint32_t)std::max<u64>((u64)4 * e->sx_cap, (words + 1023) / 1024);
             const uint32_t max_parts = O + (uint32_t)(((guarded ? guard_cap : words) + target - 1) / target);
             if (slot_stride != 0) {  // one triangle per slot: a slot's words of a stream are one contiguous piece
-                FSK_LAUNCH(fsk::k_sx_consume, dim3(O, e->sx_rounds, nb), dim3(fsk::CS_THREADS), lds, stream, (const uint32_t*)S.d_ulist.p,
+                FSK_LAUNCH(fsk::k_sx_consume<true>, dim3(O, e->sx_rounds_slot, nb), dim3(fsk::CS_THREADS), lds_slot, stream, (const uint32_t*)S.d_ulist.p,
                            (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)nullptr, O, target,
-                           e->sx_cap, e->sx_pb, K, (const uint32_t*)S.d_ucount.p, tpg, slot_stride, (const u64*)S.d_sxstat.p, cap_words);
+                           e->sx_cap_slot, e->sx_pb, K, (const uint32_t*)S.d_ucount.p, tpg, slot_stride, (const u64*)S.d_sxstat.p, cap_words);
             } else {
                 FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, stream, (const uint32_t*)S.d_list_off.p, O, target, S.d_part_base.p,
                            (const u64*)S.d_sxstat.p, cap_words);
-                FSK_LAUNCH(fsk::k_sx_consume, dim3(max_parts, e->sx_rounds), dim3(fsk::CS_THREADS), lds, stream, (const uint32_t*)S.d_ulist.p,
+                FSK_LAUNCH(fsk::k_sx_consume<false>, dim3(max_parts, e->sx_rounds), dim3(fsk::CS_THREADS), lds, stream, (const uint32_t*)S.d_ulist.p,
                            (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)S.d_part_base.p, O, target,
                            e->sx_cap, e->sx_pb, K, (const uint32_t*)nullptr, tpg, (u64)0, (const u64*)S.d_sxstat.p, cap_words);
                 e->st.launches += 1;
