@@ -69,6 +69,24 @@ __device__ __forceinline__ int wave_incl_max_i32(int x) {
     return x;
 }
 
+// running sum over the lanes (lane l gets the sum of lanes 0..l): the same DPP steps as wave_sum_u64
+__device__ __forceinline__ unsigned long long wave_incl_sum_u64(unsigned long long x) {
+#define FSK_DPP_ADD64(ctrl, rows)                                                                                   \
+    {                                                                                                               \
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, ctrl, rows, 0xf, true);      \
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), ctrl, rows, 0xf, true); \
+        x += ((unsigned long long)hi << 32) | lo;                                                                   \
+    }
+    FSK_DPP_ADD64(0x111, 0xf)  // row_shr:1
+    FSK_DPP_ADD64(0x112, 0xf)  // row_shr:2
+    FSK_DPP_ADD64(0x114, 0xf)  // row_shr:4
+    FSK_DPP_ADD64(0x118, 0xf)  // row_shr:8
+    FSK_DPP_ADD64(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+    FSK_DPP_ADD64(0x143, 0xc)  // row_bcast:31 into rows 2 and 3
+#undef FSK_DPP_ADD64
+    return x;
+}
+
 // a copy of a VGPR the compiler cannot see through (see the flush of the tile kernels: a 64-bit operand built from
 // the accumulator itself makes hipcc keep every accumulator in the low half of a register pair)
 __device__ __forceinline__ uint32_t vgpr_copy(uint32_t x) {

@@ -295,110 +295,146 @@ __device__ __forceinline__ double wave_bcast_f64(double x, uint32_t src) {
 // with): DPP row shifts / broadcasts (fsk_hw::wave_sum_u64), not six dependent LDS permutes per 32-bit half.
 __device__ __forceinline__ u64 wave_sum_u64(u64 x) { return fsk_hw::wave_sum_u64(x); }
 
-// PER values per lane (held in registers; 0.0 where the range ended) added to s as one integer total,
-// if the conditions hold
-template <int PER>
-__device__ __forceinline__ bool seq_try_regs(const double (&v)[PER], double& s) {
-    const int e = seq_exponent(s);
-    const bool usable = e != INT32_MIN && s > 0.0;
-    const double scale = seq_pow2(52 - (usable ? e : 0));
-    u64 q = 0;
-    uint32_t fl = 0, nonzero = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        if (v[k] != 0.0) nonzero = 1u;
-        seq_classify(v[k], scale, 4503599627370496.0 /* 2^52 */, q, fl);
+// The running sum of a chain: either the double s, or — while it stays inside one binade — the integer
+// S = s / 2^(e-52) in [2^52, 2^53): values that go through as integer totals are then one 64-bit add and a compare, with
+// no conversion between the two forms until a value has to be added the plain way.
+struct SeqAcc {
+    double s;
+    u64 S;
+    int e;
+    bool as_int;
+};
+__device__ __forceinline__ void seq_acc_to_int(SeqAcc& a) {
+    if (!a.as_int && a.s > 0.0 && seq_exponent(a.s) != INT32_MIN) {
+        a.e = seq_exponent(a.s);
+        a.S = (u64)(a.s * seq_pow2(52 - a.e));
+        a.as_int = true;
     }
+}
+__device__ __forceinline__ void seq_acc_to_double(SeqAcc& a) {
+    if (a.as_int) {
+        a.s = (double)a.S * seq_pow2(a.e - 52);
+        a.as_int = false;
+    }
+}
+// registers cur[OFF .. OFF + LEN) of every lane (values 64 k + lane of a group; 0.0 where the range ended) added to the
+// sum as one integer total, if the conditions hold
+template <int OFF, int LEN>
+__device__ __forceinline__ bool seq_try_span(const double (&cur)[16], SeqAcc& a) {
+    uint32_t nonzero = 0;
+#pragma unroll
+    for (int k = OFF; k < OFF + LEN; ++k)
+        if (cur[k] != 0.0) nonzero = 1u;  // (NaN counts as non-zero)
     if (__ballot(nonzero != 0u) == 0ull) return true;  // zeros change no running sum, whatever it is (s starts at +0 and +0 + -0 = +0)
-    if (!usable || __ballot(fl != 0u) != 0ull) return false;
-    const u64 tot = (u64)(s * scale) + wave_sum_u64(q);
+    seq_acc_to_int(a);
+    if (!a.as_int) return false;
+    const double scale = seq_pow2(52 - a.e);
+    u64 q = 0;
+    uint32_t fl = 0;
+#pragma unroll
+    for (int k = OFF; k < OFF + LEN; ++k) seq_classify(cur[k], scale, 4503599627370496.0 /* 2^52 */, q, fl);
+    if (__ballot(fl != 0u) != 0ull) return false;
+    const u64 tot = a.S + wave_sum_u64(q);
     if (tot >= ((u64)1 << 53)) return false;
-    s = (double)tot * seq_pow2(e - 52);
+    a.S = tot;
     return true;
 }
-// The values [lo, hi) added to s by one wave (a workgroup of its own): SQ_STAGE values at a time go
-// through registers into LDS — the loads of the next stage are in flight while this one is summed — and
-// are taken from there in groups of 1024 (16 per lane, value 64 k + lane in register k), then for a
-// group that crosses a binade, holds a tie or a negative value in its 16 sub-groups of 64, then by plain
-// sequential additions. s and every decision are wave-uniform.
-constexpr int SQ_STAGE = 4096;
-__device__ __forceinline__ double seq_range(const double* p, u64 lo, u64 hi, double s, double* stage) {
+// ... and the same span added whatever it holds: as a whole, else by halves, down to one register (64 consecutive
+// values), which is then added value by value — the place where the running sum crosses a binade, or a tie, or a
+// negative value. `here`: values of the group that exist.
+template <int OFF, int LEN>
+__device__ __forceinline__ void seq_span(const double (&cur)[16], uint32_t here, SeqAcc& a) {
+    if (seq_try_span<OFF, LEN>(cur, a)) return;
+    if constexpr (LEN == 1) {
+        seq_acc_to_double(a);
+        const uint32_t q0 = (uint32_t)OFF * 64u;
+        const uint32_t cn = q0 >= here ? 0u : (here - q0 < 64u ? here - q0 : 64u);
+        double s = a.s;
+        for (uint32_t j = 0; j < cn; ++j) s = __dadd_rn(s, wave_bcast_f64(cur[OFF], j));
+        a.s = s;
+    } else {
+        seq_span<OFF, LEN / 2>(cur, here, a);
+        seq_span<OFF + LEN / 2, LEN / 2>(cur, here, a);
+    }
+}
+// The values [lo, hi) added to the sum by one wave: groups of 1024 straight from global memory into registers (16 per
+// lane, value 64 k + lane in register k), the loads of the next group in flight while this one is summed (no LDS
+// staging: the chain is one wave per sum and every microsecond of it is latency the next batch of iterations waits
+// for). Every decision is wave-uniform.
+__device__ __forceinline__ void seq_range(const double* p, u64 lo, u64 hi, SeqAcc& a) {
     const uint32_t lane = threadIdx.x & 63u;
-    constexpr int PER = SQ_STAGE / 64;
-    double nx[PER];
+    double nx[16];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
+    for (int k = 0; k < 16; ++k) {
         const u64 i = lo + (u64)k * 64 + lane;
         nx[k] = i < hi ? p[i] : 0.0;
     }
-    for (u64 c0 = lo; c0 < hi; c0 += SQ_STAGE) {
-        __syncthreads();  // (one wave: orders the LDS reads of the stage before with these writes)
+    for (u64 g0 = lo; g0 < hi; g0 += 1024) {
+        double cur[16];
 #pragma unroll
-        for (int k = 0; k < PER; ++k) stage[k * 64 + (int)lane] = nx[k];
-        if (c0 + SQ_STAGE < hi) {
+        for (int k = 0; k < 16; ++k) cur[k] = nx[k];
+        if (g0 + 1024 < hi) {
 #pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const u64 i = c0 + SQ_STAGE + (u64)k * 64 + lane;
+            for (int k = 0; k < 16; ++k) {
+                const u64 i = g0 + 1024 + (u64)k * 64 + lane;
                 nx[k] = i < hi ? p[i] : 0.0;
             }
         }
-        __syncthreads();
-        const uint32_t here = hi - c0 < (u64)SQ_STAGE ? (uint32_t)(hi - c0) : (uint32_t)SQ_STAGE;
-        for (uint32_t g0 = 0; g0 < here; g0 += 1024u) {
-            double cur[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) cur[k] = stage[g0 + (uint32_t)k * 64u + lane];  // (0.0 beyond hi)
-            if (seq_try_regs<16>(cur, s)) continue;
-#pragma unroll 1
-            for (uint32_t k = 0; k < 16u; ++k) {  // (rolled: a rare path, kept small)
-                const uint32_t q0 = g0 + k * 64u;
-                const double one[1] = {stage[q0 + lane]};
-                if (!seq_try_regs<1>(one, s)) {
-                    const uint32_t cn = q0 >= here ? 0u : (here - q0 < 64u ? here - q0 : 64u);
-                    for (uint32_t j = 0; j < cn; ++j) s = __dadd_rn(s, wave_bcast_f64(one[0], j));
-                }
-            }
-        }
+        seq_span<0, 16>(cur, hi - g0 < 1024 ? (uint32_t)(hi - g0) : 1024u, a);
     }
-    return s;
 }
 
 // one wave: out[0] = the sequential sum of p[0..n); zeroes bsum for the slot's next use
 // (blockIdx.x = one of several independent sums laid out `stride` values / `nblocks` blocks apart)
 __global__ __launch_bounds__(64) void k_seq_chain(const double* p, u64 n, const SeqBlk* blk, uint32_t nblocks, double* bsum, double* out,
                                                   u64 stride, const SeqGrp* grp) {
-    __shared__ double stage[SQ_STAGE];
     const uint32_t lane = threadIdx.x;
     p += (u64)blockIdx.x * stride;
     blk += (size_t)blockIdx.x * nblocks;
     grp += (size_t)blockIdx.x * nblocks * (2 * SQ_GROUPS);
     bsum += (size_t)blockIdx.x * nblocks;
     out += blockIdx.x;
-    // the running sum is kept either as a double s, or — between accepted blocks of one binade — as the
-    // integer S = s / 2^(e-52) in [2^52, 2^53), so that an accepted block is one 64-bit add and a compare
-    double s = 0.0;
-    bool as_int = false;
-    int e = 0;
-    u64 S = 0;
+    SeqAcc a;
+    a.s = 0.0; a.S = 0; a.e = 0; a.as_int = false;
+    SeqBlk next;  // the block records come 64 at a time, one per lane; the next 64 are asked for a round ahead
+    next.e = 0; next.flags = 8u; next.Q = 0;
+    if (lane < nblocks) next = blk[lane];
     for (uint32_t c0 = 0; c0 < nblocks; c0 += 64) {
-        // 64 block records at a time, one per lane, handed round with scalar reads (no dependent loads in the chain)
-        SeqBlk mine;
-        mine.e = 0; mine.flags = 8u; mine.Q = 0;
-        if (c0 + lane < nblocks) mine = blk[c0 + lane];
+        const SeqBlk mine = next;
+        next.e = 0; next.flags = 8u; next.Q = 0;
+        if (c0 + 64u + lane < nblocks) next = blk[c0 + 64u + lane];
         const uint32_t cn = nblocks - c0 < 64u ? nblocks - c0 : 64u;
-        for (uint32_t j = 0; j < cn; ++j) {
-            const uint32_t kf = wave_bcast_u32(mine.flags, j);
-            if (kf & 16u) continue;  // all zeros
-            if (kf == 0u) {
-                const int ke = (int)wave_bcast_u32((uint32_t)mine.e, j);
-                const u64 kq = wave_bcast_u64(mine.Q, j);
-                if (!as_int && s > 0.0 && seq_exponent(s) == ke) {
-                    e = ke;
-                    S = (u64)(s * seq_pow2(52 - e));
-                    as_int = true;
+        // what a lane's block adds when it goes through as an integer total of the binade at hand (all-zero blocks: nothing)
+        const bool zero_blk = (mine.flags & 16u) != 0u;
+        const u64 add = zero_blk ? (u64)0 : mine.Q;
+        uint32_t j = 0;
+        while (j < cn) {
+            if (a.as_int) {
+                // Every block from j on that goes through — predicted for this binade, no flag, and the running sum
+                // still below 2^53 after it — at once: a prefix sum over the lanes and one ballot for the first that
+                // does not.
+                const bool mineok = lane >= cn || zero_blk || (mine.flags == 0u && mine.e == a.e && mine.Q < ((u64)1 << 53));
+                const u64 incl = fsk_hw::wave_incl_sum_u64((lane >= j && lane < cn && mineok) ? add : (u64)0);
+                const bool ok = lane < j || (mineok && a.S + incl < ((u64)1 << 53));
+                const u64 bad = __ballot(!ok);
+                uint32_t stop = bad ? (uint32_t)(__ffsll((long long)bad) - 1) : 64u;
+                if (stop > cn) stop = cn;
+                if (stop > j) {
+                    a.S += wave_bcast_u64(incl, stop - 1u);
+                    j = stop;
+                    continue;
                 }
-                if (as_int && e == ke && S + kq < ((u64)1 << 53)) {
-                    S += kq;
+            }
+            // block j on its own
+            const uint32_t kf = wave_bcast_u32(mine.flags, j);
+            if (kf & 16u) { ++j; continue; }  // all zeros
+            const int ke = (int)wave_bcast_u32((uint32_t)mine.e, j);
+            if (kf == 0u) {
+                const u64 kq = wave_bcast_u64(mine.Q, j);
+                if (!a.as_int && a.s > 0.0 && seq_exponent(a.s) == ke) seq_acc_to_int(a);
+                if (a.as_int && a.e == ke && a.S + kq < ((u64)1 << 53)) {
+                    a.S += kq;
+                    ++j;
                     continue;
                 }
             }
@@ -406,7 +442,6 @@ __global__ __launch_bounds__(64) void k_seq_chain(const double* p, u64 n, const 
             if (kf & 32u) {
                 // group records: the groups before and after the crossing / the tie go through as integer
                 // totals of their binade; only the group in between is redone
-                const int ke = (int)wave_bcast_u32((uint32_t)mine.e, j);
                 SeqGrp mg;
                 mg.Q = 0; mg.flags = 1u; mg.pad = 0u;
                 if (lane < 2u * SQ_GROUPS) mg = grp[(size_t)(c0 + j) * (2 * SQ_GROUPS) + lane];
@@ -414,38 +449,28 @@ __global__ __launch_bounds__(64) void k_seq_chain(const double* p, u64 n, const 
                     const u64 glo = lo + (u64)g * SQ_GROUP;
                     if (glo >= hi) break;
                     if (wave_bcast_u32(mg.flags, g) & 16u) continue;  // all zeros
-                    if (!as_int && s > 0.0 && seq_exponent(s) != INT32_MIN) {
-                        e = seq_exponent(s);
-                        S = (u64)(s * seq_pow2(52 - e));
-                        as_int = true;
-                    }
-                    if (as_int && (e == ke || e == ke + 1)) {
-                        const uint32_t r = (e == ke ? 0u : (uint32_t)SQ_GROUPS) + g;
+                    seq_acc_to_int(a);
+                    if (a.as_int && (a.e == ke || a.e == ke + 1)) {
+                        const uint32_t r = (a.e == ke ? 0u : (uint32_t)SQ_GROUPS) + g;
                         const u64 gq = wave_bcast_u64(mg.Q, r);
-                        if (wave_bcast_u32(mg.flags, r) == 0u && S + gq < ((u64)1 << 53)) {
-                            S += gq;
+                        if (wave_bcast_u32(mg.flags, r) == 0u && a.S + gq < ((u64)1 << 53)) {
+                            a.S += gq;
                             continue;
                         }
                     }
-                    if (as_int) {
-                        s = (double)S * seq_pow2(e - 52);
-                        as_int = false;
-                    }
                     const u64 ghi = glo + SQ_GROUP < hi ? glo + SQ_GROUP : hi;
-                    s = seq_range(p, glo, ghi, s, stage);
+                    seq_range(p, glo, ghi, a);
                 }
+                ++j;
                 continue;
             }
-            if (as_int) {
-                s = (double)S * seq_pow2(e - 52);
-                as_int = false;
-            }
-            s = seq_range(p, lo, hi, s, stage);
+            seq_range(p, lo, hi, a);
+            ++j;
         }
     }
-    if (as_int) s = (double)S * seq_pow2(e - 52);
+    seq_acc_to_double(a);
     if (lane == 0) {
-        out[0] = s;
+        out[0] = a.s;
         __threadfence_system();  // (`out` may be pinned host memory: the variance mode reads it after the stream's event)
     }
     for (uint32_t b = lane; b < nblocks; b += 64) bsum[b] = 0.0;

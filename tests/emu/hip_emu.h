@@ -326,6 +326,13 @@ static inline unsigned long long wave_sum_u64(unsigned long long x) {
     for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
     return x;
 }
+static inline unsigned long long wave_incl_sum_u64(unsigned long long x) {
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long y = __shfl_up(x, d);
+        if ((int)emu::lane_id() >= d) x += y;
+    }
+    return x;
+}
 static inline unsigned vgpr_copy(unsigned x) { return x; }
 // rows past `bytes` read as zero (the buffer descriptor's bounds check)
 static inline uint4 rows16(const unsigned* rows, unsigned bytes, unsigned byte_off) {
