@@ -382,6 +382,21 @@ def test_emu_relabelled_and_wide_alphabets(emu_lib, port):
     assert np.array_equal(e.get_triangle(), port.normalise(want.astype(np.float64), 20))
     assert e.stats()["path_used"] == 2 and e.stats()["key_space"] == 20 ** 14
     e.close()
+    # k = 6 over 20 symbols: 26 k-mer bits + 5 sequence bits still travel in 32-bit records, but the k-mer no longer fits
+    # the 24-bit multiply-add of the window extraction
+    X = [rng.integers(1, 21, size=int(L)) for L in rng.integers(9, 40, size=20)]
+    for x in X[:8]:
+        x[0:9] = X[11][0:9]
+    tok, off = _native.flatten(X)
+    combos = np.arange(0, port.num_combos(8, 2), 3, dtype=np.int32)
+    e = _native.Engine(8, 2, path=2, lib=emu_lib)
+    e.load_sequences(tok, off, 13, 7)
+    e.accumulate(combos)
+    e.finalize()
+    want, _, _ = port.raw_counts(tok, off, 8, 2, combos)
+    assert np.array_equal(e.get_counts(), want) and want[1] > 0
+    assert e.stats()["key_space"] == 20 ** 6
+    e.close()
     # g = 17 symbols of 8 bits pass the 128-bit window array: the records' symbols are gathered from the sequences
     X = [rng.integers(1, 21, size=int(L)) for L in rng.integers(18, 40, size=12)]
     for x in X[:5]:
