@@ -153,6 +153,7 @@ __device__ __forceinline__ unsigned fsk_mbcnt(unsigned lo, unsigned hi) {
 // the access becomes a flat_load (FSK_LDS_VOLATILE_U32: a 32-bit word re-read at every use, a counter other lanes
 // add to between two reads; as `volatile uint32_t*` it was flat_load_dword sc0 sc1 + s_waitcnt vmcnt(0)).
 #define FSK_LDS_LOAD_U8(ptr) (*(const __attribute__((address_space(3))) unsigned char*)(ptr))
+#define FSK_LDS_LOAD_U16(ptr) (*(const __attribute__((address_space(3))) unsigned short*)(ptr))
 #define FSK_LDS_LOAD_U32(ptr) (*(const __attribute__((address_space(3))) unsigned int*)(ptr))
 #define FSK_LDS_LOAD_U64(ptr) (*(const __attribute__((address_space(3))) unsigned long long*)(ptr))
 #define FSK_LDS_VOLATILE_U32(ptr) (*(volatile __attribute__((address_space(3))) unsigned int*)(ptr))

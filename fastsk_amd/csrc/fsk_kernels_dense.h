@@ -21,8 +21,9 @@ __device__ __forceinline__ void count_windows(const uint8_t* symT, uint32_t* his
                                               int k, uint32_t sigma, uint32_t j0, uint32_t hi, uint32_t cb, uint32_t nwin,
                                               uint32_t r, uint32_t half, uint32_t key_lo, uint32_t key_n, uint16_t* kcache,
                                               int kmode) {
-    if (K > 0 && !MARK && !LUT && kmode == 0) {
-        // The common case (every BASELINE config): WPT windows per trip. Window j+4 of a lane lies
+    if (K > 0 && kmode == 0) {
+        // The common case (every BASELINE config; with key compaction both of its passes — MARK sets the key's bit, LUT
+        // counts the key's rank — unless a window-key cache is in use): WPT windows per trip. Window j+4 of a lane lies
         // 4 rows = 256 bytes further in every symbol column, an immediate offset of the same
         // address registers, so the loop bookkeeping is paid once per WPT windows. Rows past a
         // sequence's end are zero padding inside symT (the trip condition keeps them in range);
@@ -46,7 +47,12 @@ __device__ __forceinline__ void count_windows(const uint8_t* symT, uint32_t* his
             }
 #pragma unroll
             for (int u = 0; u < WPT; ++u) {
-                const uint32_t key = kk[u] - key_lo;  // wraps for keys below the sweep: rejected by the compare
+                if (MARK) {
+                    if (j + 4u * u < nwin) atomicOr(&hist[kk[u] >> 5], 1u << (kk[u] & 31u));  // hist doubles as the key bitmap
+                    continue;
+                }
+                // (the table sits in LDS; a padding row's key is 0, inside it)
+                const uint32_t key = (LUT ? (uint32_t)FSK_LDS_LOAD_U16(lut + kk[u]) : kk[u]) - key_lo;  // wraps for keys below the sweep: rejected by the compare
                 if (j + 4u * u < nwin && key < key_n) atomicAdd(&hist[key * 32u + (r >> 1)], 1u << half);
             }
         }
@@ -57,6 +63,11 @@ __device__ __forceinline__ void count_windows(const uint8_t* symT, uint32_t* his
                 k0 = mad24(k0, sigma, FSK_LDS_LOAD_U8(symT + p[c]));
                 p[c] += 4 * PANEL;
             }
+            if (MARK) {
+                if (j < nwin) atomicOr(&hist[k0 >> 5], 1u << (k0 & 31u));
+                continue;
+            }
+            if (LUT) k0 = (uint32_t)FSK_LDS_LOAD_U16(lut + k0);
             k0 -= key_lo;
             if (j < nwin && k0 < key_n) atomicAdd(&hist[k0 * 32u + (r >> 1)], 1u << half);
         }

@@ -358,6 +358,7 @@ static inline unsigned fsk_mbcnt(unsigned lo, unsigned hi) {
     return (unsigned)__builtin_popcountll(m & ((1ull << emu::lane_id()) - 1ull));
 }
 #define FSK_LDS_LOAD_U8(ptr) (*reinterpret_cast<const unsigned char*>(ptr))
+#define FSK_LDS_LOAD_U16(ptr) (*reinterpret_cast<const unsigned short*>(ptr))
 #define FSK_LDS_LOAD_U32(ptr) (*reinterpret_cast<const unsigned int*>(ptr))
 #define FSK_LDS_LOAD_U64(ptr) (*reinterpret_cast<const unsigned long long*>(ptr))
 #define FSK_LDS_VOLATILE_U32(ptr) (*reinterpret_cast<volatile unsigned int*>(ptr))
