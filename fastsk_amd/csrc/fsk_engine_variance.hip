@@ -222,6 +222,8 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
         FSK_HIP(hipMemsetAsync(khat(cur), 0, (size_t)pairs * sizeof(double), e->stream));
         int iter = 1, item = tid;
         std::vector<Batch> q;  // issued, untested batches, oldest first (at most INFLIGHT)
+        std::vector<int> dropped;        // sets of buffers of the batches issued beyond the stop
+        hipStream_t fin = e->stream;     // the stream the chain's last passes run on
         {
             Batch A;
             A.first_iter = iter; A.first_item = item; A.base = cur; A.part = 0;
@@ -281,16 +283,20 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
             e->st.combos_done -= A.n - accepted;  // iterations run ahead of the stop are dropped
             q.erase(q.begin());
             if (!working) {
-                for (const Batch& B : q) e->st.combos_done -= B.n;
-                if (!q.empty()) sync_all();  // dropped batches drain before their buffers are reused
-                for (const Batch& B : q) (void)sx_harvest(e, B.part);
+                // What was issued beyond the stop is dropped — but not waited for here: the chain's result needs A's
+                // buffers and the K_hat ring only (a dropped batch reads the state after A and writes the one after
+                // itself), so the last passes run on A's own, idle stream beside the dropped kernels' tail; everything
+                // drains, and the dropped batches' counts are read, before the chain's buffers are used again (below).
+                for (const Batch& B : q) { e->st.combos_done -= B.n; dropped.push_back(B.part); }
+                const int lane_a = (A.grouped && !dense_slots) ? sx_lane_of(e, A.part) : 0;
+                fin = lane_a ? e->lane_stream : e->stream;
                 if (A.grouped && accepted < A.n) {  // the stop fell inside the batch: the state after its accepted prefix
                     if (dense_slots)
-                        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<u64>), dim3(wblocks), dim3(256), 0, e->stream, (const u64*)slots64_of(A.part),
+                        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<u64>), dim3(wblocks), dim3(256), 0, fin, (const u64*)slots64_of(A.part),
                                    accepted, (const double*)khat(A.base), khat(A.base + accepted), (double*)nullptr, (u64)0, (u64)pairs,
                                    (u64)train_pairs, (double)A.first_iter, (double*)nullptr, (uint32_t)0, 0);
                     else
-                        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<uint32_t>), dim3(wblocks), dim3(256), 0, e->stream,
+                        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<uint32_t>), dim3(wblocks), dim3(256), 0, fin,
                                    (const uint32_t*)slots_of(A.part), accepted, (const double*)khat(A.base), khat(A.base + accepted),
                                    (double*)nullptr, (u64)0, (u64)pairs, (u64)train_pairs, (double)A.first_iter, (double*)nullptr, (uint32_t)0, 0);
                 }
@@ -298,10 +304,11 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
             }
             // (working implies more items and iterations: the queue is not empty)
         }
-        // (the chain's last state may have been written in lane 1; the next chain starts over on the engine's stream)
-        if (e->lane_stream) FSK_HIP(hipStreamSynchronize(e->lane_stream));
+        // (the chain's last state was written on `fin`, or by a batch whose sums have been waited for)
+        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_add_nonzero<double>), dim3(blocks), dim3(256), 0, fin, e->d_Kf64.p, (const double*)khat(cur), (u64)pairs);
+        sync_all();  // the next chain starts over on the engine's stream, with every buffer of this one free
+        for (int part : dropped) (void)sx_harvest(e, part);
         for (bool& w : wf_set) w = false;
-        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_add_nonzero<double>), dim3(blocks), dim3(256), 0, e->stream, e->d_Kf64.p, (const double*)khat(cur), (u64)pairs);
     }
     e->result_f64 = true;
     FSK_HIP(hipStreamSynchronize(e->stream));
