@@ -323,11 +323,12 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
 
 int ensure_featseq(fsk_engine* e) {
     if (e->featseq_ready) return FSK_OK;
-    std::vector<uint32_t> fs((size_t)e->nfeat);
-    for (int64_t i = 0; i < e->N; ++i)
-        for (uint32_t f = e->h_fstart[i]; f < e->h_fstart[i + 1]; ++f) fs[f] = (uint32_t)i;
-    FSK_HIP(e->d_featseq.reserve((size_t)e->nfeat));
-    FSK_HIP(hipMemcpy(e->d_featseq.p, fs.data(), fs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // (on the device, from the window offsets that are there already: a host loop over the features and its upload
+    // were 0.2 ms of idle stream at the head of every first call)
+    FSK_HIP(e->d_featseq.reserve((size_t)std::max<int64_t>(1, e->nfeat)));
+    if (e->N > 0)
+        FSK_LAUNCH(fsk::k_sx_featseq, dim3((uint32_t)((e->N + 3) / 4)), dim3(256), 0, e->stream, (const uint32_t*)e->d_fstart.p, (uint32_t)e->N,
+                   e->d_featseq.p);
     // the g-mer windows, packed once: every record of every slot is then one 8- or 16-byte load (k_sx_extract_win)
     const int wbits = e->cfg.g * e->bits;
     e->win_words = wbits <= 64 ? 2 : wbits <= 128 ? 4 : 0;
@@ -340,8 +341,8 @@ int ensure_featseq(fsk_engine* e) {
         else
             FSK_LAUNCH(fsk::k_sx_windows<4>, grid, dim3(256), 0, e->stream, e->view(), (const uint32_t*)e->d_featseq.p,
                        (const uint32_t*)e->d_fstart.p, (uint32_t)e->nfeat, e->cfg.g, e->d_win.p);
-        FSK_HIP(hipStreamSynchronize(e->stream));  // (every lane's kernels read it)
     }
+    FSK_HIP(hipStreamSynchronize(e->stream));  // (every lane's kernels read both arrays)
     e->featseq_ready = true;
     return FSK_OK;
 }
