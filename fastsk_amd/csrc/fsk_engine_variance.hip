@@ -36,6 +36,8 @@ int enqueue_sequential_sum(fsk_engine* e, const double* d_vals, u64 n, double* b
 // chains tid = chain_first, chain_first + chain_step, ... < T (all of them: 0, 1); stdevs are chain 0's
 int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     { int rcz = materialise_zero(e); if (rcz) return rcz; }
+    // (a previous call may have left the sequential sums of a batch beyond its stop running: see the end of this function)
+    if (e->chain_stream) FSK_HIP(hipStreamSynchronize(e->chain_stream));
     const int64_t pairs = e->pairs;
     const int64_t train_pairs = (int64_t)((e->n_train / (double)2) * (e->n_train + 1));
     const size_t tp = (size_t)std::max<int64_t>(1, train_pairs);
@@ -93,10 +95,11 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     };
     struct Cleanup {
         hipEvent_t* a; hipEvent_t* b; hipEvent_t* c; fsk_engine* e;
+        bool leave_sums = false;  // (a regular end: only a dropped batch's sequential sums may still run, see below)
         ~Cleanup() {
             (void)hipStreamSynchronize(e->stream);  // nothing of this call may still be in flight
             if (e->lane_stream) (void)hipStreamSynchronize(e->lane_stream);
-            (void)hipStreamSynchronize(e->chain_stream);
+            if (!leave_sums) (void)hipStreamSynchronize(e->chain_stream);
             for (int i = 0; i < MAX_DEPTH; ++i) { (void)hipEventDestroy(a[i]); (void)hipEventDestroy(b[i]); (void)hipEventDestroy(c[i]); }
         }
     } cleanup{ev_done, ev_hand, ev_wf, e};
@@ -306,12 +309,22 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
         }
         // (the chain's last state was written on `fin`, or by a batch whose sums have been waited for)
         FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_add_nonzero<double>), dim3(blocks), dim3(256), 0, fin, e->d_Kf64.p, (const double*)khat(cur), (u64)pairs);
-        sync_all();  // the next chain starts over on the engine's stream, with every buffer of this one free
+        // Everything drains before the next chain starts over with these buffers. After the LAST chain the sequential
+        // sums of a batch beyond the stop (one wave per iteration, 200 us, nobody reads them) are left to finish on their
+        // own stream: they touch the sums' buffers only, which the next variance-mode call, and fsk_destroy, wait for.
+        const bool last_chain = tid + chain_step >= T;
+        if (last_chain) {
+            FSK_HIP(hipStreamSynchronize(e->stream));
+            if (e->lane_stream) FSK_HIP(hipStreamSynchronize(e->lane_stream));
+        } else {
+            sync_all();
+        }
         for (int part : dropped) (void)sx_harvest(e, part);
         for (bool& w : wf_set) w = false;
     }
     e->result_f64 = true;
     FSK_HIP(hipStreamSynchronize(e->stream));
+    cleanup.leave_sums = true;
     if (trace)
         fprintf(stderr, "[fsk] variance mode: setup %.2f ms, waiting for the GPU %.2f ms, total %.2f ms (%lld cells/iteration, %d batches in flight)\n",
                 t_alloc, t_wait, ms_since(t_begin), (long long)train_pairs, INFLIGHT);
