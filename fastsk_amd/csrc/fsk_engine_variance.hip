@@ -51,6 +51,8 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     // (Tried as well: deciding "no stop in this batch" from the approximate block sums, a safe margin below 1.96, so
     // that the next issue does not wait for the oldest batch's exact sums — the lanes then run in lockstep and the
     // GPU's throughput bounds the batch rate just the same: 6.2 -> 6.3 ms on config 1.)
+    // (batches of 8 iterations: 4 / 6 / 8 give 7.5 / 6.55 / 5.75 ms on config 1 — the two dozen launches of a batch are
+    // paid per batch —; 16 (k_welford_batch carrying sixteen slots) is slower again, 6.7 ms)
     // (two batches in flight, one per lane. Measured with three and four — the issue of a batch waits for the sums
     // of the oldest one in flight, a latency a third batch would cover —: config 1 6.4 -> 6.8 -> 7.4 ms; the GPU is
     // busy as it is, and what the extra batches add are iterations beyond the stop.)
