@@ -52,7 +52,8 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     // that the next issue does not wait for the oldest batch's exact sums — the lanes then run in lockstep and the
     // GPU's throughput bounds the batch rate just the same: 6.2 -> 6.3 ms on config 1.)
     // (batches of 8 iterations: 4 / 6 / 8 give 7.5 / 6.55 / 5.75 ms on config 1 — the two dozen launches of a batch are
-    // paid per batch —; 16 (k_welford_batch carrying sixteen slots) is slower again, 6.7 ms)
+    // paid per batch —; 10 / 12 / 16, as two Welford passes of up to 8 over one sparse batch: 6.3 / 5.9 / 6.0 ms there, and
+    // 18.2 against 18.6 ms on the 210 iterations of the reference's CI configuration: not worth twice the buffers)
     // (two batches in flight, one per lane. Measured with three and four — the issue of a batch waits for the sums
     // of the oldest one in flight, a latency a third batch would cover —: config 1 6.4 -> 6.8 -> 7.4 ms; the GPU is
     // busy as it is, and what the extra batches add are iterations beyond the stop.)
@@ -124,10 +125,17 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     constexpr int HEDGE = 2;  // iterations issued ahead once the stop is expected to have fired already
     // how many iterations can still follow (end of the work list, max_iters)
     auto plan = [&](int first_iter, int first_item) {
-        int n = AHEAD;
+        // (sparse batches: the first of a set of sequences is sized for what is known to fit, later ones by the update
+        // words per record seen — a batch beyond the stream limit would fall back to one iteration at a time for good)
+        int most = AHEAD;
+        if (e->path == FSK_PATH_SPARSE) {
+            if (e->sx_wpr == 0) most = std::min(most, (int)fsk::WF_SLOTS);
+            else most = std::max(1, std::min(most, (int)((double)(e->sx_max_words / 2) / (e->sx_wpr * (double)std::max<int64_t>(1, e->nfeat)))));
+        }
+        int n = most;
         if (pred_stop != INT32_MAX) {
             const int64_t left = (int64_t)pred_stop + 1 - first_iter;  // (one to spare)
-            n = left >= AHEAD ? AHEAD : left > 0 ? (int)left : HEDGE;
+            n = left >= most ? most : left > 0 ? (int)left : HEDGE;
         }
         n = std::min(n, first_item < n_order ? (n_order - first_item + T - 1) / T : 0);
         if (e->cfg.max_iters != -1) n = std::min(n, e->cfg.max_iters - first_iter + 1);
@@ -157,7 +165,26 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     if (dense_slots) FSK_HIP(e->d_Kslots.reserve((size_t)pairs * AHEAD * DEPTH));
     auto slots_of = [&](int part) { return reinterpret_cast<uint32_t*>(e->d_Kslots.p) + (size_t)part * AHEAD * (size_t)pairs; };
     auto slots64_of = [&](int part) { return e->d_Kslots.p + (size_t)part * AHEAD * (size_t)pairs; };
-    static_assert(AHEAD <= fsk::WF_SLOTS, "k_welford_batch carries a batch's iterations in registers");
+    // The Welford pass of a batch: k_welford_batch carries up to WF_SLOTS iterations in registers, a larger batch takes
+    // several passes (each leaves the state after its last iteration in the ring). `first` .. `first + count`: the
+    // batch's slots to fold, from the state after slot first - 1; with_sums = 0: states only (a stop inside the batch).
+    auto welford_passes = [&](const Batch& B, bool u64_slots, int first, int count, int with_sums, hipStream_t st) -> int {
+        for (int c = first; c < first + count; c += fsk::WF_SLOTS) {
+            const int nc = std::min((int)fsk::WF_SLOTS, first + count - c);
+            const size_t slot = (size_t)B.part * AHEAD + c;
+            if (u64_slots)
+                FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<u64>), dim3(wblocks), dim3(256), 0, st, (const u64*)slots64_of(B.part) + (size_t)c * pairs,
+                           nc, (const double*)khat(B.base + c), khat(B.base + c + nc), with_sums ? e->d_prod.p + slot * tp : (double*)nullptr,
+                           (u64)tp, (u64)pairs, (u64)train_pairs, (double)(B.first_iter + c), with_sums ? e->d_bsum.p + slot * nblk : (double*)nullptr,
+                           (uint32_t)nblk, with_sums);
+            else
+                FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<uint32_t>), dim3(wblocks), dim3(256), 0, st,
+                           (const uint32_t*)slots_of(B.part) + (size_t)c * pairs, nc, (const double*)khat(B.base + c), khat(B.base + c + nc),
+                           with_sums ? e->d_prod.p + slot * tp : (double*)nullptr, (u64)tp, (u64)pairs, (u64)train_pairs,
+                           (double)(B.first_iter + c), with_sums ? e->d_bsum.p + slot * nblk : (double*)nullptr, (uint32_t)nblk, with_sums);
+        }
+        return FSK_OK;
+    };
     // (Tried: the Welford pass INSIDE the by-slot pass over the update streams — one workgroup per owner band goes
     // through the batch's slots in order, K_hat in registers, no slot triangles written and read back (2 x 204 MB
     // of a config-1 batch's 1.3 GB). The slots then come one after the other inside a workgroup, a few tens of words
@@ -179,11 +206,9 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
         if (was_grouped && !grouped) sync_all();  // (leaving the two-lane form: everything drains first, once)
         for (int l = 0; l < LANES; ++l)  // K_hat comes from the previous batch's Welford pass, wherever that ran
             if (l != lane && wf_set[l]) FSK_HIP(hipStreamWaitEvent(bs, ev_wf[l], 0));
-        if (grouped) {  // K_hat through the batch's iterations in one pass; only the state after the batch is written
-            const size_t slot0 = (size_t)B.part * AHEAD;
-            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<uint32_t>), dim3(wblocks), dim3(256), 0, bs, (const uint32_t*)slots_of(B.part), B.n,
-                       (const double*)khat(B.base), khat(B.base + B.n), e->d_prod.p + slot0 * tp, (u64)tp, (u64)pairs, (u64)train_pairs,
-                       (double)B.first_iter, e->d_bsum.p + slot0 * nblk, (uint32_t)nblk, 1);
+        if (grouped) {  // K_hat through the batch's iterations, WF_SLOTS per pass
+            int rc = welford_passes(B, false, 0, B.n, 1, bs);
+            if (rc) return rc;
         } else if (dense_slots) {
             for (int b = 0; b < B.n; ++b) {
                 int32_t combo = e->order[B.first_item + b * T];
@@ -192,10 +217,8 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
                 e->store_next = false;
                 if (rc) return rc;
             }
-            const size_t slot0 = (size_t)B.part * AHEAD;
-            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<u64>), dim3(wblocks), dim3(256), 0, e->stream, (const u64*)slots64_of(B.part), B.n,
-                       (const double*)khat(B.base), khat(B.base + B.n), e->d_prod.p + slot0 * tp, (u64)tp, (u64)pairs, (u64)train_pairs,
-                       (double)B.first_iter, e->d_bsum.p + slot0 * nblk, (uint32_t)nblk, 1);
+            int rc = welford_passes(B, true, 0, B.n, 1, e->stream);
+            if (rc) return rc;
         }
         for (int b = 0; b < B.n && !B.grouped; ++b) {
             const size_t slot = (size_t)(B.part * AHEAD + b);
@@ -295,15 +318,12 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
                 for (const Batch& B : q) { e->st.combos_done -= B.n; dropped.push_back(B.part); }
                 const int lane_a = (A.grouped && !dense_slots) ? sx_lane_of(e, A.part) : 0;
                 fin = lane_a ? e->lane_stream : e->stream;
-                if (A.grouped && accepted < A.n) {  // the stop fell inside the batch: the state after its accepted prefix
-                    if (dense_slots)
-                        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<u64>), dim3(wblocks), dim3(256), 0, fin, (const u64*)slots64_of(A.part),
-                                   accepted, (const double*)khat(A.base), khat(A.base + accepted), (double*)nullptr, (u64)0, (u64)pairs,
-                                   (u64)train_pairs, (double)A.first_iter, (double*)nullptr, (uint32_t)0, 0);
-                    else
-                        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<uint32_t>), dim3(wblocks), dim3(256), 0, fin,
-                                   (const uint32_t*)slots_of(A.part), accepted, (const double*)khat(A.base), khat(A.base + accepted),
-                                   (double*)nullptr, (u64)0, (u64)pairs, (u64)train_pairs, (double)A.first_iter, (double*)nullptr, (uint32_t)0, 0);
+                // the stop fell inside the batch: the state after its accepted prefix (the passes before the one the stop
+                // fell in have left theirs in the ring)
+                const int done = accepted / (int)fsk::WF_SLOTS * (int)fsk::WF_SLOTS;
+                if (A.grouped && accepted < A.n && accepted > done) {
+                    int rc = welford_passes(A, dense_slots, done, accepted - done, 0, fin);
+                    if (rc) return rc;
                 }
                 break;
             }
