@@ -11,9 +11,9 @@ namespace fsk_detail {
 
 // ---------------------------------------------------------------------------------------------
 // sparse dataflow: owner bands of K. The update stream of a band is summed in LDS by one workgroup,
-// so a band is a range of whole rows with about 8192 cells (the LDS budget of k_sx_consume bounds
-// it: SX_CAP cells per round, at most SX_MAX_ROUNDS rounds over the band's stream).
-constexpr uint32_t SX_CAP = 16384;        // u32 cells of K one k_sx_consume workgroup holds in LDS (64 KiB)
+// so a band is a range of whole rows with 8192 or 16384 cells + up to a row (the LDS budget of k_sx_consume
+// bounds it: SX_CAP cells per round, at most SX_MAX_ROUNDS rounds over the band's stream).
+constexpr uint32_t SX_CAP = 19456;        // u32 cells of K one k_sx_consume workgroup holds in LDS (76 KiB + the parts table: two workgroups per CU)
 constexpr uint32_t SX_MAX_ROUNDS = 16;
 constexpr uint32_t SX_CAP_SLOT = 20480;   // by-slot form (no parts table in LDS): 80 KiB, two workgroups per CU
 
@@ -22,7 +22,11 @@ void plan_owner_bands(fsk_engine* e) {
     // of its triangular index, bands hold about 2^t cells (2^t + N at most: the last row of a band is
     // kept whole) and can be empty when a single row is longer than 2^t cells.
     const u64 N = (u64)e->N, cells = N * (N + 1) / 2;
+    // (as large as ONE round of k_sx_consume takes: with half the bands k_sx_emit bins, scans and offsets half as much per
+    // tile and the per-(tile, band) word counts are half the matrix — config 4, N = 2560: 400 -> 200 bands, emit 3.75 ->
+    // 3.57 ms, the column scans 0.37 -> 0.26, consume 1.04 -> 1.13)
     int t = 13;
+    while (t < 20 && ((u64)1 << (t + 1)) + N <= (u64)SX_CAP) ++t;
     while ((((cells + (((u64)1) << t) - 1) >> t)) > (u64)fsk::SX_MAX_OWNERS) ++t;
     e->sx_own_shift = t;
     e->n_owners = (uint32_t)((cells + (((u64)1) << t) - 1) >> t);
