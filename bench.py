@@ -38,7 +38,7 @@ One JSON line on rank 0. Extra objects:
   cpu_baseline  FastSK's own multithreaded engine (oracle/_ref, kind "reference"; our C restatement
                 as "port" when the compiled reference did not travel) on the host cores at
                 N = 4000 and 8000 of the same generator, T = physical cores and T = 20; rank 0, N=1 only.
-  end_to_end    load (pack + H2D) + one step + a normalised 4k x 4k block: SURVEY 8(d)'s metric boundary.
+  end_to_end    load (pack + H2D) + one step + the WHOLE normalised triangle on the device: SURVEY 8(d)'s metric boundary.
 """
 import argparse
 import hashlib
@@ -689,22 +689,51 @@ def main():
                 # milliseconds of kernels: its latency, not the links' bandwidth, is what a step pays
                 "latency_bound": bool(not dense or payload < (64 << 20))}
 
-    # ---- SURVEY 8(d)'s metric boundary: load + one step + a normalised block (single GPU only)
+    # ---- SURVEY 8(d)'s metric boundary, literally: H2D of the packed sequences + every combo + normalise, the
+    # whole triangle (fastsk_kernel.cpp:96-103 over all N(N+1)/2 cells, device resident) when a second
+    # triangle of doubles fits beside the integer one, else a 4096 x 4096 block (single GPU only)
     end_to_end = None
     if world == 1 and not use_dist:
         nblk = min(4096, N)
+        free, _ = torch.cuda.mem_get_info()
+        whole = free > pairs * 8 + (8 << 30)
+        tri = torch.empty(pairs, dtype=torch.float64, device="cuda") if whole else None
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         eng.load_sequences(tokens, offsets, N, 0)
         eng.accumulate(every)
         eng.finalize()
-        blk = eng.get_block_torch(0, nblk, 0, nblk)
+        t1 = time.perf_counter()
+        if whole:
+            eng.get_triangle_torch(tri)   # fsk_get_triangle_device: returns when the triangle is written
+        else:
+            blk = eng.get_block_torch(0, nblk, 0, nblk)
         torch.cuda.synchronize()
         t_e2e = time.perf_counter() - t0
-        assert bool((blk.diagonal() == 1.0).all())
-        end_to_end = {"seconds": t_e2e, "combos_per_s": ncomb / t_e2e,
+        t_norm = time.perf_counter() - t1
+        if whole:
+            rr = torch.arange(N, device="cuda", dtype=torch.int64)
+            assert bool((tri[rr * (rr + 1) // 2 + rr] == 1.0).all()), "a normalised diagonal is not 1.0"
+            blk = eng.get_block_torch(0, nblk, 0, nblk)   # and a block of it against the block getter
+            ii = torch.arange(nblk, device="cuda", dtype=torch.int64)
+            low = torch.tril(torch.ones(nblk, nblk, dtype=torch.bool, device="cuda"))
+            cells = (ii[:, None] * (ii[:, None] + 1) // 2 + ii[None, :])[low]
+            assert bool(torch.equal(tri[cells], blk[low])), "normalised triangle and block getter disagree"
+            del tri
+        else:
+            assert bool((blk.diagonal() == 1.0).all())
+        end_to_end = {"seconds": t_e2e, "combos_per_s": ncomb / t_e2e, "normalise_ms": 1e3 * t_norm,
+                      "normalise_cells": pairs if whole else nblk * nblk,
+                      "normalise_GBs": (16.0 * pairs / t_norm / 1e9) if whole else None,
                       "includes": "fsk_load_sequences (alphabet scan, bit-packing, H2D of the packed sequences, zeroing K) + "
-                                  "all %d combos + fsk_finalize + normalised %d x %d train block on the device" % (ncomb, nblk, nblk)}
+                                  "all %d combos + fsk_finalize + %s" % (
+                                      ncomb, "the WHOLE normalised triangle, %d cells of float64 written on the device "
+                                      "(fsk_get_triangle_device; 16 bytes of HBM per cell)" % pairs if whole
+                                      else "a normalised %d x %d train block on the device (no room for a second triangle)" % (nblk, nblk)),
+                      "value_excludes": "`value` times the combos with the packed sequences resident in HBM: it excludes "
+                                        "fsk_load_sequences (pack + H2D, load_seconds_untimed) and the normalisation "
+                                        "(normalise_ms); end_to_end.combos_per_s includes both"}
+        torch.cuda.empty_cache()
 
     out = None
     if rank == 0:

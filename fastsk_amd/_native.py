@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfastsk_amd.so")
 
 PATH_AUTO, PATH_DENSE, PATH_SPARSE = 0, 1, 2
 COLL_AUTO, COLL_RCCL, COLL_P2P = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ERRORS = {-1: "FSK_EINVAL", -2: "FSK_ESHORT", -3: "FSK_ESTATE", -4: "FSK_EDEVICE", -5: "FSK_ENOMEM",
           -6: "FSK_EUNSUPPORTED"}
@@ -72,7 +72,8 @@ SYMBOLS = ["fsk_create", "fsk_destroy", "fsk_last_error", "fsk_abi_version", "fs
            "fsk_get_counts_block", "fsk_get_counts_cells", "fsk_get_stdevs", "fsk_save_kernel", "fsk_get_stats", "fsk_num_combos",
            "fsk_combo_positions", "fsk_stream_wait_engine", "fsk_engine_wait_stream", "fsk_read_fasta", "fsk_sequential_sum",
            "fsk_run_chains", "fsk_get_kernel_sum_device", "fsk_set_kernel_sum_device", "fsk_create_multi", "fsk_get_multi_info",
-           "fsk_counts_digest", "fsk_alloc_block_device", "fsk_free_device", "fsk_set_skip_test_block"]
+           "fsk_counts_digest", "fsk_alloc_block_device", "fsk_free_device", "fsk_set_skip_test_block",
+           "fsk_get_triangle_device", "fsk_alloc_triangle_device"]
 
 
 _hip_shared = False
@@ -198,6 +199,8 @@ class Library:
             "fsk_alloc_block_device": ([vp, i64, i64, i64, i64, C.POINTER(vp)], C.c_int),
             "fsk_free_device": ([vp, vp], C.c_int),
             "fsk_set_skip_test_block": ([vp, i32], C.c_int),
+            "fsk_get_triangle_device": ([vp, vp], C.c_int),
+            "fsk_alloc_triangle_device": ([vp, C.POINTER(vp)], C.c_int),
         }
         for name, (argtypes, restype) in sig.items():
             fn = getattr(L, name)
@@ -384,6 +387,16 @@ class Engine:
     def get_triangle(self):
         out = np.empty(self.pairs, dtype=np.float64)
         self._ck(self.lib.L.fsk_get_triangle(self.h, out.ctypes.data))
+        return out
+
+    def get_triangle_torch(self, out=None):
+        """The whole normalised triangle as a float64 torch tensor ON THE GPU (pairs doubles, the reference's K)."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        if out is None:
+            out = torch.empty(self.pairs, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)
+        self._ck(self.lib.L.fsk_get_triangle_device(self.h, C.c_void_p(out.data_ptr())))
         return out
 
     def get_counts(self):

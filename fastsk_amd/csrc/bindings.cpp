@@ -11,7 +11,10 @@
 //     DLPack getters. devices=[0,1,...]: one engine per listed GPU behind the same object (fsk_create_multi) —
 //     the reference parallelises the same call over t host threads (fastsk_kernel.cpp:54-93).
 //   - the test x test block, which no getter of the reference exposes (fastsk.cpp:190-217), is not computed
-//     until something asks for it (get_block over test x test cells, get_counts_np, save_kernel).
+//     until something asks for it (get_block over test x test cells, get_counts_np, counts_digest over test rows,
+//     get_triangle_dlpack, save_kernel): that first request runs the whole compute once more with nothing left
+//     out (about twice the time of compute_kernel in total; the object keeps a copy of the tokens until then).
+//     skip_test_block=False computes everything in compute_kernel, as the reference does.
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -121,17 +124,13 @@ class FastSK {
         kept_tokens_.clear(); kept_tokens_.shrink_to_fit();
         kept_offsets_.clear();
     }
-    py::capsule dlpack_block(int64_t i0, int64_t i1, int64_t j0, int64_t j1) {
-        if (!computed_) throw std::runtime_error("call compute_kernel or compute_train first");
-        if (i1 < i0 || j1 < j0) throw py::value_error("empty block");
-        if (i1 > n_train_ && j1 > n_train_) need_test_block();
-        double* dev = nullptr;
-        check(fsk_alloc_block_device(h_, i0, i1, j0, j1, &dev));
-        auto* owner = new BlockOwner{{i1 - i0, j1 - j0}};
+    // device memory of the engine's first GPU (released with fsk_free_device) as a DLPack capsule of float64
+    py::capsule dlpack_of(double* dev, int ndim, int64_t d0, int64_t d1) {
+        auto* owner = new BlockOwner{{d0, d1}};
         auto* mt = new DLManagedTensor{};
         mt->dl_tensor.data = dev;
         mt->dl_tensor.device = DLDevice{kDLROCM, device0_};
-        mt->dl_tensor.ndim = 2;
+        mt->dl_tensor.ndim = ndim;
         mt->dl_tensor.dtype = DLDataType{kDLFloat, 64, 1};
         mt->dl_tensor.shape = owner->shape;
         mt->dl_tensor.strides = nullptr;  // compact row-major
@@ -148,6 +147,14 @@ class FastSK {
                 if (t && t->deleter) t->deleter(t);
             }
         });
+    }
+    py::capsule dlpack_block(int64_t i0, int64_t i1, int64_t j0, int64_t j1) {
+        if (!computed_) throw std::runtime_error("call compute_kernel or compute_train first");
+        if (i1 < i0 || j1 < j0) throw py::value_error("empty block");
+        if (i1 > n_train_ && j1 > n_train_) need_test_block();
+        double* dev = nullptr;
+        check(fsk_alloc_block_device(h_, i0, i1, j0, j1, &dev));
+        return dlpack_of(dev, 2, i1 - i0, j1 - j0);
     }
     py::array_t<double> block(bool test) const {
         if (!computed_) throw std::runtime_error("call compute_kernel or compute_train first");
@@ -261,7 +268,12 @@ public:
     py::capsule get_train_kernel_dlpack() { return dlpack_block(0, n_train_, 0, n_train_); }
     py::capsule get_test_kernel_dlpack() { return dlpack_block(n_train_, n_train_ + n_test_, 0, n_train_); }
     py::capsule get_block_dlpack(int64_t i0, int64_t i1, int64_t j0, int64_t j1) { return dlpack_block(i0, i1, j0, j1); }
-    void set_combo_order(std::vector<int32_t> order) { check(fsk_set_combo_order(h_, order.data(), (int32_t)order.size())); }
+    void set_combo_order(std::vector<int32_t> order) {
+        // a result whose test x test block is still to come belongs to the OLD order: complete it first, so that
+        // every block of one compute_kernel call comes from one set of combos
+        need_test_block();
+        check(fsk_set_combo_order(h_, order.data(), (int32_t)order.size()));
+    }
     py::array_t<double> get_block(int64_t i0, int64_t i1, int64_t j0, int64_t j1) {
         if (i1 < i0 || j1 < j0) throw py::value_error("empty block");
         if (i1 > n_train_ && j1 > n_train_) need_test_block();
@@ -276,6 +288,50 @@ public:
         py::array_t<uint64_t> out((py::ssize_t)(N * (N + 1) / 2));
         check(fsk_get_counts(h_, out.mutable_data()));
         return out;
+    }
+    // ---- additive: the raw integer kernel without copying the triangle out (exact and skip-variance modes).
+    // The reference has no such getter (its K is normalised in place, fastsk_kernel.cpp:96-103); these are what a
+    // caller uses to check a 100k-sequence result, whose triangle is 40 GB.
+    // (sum, xor of cell * (index | 1)) mod 2^64 over the integer cells of rows [row_begin, row_end): fsk_counts_digest
+    py::tuple counts_digest(int64_t row_begin, int64_t row_end) {
+        if (!computed_) throw std::runtime_error("call compute_kernel or compute_train first");
+        const int64_t N = n_train_ + n_test_;
+        if (row_end < 0) row_end = N;
+        if (row_end > n_train_ + 1) need_test_block();  // (row n_train holds one test x test cell, its diagonal, always computed)
+        uint64_t d[2] = {0, 0};
+        check(fsk_counts_digest(h_, row_begin, row_end, d));
+        return py::make_tuple(py::int_(d[0]), py::int_(d[1]));
+    }
+    py::array_t<uint64_t> get_counts_block(int64_t i0, int64_t i1, int64_t j0, int64_t j1) {
+        if (!computed_) throw std::runtime_error("call compute_kernel or compute_train first");
+        if (i1 < i0 || j1 < j0) throw py::value_error("empty block");
+        if (i1 > n_train_ && j1 > n_train_) need_test_block();
+        py::array_t<uint64_t> out({(py::ssize_t)(i1 - i0), (py::ssize_t)(j1 - j0)});
+        check(fsk_get_counts_block(h_, i0, i1, j0, j1, out.mutable_data()));
+        return out;
+    }
+    // scattered cells (rows[q], cols[q]) of the symmetric integer matrix: tri_access of arbitrary pairs, shared.cpp:97-117
+    py::array_t<uint64_t> get_counts_cells(py::array_t<int64_t, py::array::c_style | py::array::forcecast> rows,
+                                           py::array_t<int64_t, py::array::c_style | py::array::forcecast> cols) {
+        if (!computed_) throw std::runtime_error("call compute_kernel or compute_train first");
+        if (rows.ndim() != 1 || cols.ndim() != 1 || rows.shape(0) != cols.shape(0)) throw py::value_error("rows and cols must be 1-D and of equal length");
+        const int64_t n = (int64_t)rows.shape(0);
+        if (test_block_missing_)
+            for (int64_t q = 0; q < n; ++q)
+                if (rows.data()[q] >= n_train_ && cols.data()[q] >= n_train_ && rows.data()[q] != cols.data()[q]) { need_test_block(); break; }
+        py::array_t<uint64_t> out((py::ssize_t)n);
+        check(fsk_get_counts_cells(h_, rows.data(), cols.data(), n, out.mutable_data()));
+        return out;
+    }
+    // the reference's K itself — the whole normalised lower triangle, cell (i, j <= i) at i(i+1)/2 + j
+    // (fastsk_kernel.cpp:96-103) — resident on the GPU as a 1-D float64 DLPack capsule
+    py::capsule get_triangle_dlpack() {
+        if (!computed_) throw std::runtime_error("call compute_kernel or compute_train first");
+        need_test_block();
+        double* dev = nullptr;
+        check(fsk_alloc_triangle_device(h_, &dev));
+        const int64_t N = n_train_ + n_test_;
+        return dlpack_of(dev, 1, N * (N + 1) / 2, 1);
     }
     py::dict stats() const {
         fsk_stats s;
@@ -341,6 +397,10 @@ PYBIND11_MODULE(_fastsk, m) {
         .def("get_test_kernel_dlpack", &FastSK::get_test_kernel_dlpack)
         .def("get_block_dlpack", &FastSK::get_block_dlpack, py::arg("i0"), py::arg("i1"), py::arg("j0"), py::arg("j1"))
         .def("get_counts_np", &FastSK::get_counts_np)
+        .def("counts_digest", &FastSK::counts_digest, py::arg("row_begin") = 0, py::arg("row_end") = -1)
+        .def("get_counts_block", &FastSK::get_counts_block, py::arg("i0"), py::arg("i1"), py::arg("j0"), py::arg("j1"))
+        .def("get_counts_cells", &FastSK::get_counts_cells, py::arg("rows"), py::arg("cols"))
+        .def("get_triangle_dlpack", &FastSK::get_triangle_dlpack)
         .def("set_combo_order", &FastSK::set_combo_order, py::arg("order"))
         .def("stats", &FastSK::stats);
     m.attr("__version__") = "dev";

@@ -930,6 +930,17 @@ int fsk_get_test(fsk_engine* e, double* out) {
     return fetch_block(e, e->n_train, e->N, 0, e->n_train, out);
 }
 
+// cells [c0, c0 + cnt) of the normalised triangle into device memory at `dst` (dst[0] = cell c0)
+static int launch_triangle(fsk_engine* e, u64 c0, u64 cnt, double* dst) {
+    const u64 per_block = (u64)256 * fsk::TR_ITEMS;
+    const uint32_t blocks = (uint32_t)((cnt + per_block - 1) / per_block);
+    if (e->result_f64)
+        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_triangle<double>), dim3(blocks), dim3(256), 0, e->stream, e->d_Kf64.p, e->d_diag.p, c0, cnt, dst);
+    else
+        FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_triangle<u64>), dim3(blocks), dim3(256), 0, e->stream, e->d_K, e->d_diag.p, c0, cnt, dst);
+    return FSK_OK;
+}
+
 int fsk_get_triangle(fsk_engine* e, double* out) {
     if (!e) return FSK_EINVAL;
     if (!e->finalized) return e->fail(FSK_ESTATE, "no finalized kernel");
@@ -940,14 +951,42 @@ int fsk_get_triangle(fsk_engine* e, double* out) {
     FSK_HIP(e->d_stage.reserve((size_t)std::min<u64>(chunk, (u64)e->pairs)));
     for (u64 c0 = 0; c0 < (u64)e->pairs; c0 += chunk) {
         const u64 cnt = std::min<u64>(chunk, (u64)e->pairs - c0);
-        const uint32_t blocks = (uint32_t)((cnt + 255) / 256);
-        if (e->result_f64)
-            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_triangle<double>), dim3(blocks), dim3(256), 0, e->stream, e->d_Kf64.p, e->d_diag.p, c0, cnt, e->d_stage.p);
-        else
-            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_triangle<u64>), dim3(blocks), dim3(256), 0, e->stream, e->d_K, e->d_diag.p, c0, cnt, e->d_stage.p);
+        { int rc = launch_triangle(e, c0, cnt, e->d_stage.p); if (rc) return rc; }
         FSK_HIP(hipMemcpyAsync(out + c0, e->d_stage.p, cnt * sizeof(double), hipMemcpyDeviceToHost, e->stream));
         FSK_HIP(hipStreamSynchronize(e->stream));
     }
+    return FSK_OK;
+}
+
+int fsk_get_triangle_device(fsk_engine* e, double* device_out) {
+    if (!e) return FSK_EINVAL;
+    if (!e->finalized) return e->fail(FSK_ESTATE, "no finalized kernel: call fsk_compute or fsk_finalize first");
+    if (!device_out) return e->fail(FSK_EINVAL, "null output");
+    FSK_ON_DEVICE(e);
+    { int rcz = materialise_zero(e); if (rcz) return rcz; }
+    const u64 chunk = (u64)1 << 33;  // (grid.x stays far below its limit)
+    for (u64 c0 = 0; c0 < (u64)e->pairs; c0 += chunk) {
+        const int rc = launch_triangle(e, c0, std::min<u64>(chunk, (u64)e->pairs - c0), device_out + c0);
+        if (rc) return rc;
+    }
+    FSK_HIP(hipStreamSynchronize(e->stream));
+    return FSK_OK;
+}
+
+int fsk_alloc_triangle_device(fsk_engine* e, double** device_out) {
+    if (!e || !device_out) return FSK_EINVAL;
+    *device_out = nullptr;
+    if (!e->finalized) return e->fail(FSK_ESTATE, "no finalized kernel: call fsk_compute or fsk_finalize first");
+    FSK_ON_DEVICE(e);
+    double* p = nullptr;
+    if (hipMalloc((void**)&p, (size_t)e->pairs * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError();
+        return e->fail(FSK_ENOMEM, "cannot allocate the %lld-cell normalised triangle (%.1f GB) on device %d", (long long)e->pairs,
+                       (double)e->pairs * 8e-9, e->cfg.device);
+    }
+    const int rc = fsk_get_triangle_device(e, p);
+    if (rc) { (void)hipFree(p); return rc; }
+    *device_out = p;
     return FSK_OK;
 }
 

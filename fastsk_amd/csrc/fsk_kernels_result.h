@@ -50,18 +50,29 @@ __global__ __launch_bounds__(256) void k_cells_raw(const u64* K, const int64_t* 
     out[q] = K[i > j ? tri_index(i, j) : tri_index(j, i)];
 }
 
-// whole triangle, cells [c0, c0+count) of the reference layout
+// whole triangle, cells [c0, c0+count) of the reference layout (fastsk_kernel.cpp:96-103 over every cell). A thread
+// takes TR_ITEMS cells 256 apart (coalesced 8-byte loads and stores): the row of its first cell comes from one
+// fp64 square root (corrected to the exact integer), the later ones from stepping the column by 256 and carrying
+// into the row — no division or root per cell. 16 bytes of HBM per cell, the diagonal gathers stay in L2.
+constexpr int TR_ITEMS = 16;
 template <typename SrcT>
 __global__ __launch_bounds__(256) void k_triangle(const SrcT* K, const double* diag, u64 c0, u64 count, double* out) {
-    const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (t >= count) return;
-    const u64 c = c0 + t;
+    const u64 base = (u64)blockIdx.x * (256 * TR_ITEMS) + threadIdx.x;
+    if (base >= count) return;
+    const u64 c = c0 + base;
     u64 i = (u64)((sqrt(8.0 * (double)c + 1.0) - 1.0) * 0.5);
     while (i * (i + 1) / 2 > c) --i;
     while ((i + 1) * (i + 2) / 2 <= c) ++i;
-    const u64 j = c - i * (i + 1) / 2;
-    const double x = (double)K[c];
-    out[t] = normalised_cell(x, diag[i], diag[j], i == j);
+    u64 j = c - i * (i + 1) / 2;
+#pragma unroll 4
+    for (int q = 0; q < TR_ITEMS; ++q) {
+        const u64 t = base + (u64)q * 256;
+        if (t >= count) break;
+        const double x = (double)K[c0 + t];
+        out[t] = normalised_cell(x, diag[i], diag[j], i == j);
+        j += 256;
+        while (j > i) { j -= i + 1; ++i; }
+    }
 }
 
 

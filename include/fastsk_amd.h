@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define FSK_ABI_VERSION 2  /* 2: fsk_create_multi + fsk_config.collective/shard/bands, fsk_counts_digest, device-block allocation */
+#define FSK_ABI_VERSION 3  /* 2: fsk_create_multi + fsk_config.collective/bands, fsk_counts_digest, device-block allocation;
+                              3: fsk_get_triangle_device / fsk_alloc_triangle_device, fsk_set_deadline_ms */
 
 enum {
     FSK_OK = 0,
@@ -43,11 +44,15 @@ enum {
 /* accumulate dataflow */
 enum {
     FSK_PATH_AUTO = 0,
-    FSK_PATH_DENSE = 1,  /* per-sequence LDS counting sort -> 4-bit count panels (lo + 16*hi) ->
-                            LDS-tiled integer co-occurrence accumulate (v_dot8_u32_u4), one
-                            64-bit atomicAdd per cell                                            */
-    FSK_PATH_SPARSE = 2  /* radix sort of (k-mer, seq) -> run-length segments -> 64-bit atomicAdd
-                            per (run, pair): the reference's dataflow, cntsrtna+countAndUpdateTri */
+    FSK_PATH_DENSE = 1,  /* k_dense_count: per-sequence LDS counting sort -> 4-bit count panels (lo + 16*hi);
+                            k_dense_tile_dma: 128 x 128 tiles of K, panels DMA'd into LDS, v_dot8_u32_u4
+                            co-occurrence sums kept in registers over all combos of the launch, then one
+                            64-bit store (first launch after a reset) or atomicAdd per cell            */
+    FSK_PATH_SPARSE = 2  /* the reference's dataflow (cntsrtna + countAndUpdateTri) as streams: packed
+                            (k-mer, seq) records -> LSD radix sort in LDS-staged passes -> run-length
+                            entries -> one 32-bit update word per += binned by owner band of K -> the
+                            band's words summed in LDS, one 64-bit add per touched cell; 64-bit
+                            atomicAdd per (run, pair) only when no band of K fits LDS (N > ~23,000)   */
 };
 
 /* how the engines of fsk_create_multi sum their partial triangles (fastsk_kernel.cpp:286-315) */
@@ -94,7 +99,8 @@ typedef struct fsk_stats {
     int32_t path_used;       /* FSK_PATH_DENSE / FSK_PATH_SPARSE                                */
     int32_t n_combos_total;  /* C(g,m)                                                          */
     int64_t combos_done;     /* combos accumulated so far                                       */
-    uint64_t cell_updates;   /* U = sum over runs d(d+1)/2 (sparse path: exact; dense: 0)       */
+    uint64_t cell_updates;   /* U = sum over runs d(d+1)/2, exact on both dataflows (dense: counted from the
+                                count panels by k_dense_distinct when profile = 1, else 0)                */
     uint64_t sort_records;   /* records pushed through the radix sort                           */
     int32_t sort_passes;     /* 8-bit LSD passes per batch                                      */
     int32_t launches;        /* kernel launches in accumulate                                   */
@@ -224,6 +230,11 @@ int fsk_set_skip_test_block(fsk_engine* e, int32_t skip);
 int fsk_get_train(fsk_engine* e, double* out);      /* n_train x n_train, get_train_kernel()   */
 int fsk_get_test(fsk_engine* e, double* out);       /* n_test  x n_train, get_test_kernel()    */
 int fsk_get_triangle(fsk_engine* e, double* out);   /* double[N(N+1)/2], the reference's K     */
+/* The whole normalised triangle (fastsk_kernel.cpp:96-103 applied to every cell) written to DEVICE memory:
+ * N(N+1)/2 doubles at `device_out` (caller-owned), or in a buffer the engine allocates on its device
+ * (*device_out; release with fsk_free_device). One streaming pass: 16 bytes per cell. */
+int fsk_get_triangle_device(fsk_engine* e, double* device_out);
+int fsk_alloc_triangle_device(fsk_engine* e, double** device_out);
 int fsk_get_counts(fsk_engine* e, uint64_t* out);   /* raw integer triangle (exact/skip-var)   */
 int fsk_get_counts_block(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1, uint64_t* out);
 /* raw integer cells (rows[q], cols[q]), q < n, of the symmetric matrix: scattered spot checks of a

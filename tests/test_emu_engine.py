@@ -71,7 +71,7 @@ def test_emu_staged_accumulate_vs_port(emu_lib, port, name, path, ncombo):
     combos = np.linspace(0, nc - 1, ncombo).astype(np.int32)
     combos = np.unique(combos)
     want, _, U = port.raw_counts(d["tokens"], d["offsets"], d["g"], d["m"], combos)
-    e = _native.Engine(d["g"], d["m"], path=path, lib=emu_lib)
+    e = _native.Engine(d["g"], d["m"], path=path, lib=emu_lib, profile=True)  # (profile: the dense dataflow counts U too)
     e.load_sequences(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
     half = len(combos) // 2
     e.accumulate(combos[:half])
@@ -81,8 +81,9 @@ def test_emu_staged_accumulate_vs_port(emu_lib, port, name, path, ncombo):
     N = d["n_train"] + d["n_test"]
     assert np.array_equal(e.get_triangle(), port.normalise(want.astype(np.float64), N))
     st = e.stats()
-    if st["path_used"] == 2:
-        assert st["cell_updates"] == U  # the engine issues exactly the reference's `+=` count
+    # sparse: the engine issues exactly the reference's `+=` count; dense: k_dense_distinct counts the same U from
+    # the count panels (what bench.py's algorithmic bytes and useful_update_frac are built from)
+    assert st["path_used"] in (1, 2) and st["cell_updates"] == U
     blk = e.get_counts_block(3, 17, 1, 9)
     assert np.array_equal(blk, tri_to_square(want, N)[3:17, 1:9])
 

@@ -96,7 +96,7 @@ def test_dense_equals_sparse_on_seeded_dna(native, port):
     combos = np.arange(0, 495, 33, dtype=np.int32)
     out = []
     for path in (1, 2):
-        e = native.Engine(12, 8, path=path)
+        e = native.Engine(12, 8, path=path, profile=True)  # (profile: the dense dataflow counts U as well)
         e.load_sequences(tokens, offsets, 700, 0)
         e.accumulate(combos)
         e.finalize()
@@ -107,6 +107,16 @@ def test_dense_equals_sparse_on_seeded_dna(native, port):
     assert np.array_equal(out[0][1], out[1][1])
     assert np.array_equal(out[0][1], port.normalise(want.astype(np.float64), 700))
     assert out[1][2]["cell_updates"] == U
+    # the dense dataflow's U (k_dense_distinct over the count panels) is what bench.py's headline line builds
+    # cell_updates_per_launch / useful_update_frac / algorithmic bytes from: the same exact count
+    assert out[0][2]["path_used"] == 1 and out[0][2]["cell_updates"] == U
+    # ... also over several accumulate calls, a repeated combo list (the cached-U shortcut) and key compaction
+    e = native.Engine(12, 8, path=1, profile=True)
+    e.load_sequences(tokens, offsets, 700, 0)
+    e.accumulate(combos[:7]); e.accumulate(combos[7:]); e.accumulate(combos[7:])
+    _, _, U2 = port.raw_counts(tokens, offsets, 12, 8, combos[7:], threads=8)
+    assert e.stats()["cell_updates"] == U + U2
+    e.close()
 
 
 @pytest.mark.parametrize("sigma,g,m,n,lo,hi", [(4, 8, 4, 257, 8, 90), (5, 10, 6, 130, 10, 400), (20, 7, 3, 300, 7, 120),
@@ -354,6 +364,112 @@ def test_config5_full_size_100k(native, port):
     ra, rb = np.searchsorted(sub, np.arange(a0, a1)), np.searchsorted(sub, np.arange(b0, b1))
     assert np.array_equal(e.get_counts_block(a0, a1, b0, b1), sq[np.ix_(ra, rb)])
     e.close()
+
+
+def committed_digest(key):
+    import json
+    d = json.load(open(os.path.join(os.path.dirname(GOLD), "..", "profiles", "k_digests.json")))[key]
+    return int(d["sum"], 16), int(d["xor"], 16)
+
+
+def oracle_on_rows(native, port, X, rows, g, m, threads):
+    """Raw integer square matrix and normalised matrix of the oracle run on just X[rows] (sub-block property:
+    cells of the big kernel — raw AND normalised, the diagonals being the sequences' own — are the cells of the
+    kernel of any subset of the sequences)."""
+    st, so = native.flatten(X[rows])
+    ncomb = native.library().num_combos(g, m)
+    want, _, _ = port.raw_counts(st, so, g, m, np.arange(ncomb), threads=threads)
+    n = len(rows)
+    sq = tri_to_square(want, n)
+    dg = np.diag(sq).astype(np.float64)
+    norm = sq.astype(np.float64) / np.sqrt(dg[:, None] * dg[None, :])
+    # the reference normalises a diagonal cell as K_ii / sqrt(K_ii * K_ii) (fastsk_kernel.cpp:99-102)
+    norm[np.arange(n), np.arange(n)] = dg / np.sqrt(dg * dg)
+    return sq, norm
+
+
+def test_config5_full_size_100k_through_the_class(native, port):
+    """The north-star call itself at the north-star size: fastsk.FastSK(g=12, m=8).compute_train(X) and
+    .compute_kernel(X[:90000], X[90000:]) on the 100000 x 300 array of the config-5 generator, through
+    the pybind11 class and the one-call fsk_compute (bindings.cpp:23-31, fastsk.cpp:30-188) — nothing staged, no
+    caller-bound buffer. The integer triangle's digest must be the committed single-GPU one; normalised and raw
+    blocks of >= 1000 randomly placed sequences must equal the oracle run on just those sequences; a device-resident
+    block straddles row 46,341, where the reference's int triangle index overflows (shared.cpp:97-117)."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 110e9:
+        pytest.skip("needs ~100 GB of free HBM (40 GB integer triangle + 40 GB normalised triangle + panels)")
+    from fastsk import FastSK
+    N, L, g, m = 100000, 300, 12, 8
+    tokens, _ = synthetic_dna(N, L)
+    X = tokens.reshape(N, L)
+    want = committed_digest("config5:n_seq=100000,seq_len=300,g=12,m=8,combos=495")
+    threads = min(64, os.cpu_count() or 8)
+    rng = np.random.Generator(np.random.PCG64(4100000))
+
+    # ---- compute_train
+    f = FastSK(g=g, m=m)
+    f.compute_train(X)
+    st = f.stats()
+    assert st["path_used"] == "dense" and st["combos_done"] == 495 and st["n_seq"] == N
+    assert f.counts_digest() == want
+    d_train = f.counts_digest(0, 90000)
+    d_rest = f.counts_digest(90000, N)
+    assert ((d_train[0] + d_rest[0]) % (1 << 64), d_train[1] ^ d_rest[1]) == want  # digests of row ranges combine
+    # two randomly placed runs of 520 sequences (one beyond row 46,340) = a 1040-sequence subset
+    a0 = int(rng.integers(0, 40000)); b0 = int(rng.integers(50000, N - 520))
+    rows = np.concatenate([np.arange(a0, a0 + 520), np.arange(b0, b0 + 520)])
+    sq, norm = oracle_on_rows(native, port, X, rows, g, m, threads)
+    for (r0, r1, q0, q1) in [(0, 520, 0, 520), (520, 1040, 0, 520), (520, 1040, 520, 1040), (0, 520, 520, 1040)]:
+        i0, i1, j0, j1 = rows[r0], rows[r1 - 1] + 1, rows[q0], rows[q1 - 1] + 1
+        assert np.array_equal(f.get_counts_block(i0, i1, j0, j1), sq[r0:r1, q0:q1])
+        assert np.array_equal(f.get_block(i0, i1, j0, j1), norm[r0:r1, q0:q1])
+    # scattered cells of a random 1000-sequence subset, raw and (from them) normalised
+    idx = np.sort(rng.choice(N, size=1000, replace=False))
+    sq2, norm2 = oracle_on_rows(native, port, X, idx, g, m, threads)
+    a, b = np.tril_indices(1000)
+    got = f.get_counts_cells(idx[a], idx[b])
+    assert np.array_equal(got, sq2[a, b])
+    dg = f.get_counts_cells(idx, idx).astype(np.float64)
+    off = a != b
+    assert np.array_equal(got[off].astype(np.float64) / np.sqrt(dg[a[off]] * dg[b[off]]), norm2[a[off], b[off]])
+    # a device-resident block straddling row 46,341
+    blk = torch.from_dlpack(f.get_block_dlpack(46300, 46400, 46290, 46420))
+    assert blk.is_cuda and blk.dtype == torch.float64 and tuple(blk.shape) == (100, 130)
+    sub = np.arange(46290, 46420)
+    _, norm3 = oracle_on_rows(native, port, X, sub, g, m, 8)
+    assert np.array_equal(blk.cpu().numpy(), norm3[10:110, :])
+    # the reference's K itself: the whole normalised triangle, device resident (fastsk_kernel.cpp:96-103 on 5e9 cells)
+    tri = torch.from_dlpack(f.get_triangle_dlpack())
+    assert tri.is_cuda and tri.dtype == torch.float64 and tri.numel() == N * (N + 1) // 2
+    rr = torch.arange(N, device="cuda", dtype=torch.int64)
+    assert bool((tri[rr * (rr + 1) // 2 + rr] == 1.0).all())                       # every diagonal
+    ii, jj = torch.from_numpy(idx[a]).cuda(), torch.from_numpy(idx[b]).cuda()
+    assert np.array_equal(tri[ii * (ii + 1) // 2 + jj].cpu().numpy()[off], norm2[a[off], b[off]])
+    r0 = 46341 * 46342 // 2
+    assert np.array_equal(tri[r0 + 46290:r0 + 46342].cpu().numpy()[:-1], norm3[46341 - 46290, :46341 - 46290])
+    del tri, blk, f
+    torch.cuda.empty_cache()
+
+    # ---- compute_kernel, SURVEY 8(d)'s 90k / 10k split; the test x test block is lazy (skip_test_block=None)
+    f = FastSK(g=g, m=m)
+    f.compute_kernel(X[:90000], X[90000:])
+    st = f.stats()
+    assert st["combos_done"] == 495 and not st["test_block_computed"]
+    assert f.counts_digest(0, 90000) == d_train            # train x train: same cells as compute_train's
+    assert not f.stats()["test_block_computed"]
+    tb = int(rng.integers(90000, N - 300)); ta = int(rng.integers(0, 90000 - 700))
+    rows = np.concatenate([np.arange(ta, ta + 700), np.arange(tb, tb + 300)])
+    sq, norm = oracle_on_rows(native, port, X, rows, g, m, threads)
+    assert np.array_equal(f.get_block(tb, tb + 300, ta, ta + 700), norm[700:, :700])      # test x train
+    te = torch.from_dlpack(f.get_test_kernel_dlpack())
+    assert tuple(te.shape) == (10000, 90000)
+    assert np.array_equal(te[tb - 90000:tb - 90000 + 300, ta:ta + 700].cpu().numpy(), norm[700:, :700])
+    del te
+    assert not f.stats()["test_block_computed"]
+    assert np.array_equal(f.get_block(tb, tb + 300, tb, tb + 300), norm[700:, 700:])      # test x test: computed now
+    assert f.stats()["test_block_computed"]
+    assert f.counts_digest() == want
 
 
 def protein_like(N, lo, hi, seed, sigma=20):
