@@ -292,6 +292,127 @@ def free_port():
     return port
 
 
+class Watchdog:
+    """Fail fast, and always leave a line (multi-GPU first contact must not burn the lease silently).
+
+    A daemon thread per rank. `stage(name, bound_s)` names what the main thread is doing and how long it may take;
+    when a stage outlives its bound — a collective waiting for a rank that never comes, a communicator that never
+    initialises — rank 0 prints ONE JSON line {"error", "stage", "n_gpus", "timings", ...} on stdout and the process
+    ends with os._exit(2): no re-exec, no restart of a process that has touched the GPU, no Python-level cleanup that
+    could itself block on the device. The other ranks wait `grace_s` longer than rank 0 so that rank 0's line is out
+    before the launcher, seeing a rank die, terminates the rest; and when the launcher's SIGTERM arrives first (some
+    other rank crashed), the thread — woken through the signal wake-up pipe: the main thread may be stuck inside a
+    collective, where no Python handler would run — writes the same line with what it knows and exits 143.
+    """
+
+    def __init__(self, rank, world, args, grace_s=20.0):
+        import signal
+        import threading
+        self.rank, self.world, self.args = rank, world, args
+        self.grace = 0.0 if rank == 0 else grace_s
+        self.lock = threading.Lock()
+        self.name, self.t0, self.bound = "start", time.perf_counter(), None
+        self.timings = {}          # finished stages: seconds
+        self.partial = {}          # whatever the main thread wants reported on failure
+        self.done = False
+        self._signal = signal
+        # SIGTERM: a do-nothing Python handler makes the signal "caught" (so it no longer kills the process), and
+        # CPython's C-level handler — which runs at once, on whichever thread the kernel picks, while the main thread
+        # may be stuck inside a collective where no Python handler can run — writes the signal number to this pipe;
+        # the watchdog thread selects on it.
+        self.sig_r = None
+        try:
+            r, w = os.pipe()
+            os.set_blocking(w, False)
+            os.set_blocking(r, False)
+            signal.signal(signal.SIGTERM, lambda *a: None)
+            signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+            self.sig_r = r
+        except (AttributeError, ValueError, OSError):
+            self.sig_r = None
+        self.thread = threading.Thread(target=self._run, name="bench-watchdog", daemon=True)
+        self.thread.start()
+
+    def stage(self, name, bound_s):
+        now = time.perf_counter()
+        with self.lock:
+            self.timings[self.name] = round(self.timings.get(self.name, 0.0) + now - self.t0, 4)
+            self.name, self.t0, self.bound = name, now, bound_s
+
+    def finish(self):
+        with self.lock:
+            self.done = True
+
+    def _line(self, why, code):
+        with self.lock:
+            out = {"error": why, "stage": self.name, "stage_seconds": round(time.perf_counter() - self.t0, 3),
+                   "stage_bound_seconds": self.bound, "n_gpus": self.world, "rank": self.rank,
+                   "metric": "gkm kernel build: mismatch-combos/s", "value": None, "unit": "combos/s",
+                   "steps": self.args.steps, "warmup": self.args.warmup, "timings": dict(self.timings), "partial": dict(self.partial)}
+        try:
+            if self.rank == 0:
+                sys.stdout.write(json.dumps(out) + "\n")
+                sys.stdout.flush()
+            sys.stderr.write("bench.py rank %d: %s (stage %r)\n" % (self.rank, why, out["stage"]))
+            sys.stderr.flush()
+        finally:
+            os._exit(code)
+
+    def _run(self):
+        import select
+        while True:
+            got = False
+            if self.sig_r is not None:
+                try:
+                    ready, _, _ = select.select([self.sig_r], [], [], 0.25)
+                    if ready:
+                        got = self._signal.SIGTERM in os.read(self.sig_r, 64)
+                except (InterruptedError, OSError, ValueError):
+                    got = False
+            else:
+                time.sleep(0.25)
+            with self.lock:
+                if self.done:
+                    if got:
+                        os._exit(143)
+                    continue
+                name, t0, bound = self.name, self.t0, self.bound
+            if got:
+                self._line("terminated by the launcher (SIGTERM) — another rank failed or the run was cancelled", 143)
+            if bound is not None and time.perf_counter() - t0 > bound + self.grace:
+                self._line("stage %r exceeded its bound of %.0f s: a rank, a link or a collective is not answering" % (name, bound), 2)
+
+
+def fatal(wd, rank, world, args, why, stage, extra=None):
+    """A check failed (not a hang): rank 0 prints the JSON error line, every rank exits non-zero."""
+    out = {"error": why, "stage": stage, "n_gpus": world, "rank": rank, "metric": "gkm kernel build: mismatch-combos/s",
+           "value": None, "unit": "combos/s", "steps": args.steps, "warmup": args.warmup,
+           "timings": dict(wd.timings) if wd else {}, "partial": dict(extra or {})}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    sys.stderr.write("bench.py rank %d: %s\n" % (rank, why))
+    sys.stderr.flush()
+    os._exit(2)
+
+
+def expected_step_seconds(args):
+    """What one step of the workload takes on ONE MI355X (profiles/: config 5 at 100k x 300 = 2.12 s, ~N^2; config 4
+    = 10 ms): the yardstick the watchdog's bounds are derived from until this run has measured its own step."""
+    if args.config == 4:
+        return 0.05
+    return 2.2 * (args.n_seq / 100000.0) ** 2 * (args.seq_len / 300.0) + 0.05
+
+
+def memory_plan(N, pairs, world, dense, narrow_possible):
+    """Bytes one rank needs on its GPU: the integer triangle, the int32 staging of the largest exchanged band, the
+    count panels (the engine takes up to 32 GB or 60 % of what is free), headroom."""
+    k = pairs * 8
+    staging = (pairs * 4 // 8 if world > 1 and narrow_possible else 0)   # <= the largest of >= 8 equal-area bands
+    panels = (13 << 30) if (dense and N >= 50000) else (2 << 30)
+    return {"triangle_u64": k, "exchange_staging": staging, "count_panels_or_sort_scratch": panels, "headroom": 2 << 30,
+            "total": k + staging + panels + (2 << 30)}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -315,6 +436,10 @@ def parse_args():
     ap.add_argument("--collective", choices=["auto", "rccl", "p2p"], default="auto", help="--inproc: the exchange (auto = RCCL)")
     ap.add_argument("--no-inproc-leg", action="store_true", help="multi-process run: do not add the in-process measurement")
     ap.add_argument("--inproc-timeout", type=float, default=420.0, help="seconds the in-process child of a multi-process run may take")
+    ap.add_argument("--no-preflight", action="store_true", help="multi-GPU: skip the 1-step N = 16000 job whose digest is committed")
+    ap.add_argument("--init-timeout", type=float, default=180.0, help="seconds init_process_group / a collective may take (torch timeout)")
+    ap.add_argument("--no-watchdog", action="store_true", help="no stage bounds (debugging under a profiler)")
+    ap.add_argument("--step-bound", type=float, default=0.0, help="seconds one step may take before the watchdog gives up (default: from the 1-GPU step time)")
     return ap.parse_args()
 
 
@@ -453,31 +578,53 @@ def main_inproc(args):
     # (FSK_BENCH_SHARE_GPU=1: a smoke test of the group on a 1-GPU box, every engine on device 0 over the P2P kernels)
     devices = [0] * args.gpus if os.environ.get("FSK_BENCH_SHARE_GPU") == "1" else list(range(args.gpus))
     coll = {"auto": _native.COLL_AUTO, "rccl": _native.COLL_RCCL, "p2p": _native.COLL_P2P}[args.collective]
-    eng = _native.Engine(g, m, devices=devices, collective=coll, bands=args.bands or 0, profile=True)
+    exp = expected_step_seconds(args)
+    step_bound = args.step_bound if args.step_bound > 0 else max(45.0, 12.0 * exp)
+    wd = None if args.no_watchdog else Watchdog(0, args.gpus, args)
+    stage = (lambda name, bound: wd.stage(name, bound)) if wd else (lambda name, bound: None)
+    stage("fsk_create_multi (ncclCommInitAll)", args.init_timeout + 30.0)
+    try:
+        # the engine's own deadline (fsk_config.deadline_ms) bounds every host-side wait of the exchange: communicator
+        # set-up, the engines' barriers, each band's all-reduce; the watchdog above is the backstop for a thread that
+        # never returns from the runtime
+        eng = _native.Engine(g, m, devices=devices, collective=coll, bands=args.bands or 0, profile=True,
+                             deadline_ms=int(1e3 * min(args.init_timeout, step_bound)))
+    except _native.FskError as exc:
+        fatal(wd, 0, args.gpus, args, "fsk_create_multi failed: %s" % exc, "fsk_create_multi")
     ncomb = eng.lib.num_combos(g, m)
     workload += ", %d combos" % ncomb
-    t_load = time.perf_counter()
-    eng.load_sequences(tokens, offsets, N, 0)
-    eng.synchronize()
-    t_load = time.perf_counter() - t_load
-    every = np.arange(ncomb, dtype=np.int32)
-    dense = eng.stats()["path_used"] == 1
+    pairs = N * (N + 1) // 2
+    plan = memory_plan(N, pairs, args.gpus, dense=args.config == 5, narrow_possible=True)
+    try:
+        stage("load sequences", 240.0)
+        t_load = time.perf_counter()
+        eng.load_sequences(tokens, offsets, N, 0)
+        eng.synchronize()
+        t_load = time.perf_counter() - t_load
+        every = np.arange(ncomb, dtype=np.int32)
+        dense = eng.stats()["path_used"] == 1
 
-    def step():
-        eng.reset_counts()
-        eng.accumulate(every)   # combos r, r + R, ... on engine r; the all-reduce band by band behind the kernels
-        eng.finalize()
+        def step():
+            eng.reset_counts()
+            eng.accumulate(every)   # combos r, r + R, ... on engine r; the all-reduce band by band behind the kernels
+            eng.finalize()
 
-    for _ in range(args.warmup):
-        step()
-    eng.synchronize()
-    s0 = eng.stats()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    eng.synchronize()
-    elapsed = time.perf_counter() - t0
-    s1 = eng.stats()
+        for i in range(args.warmup):
+            stage("warm-up step %d of %d" % (i + 1, args.warmup), step_bound + 120.0)
+            step()
+        eng.synchronize()
+        s0 = eng.stats()
+        stage("%d timed steps" % args.steps, args.steps * (step_bound + (0.0 if args.warmup else 120.0)) + 30.0)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        eng.synchronize()
+        elapsed = time.perf_counter() - t0
+        s1 = eng.stats()
+        stage("digest + line", step_bound)
+    except _native.FskError as exc:
+        fatal(wd, 0, args.gpus, args, "the in-process group failed: %s" % exc, wd.name if wd else "step",
+              {"memory_plan_GB": {k: round(v / 1e9, 2) for k, v in plan.items()}})
     info = eng.multi_info()
     digest = eng.counts_digest()
     key = digest_key(args.config, N, L, g, m, ncomb)
@@ -509,6 +656,8 @@ def main_inproc(args):
         "bit_identical_to_1gpu": None if want is None else (digest_hex(digest) == {"sum": want["sum"], "xor": want["xor"]}),
     }
     eng.close()
+    if wd:
+        wd.finish()
     finish(out, args, N, L, g, m, _native)
 
 
@@ -540,21 +689,96 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("FSK_BENCH_FORCE_DIST") == "1"
+    # ---- fail fast (first contact with several GPUs): every stage below has a bound; see Watchdog
+    wd = None
+    if use_dist and not args.no_watchdog:
+        wd = Watchdog(rank, world, args)
+    stall = os.environ.get("FSK_BENCH_STALL", "").split(":")  # test-only: "rank:stage substring:seconds" — this rank hangs there
+
+    def stage(name, bound):
+        if wd:
+            wd.stage(name, bound)
+        if len(stall) == 3 and stall[0] == str(rank) and stall[1] in name:
+            time.sleep(float(stall[2]))
+
+    exp = expected_step_seconds(args)
+    # one whole step of one rank, exchange included (1 GPU: `exp` seconds)
+    step_bound = args.step_bound if args.step_bound > 0 else max(45.0, 12.0 * exp)
     backend = None
     if use_dist:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         backend = "gloo" if share else "nccl"
+        stage("init_process_group(%s)" % backend, args.init_timeout + 30.0)
+        tmo = datetime.timedelta(seconds=args.init_timeout)
         if share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=tmo)
+        stage("first collective (communicator set-up)", args.init_timeout + 30.0)
+        probe = torch.ones(1, dtype=torch.int64, device="cpu" if share else "cuda")
+        dist.all_reduce(probe)
+        if int(probe.item()) != world:
+            fatal(wd, rank, world, args, "the first all-reduce over %d ranks returned %d" % (world, int(probe.item())), "first collective")
 
+    stage("workload + memory plan", 180.0)
     tokens, offsets, N, L, g, m, workload, data = workload_of(args)
+    pairs = N * (N + 1) // 2
+    # ---- per-rank memory plan, checked before anything large is allocated
+    free_b, total_b = torch.cuda.mem_get_info()
+    plan = memory_plan(N, pairs, world, dense=args.config == 5, narrow_possible=True)
+    if wd:
+        wd.partial["memory_plan_GB"] = {k: round(v / 1e9, 2) for k, v in plan.items()}
+        wd.partial["hbm_free_GB"] = round(free_b / 1e9, 2)
+    if free_b < plan["total"] and not share:
+        fatal(wd, rank, world, args,
+              "rank %d (cuda:%d): %.1f GB of HBM free, the plan needs %.1f GB (%.1f GB integer triangle + %.2f GB exchange staging + "
+              "%.1f GB count panels / sort scratch + headroom): free the GPU or lower --n-seq"
+              % (rank, local_rank, free_b / 1e9, plan["total"] / 1e9, plan["triangle_u64"] / 1e9, plan["exchange_staging"] / 1e9,
+                 plan["count_panels_or_sort_scratch"] / 1e9), "memory plan", {"memory_plan_GB": {k: round(v / 1e9, 2) for k, v in plan.items()}})
+
+    # ---- preflight: the same multi-GPU code on a job that takes a fraction of a second and whose single-GPU digest
+    # is committed (config 5 at N = 16000): a broken interconnect or a wrong reduce is reported in seconds
+    preflight = None
+    if use_dist and world > 1 and args.config == 5 and not args.no_preflight and N >= 16000:
+        stage("preflight (N = 16000, one step, digest committed)", max(90.0, step_bound))
+        pN = 16000
+        ptok, poff, _ = synthetic(pN, args.seq_len)
+        pg, pm = args.g or 12, args.m or 8
+        peng = _native.Engine(pg, pm, device=local_rank)
+        pncomb = peng.lib.num_combos(pg, pm)
+        ppairs = pN * (pN + 1) // 2
+        pK = torch.zeros(ppairs, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        peng.bind_counts(pK.data_ptr(), ppairs, keepalive=pK)
+        peng.load_sequences(ptok, poff, pN, 0)
+        t0 = time.perf_counter()
+        peng.reset_counts()
+        distributed.accumulate_and_reduce(peng, pK, np.arange(rank, pncomb, world, dtype=np.int32), n_combos_total=pncomb, n_bands=args.bands)
+        peng.finalize()
+        torch.cuda.synchronize()
+        pdt = time.perf_counter() - t0
+        pd = peng.counts_digest()
+        pwant = committed_digest(digest_key(5, pN, args.seq_len, pg, pm, pncomb))
+        ok = None if pwant is None else digest_hex(pd) == {"sum": pwant["sum"], "xor": pwant["xor"]}
+        flag = torch.tensor([0 if ok is False else 1], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        preflight = {"n_seq": pN, "seconds": pdt, "k_digest": digest_hex(pd), "committed": pwant, "bit_identical_to_1gpu": ok,
+                     "every_rank_agrees": bool(int(flag.item()) == 1)}
+        if wd:
+            wd.partial["preflight"] = preflight
+        peng.close()
+        del pK
+        torch.cuda.empty_cache()
+        if int(flag.item()) != 1:
+            fatal(wd, rank, world, args, "preflight: the %d-GPU triangle of the N = 16000 job is not the committed single-GPU one "
+                  "(rank %d digest %s)" % (world, rank, digest_hex(pd)), "preflight", {"preflight": preflight})
+
+    stage("allocate the triangle + load sequences", 240.0)
     eng = _native.Engine(g, m, device=local_rank, profile=True)
     ncomb = eng.lib.num_combos(g, m)
     workload += ", %d combos" % ncomb
-    pairs = N * (N + 1) // 2
     K = torch.zeros(pairs, dtype=torch.int64, device="cuda")  # the integer triangle RCCL reduces
     torch.cuda.synchronize()
     eng.bind_counts(K.data_ptr(), pairs, keepalive=K)
@@ -618,15 +842,25 @@ def main():
 
     def timed(how, warmup, steps):
         eng.reset_counts()  # whatever the other decomposition left in K (untimed)
-        for _ in range(warmup):
+        bound = step_bound
+        for i in range(warmup):
+            stage("%s: warm-up step %d of %d" % (how, i + 1, warmup), bound + (120.0 if i == 0 else 0.0))  # (first: allocations, RCCL channels)
+            tw = time.perf_counter()
             step(how)
+            torch.cuda.synchronize()
+            bound = max(30.0, 10.0 * (time.perf_counter() - tw)) if i > 0 or warmup == 1 else bound  # this run's own step time
+        stage("%s: barrier before the timed steps" % how, step_bound)
         barrier()
         a = eng.stats()
+        stage("%s: %d timed steps" % (how, steps), steps * (bound if warmup else step_bound + 120.0) + 30.0)
         t0 = time.perf_counter()
         for _ in range(steps):
             step(how)
         barrier()
         dt = time.perf_counter() - t0
+        if wd:
+            wd.partial["%s_ms_per_step_this_rank" % how] = round(1e3 * dt / max(1, steps), 3)
+        stage("%s: max over ranks + digest" % how, step_bound)
         b = eng.stats()
         if use_dist:
             tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -663,6 +897,7 @@ def main():
     # ---- the exchange by itself: the same band-wise all-reduce, nothing overlapping it (untimed extras;
     # K is garbage afterwards and is reset by whatever runs next)
     comm = None
+    stage("the exchange by itself", step_bound)
     if use_dist:
         narrow = ncomb * eng.stats()["max_windows"] ** 2 < 2 ** 31
         tiles = ((N + 127) // 128) * ((N + 127) // 128 + 1) // 2
@@ -693,6 +928,7 @@ def main():
     # whole triangle (fastsk_kernel.cpp:96-103 over all N(N+1)/2 cells, device resident) when a second
     # triangle of doubles fits beside the integer one, else a 4096 x 4096 block (single GPU only)
     end_to_end = None
+    stage("end_to_end", 4 * step_bound)
     if world == 1 and not use_dist:
         nblk = min(4096, N)
         free, _ = torch.cuda.mem_get_info()
@@ -757,8 +993,15 @@ def main():
             out["alt"] = alt
         if comm is not None:
             out["comm"] = comm
+        if preflight is not None:
+            out["preflight"] = preflight
+        if use_dist:
+            out["memory_plan_GB"] = {k: round(v / 1e9, 2) for k, v in plan.items()}
+            out["fail_fast"] = {"watchdog": wd is not None, "init_timeout_s": args.init_timeout, "step_bound_s": step_bound,
+                                "note": "every stage of a multi-GPU run is bounded; an overrun prints one JSON error line on rank 0 and exits 2"}
         if end_to_end is not None:
             out["end_to_end"] = end_to_end
+    stage("closing barrier", step_bound)
     if use_dist:
         dist.barrier()
     eng.close()
@@ -769,6 +1012,9 @@ def main():
     # and the others wait on the rendezvous store, not on a collective that would spin on their GPUs.
     if world > 1 and backend == "nccl" and not args.no_inproc_leg:
         import datetime
+        stage("in-process leg (child of rank 0)", args.inproc_timeout + 180.0)
+        if wd and out is not None:
+            wd.partial["line_so_far"] = {k: out[k] for k in ("value", "ms_per_step", "bit_identical_to_1gpu", "k_digest") if k in out}
         store = dist.distributed_c10d._get_default_store()
         torch.cuda.synchronize()
         dist.barrier()
@@ -798,8 +1044,13 @@ def main():
             store.set("fsk_inproc_leg_done", "1")
         else:
             store.wait(["fsk_inproc_leg_done"], datetime.timedelta(seconds=args.inproc_timeout + 120))
+    stage("destroy_process_group", 120.0)
+    if wd and out is not None:
+        wd.partial["line_so_far"] = {k: out[k] for k in ("value", "ms_per_step", "bit_identical_to_1gpu", "k_digest") if k in out}
     if use_dist:
         dist.destroy_process_group()
+    if wd:
+        wd.finish()
     if rank == 0:
         finish(out, args, N, L, g, m, _native)
     elif identical is False:

@@ -32,7 +32,7 @@ class Config(C.Structure):
                 ("delta", C.c_double), ("max_iters", C.c_int32), ("skip_variance", C.c_int32),
                 ("device", C.c_int32), ("path", C.c_int32), ("profile", C.c_int32),
                 ("skip_test_block", C.c_int32), ("collective", C.c_int32), ("bands", C.c_int32),
-                ("reserved", C.c_int32 * 2)]
+                ("deadline_ms", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class Stats(C.Structure):
@@ -253,7 +253,7 @@ class Engine:
 
     def __init__(self, g, m, t=-1, approx=False, delta=0.025, max_iters=-1, skip_variance=False, device=0,
                  path=PATH_AUTO, profile=False, lib=None, skip_test_block=False, devices=None, collective=COLL_AUTO,
-                 bands=0):
+                 bands=0, deadline_ms=0):
         self.lib = lib or library()
         if devices is not None:
             devices = [int(d) for d in devices]
@@ -262,7 +262,8 @@ class Engine:
             device = devices[0]
         cfg = Config(g=g, m=m, t=t, approx=int(bool(approx)), delta=delta, max_iters=max_iters,
                      skip_variance=int(bool(skip_variance)), device=device, path=path, profile=int(bool(profile)),
-                     skip_test_block=int(bool(skip_test_block)), collective=int(collective), bands=int(bands))
+                     skip_test_block=int(bool(skip_test_block)), collective=int(collective), bands=int(bands),
+                     deadline_ms=int(deadline_ms))
         h = C.c_void_p()
         if devices is None:
             rc = self.lib.L.fsk_create(C.byref(cfg), C.byref(h))

@@ -7,7 +7,7 @@
 //   - errors raise ValueError / RuntimeError instead of printf + exit(1) (fastsk.cpp:53-58);
 //   - fit() / score() (LIBSVM, fastsk.cpp:239-530) are outside this path and raise
 //     NotImplementedError (they are unusable from Python in the reference as well);
-//   - additive keyword arguments (device, devices, collective, path, seed, skip_test_block), numpy and
+//   - additive keyword arguments (device, devices, collective, deadline_ms, path, seed, skip_test_block), numpy and
 //     DLPack getters. devices=[0,1,...]: one engine per listed GPU behind the same object (fsk_create_multi) —
 //     the reference parallelises the same call over t host threads (fastsk_kernel.cpp:54-93).
 //   - the test x test block, which no getter of the reference exposes (fastsk.cpp:190-217), is not computed
@@ -174,13 +174,14 @@ class FastSK {
 public:
     FastSK(int g, int m, int t, bool approx, double delta, int max_iters, bool skip_variance, int device,
            const std::string& path, py::object seed, py::object skip_test_block, py::object devices,
-           const std::string& collective) {
+           const std::string& collective, int deadline_ms) {
         fsk_config c{};
         lazy_test_block_ = skip_test_block.is_none();
         c.skip_test_block = lazy_test_block_ ? 0 : (skip_test_block.cast<bool>() ? 1 : 0);
         c.g = g; c.m = m; c.t = t; c.approx = approx; c.delta = delta; c.max_iters = max_iters;
         c.skip_variance = skip_variance; c.device = device; c.path = parse_path(path);
         c.collective = parse_collective(collective);
+        c.deadline_ms = deadline_ms;
         int rc;
         if (devices.is_none()) {
             device0_ = device;
@@ -371,11 +372,11 @@ PYBIND11_MODULE(_fastsk, m) {
     m.doc() = "MI355X-native gapped-k-mer kernel engine behind the FastSK Python surface";
     py::class_<FastSK>(m, "FastSK")
         .def(py::init<int, int, int, bool, double, int, bool, int, const std::string&, py::object, py::object, py::object,
-                      const std::string&>(),
+                      const std::string&, int>(),
              py::arg("g"), py::arg("m"), py::arg("t") = -1, py::arg("approx") = false, py::arg("delta") = 0.025,
              py::arg("max_iters") = -1, py::arg("skip_variance") = false, py::arg("device") = 0,
              py::arg("path") = "auto", py::arg("seed") = py::none(), py::arg("skip_test_block") = py::none(),
-             py::arg("devices") = py::none(), py::arg("collective") = "auto")
+             py::arg("devices") = py::none(), py::arg("collective") = "auto", py::arg("deadline_ms") = 0)
         .def("compute_kernel", &FastSK::compute_kernel_np, py::arg("Xtrain").noconvert(), py::arg("Xtest").noconvert())
         .def("compute_kernel", &FastSK::compute_kernel, py::arg("Xtrain"), py::arg("Xtest"))
         .def("compute_kernel_flat", &FastSK::compute_kernel_flat, py::arg("tokens").noconvert(), py::arg("offsets").noconvert(),

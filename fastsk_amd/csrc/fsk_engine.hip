@@ -335,6 +335,8 @@ void fsk_detail::one_destroy(fsk_engine* e) {
     if (e->h_prod) (void)hipHostFree(e->h_prod);
     if (e->h_sx_pos) (void)hipHostFree(e->h_sx_pos);
     if (e->h_sx_stat) (void)hipHostFree(e->h_sx_stat);
+    if (e->h_sx_head_pos) (void)hipHostFree(e->h_sx_head_pos);
+    if (e->h_sx_head_stat) (void)hipHostFree(e->h_sx_head_stat);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     if (e->ev_out) (void)hipEventDestroy(e->ev_out);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
@@ -672,6 +674,9 @@ int fsk_bind_counts(fsk_engine* e, void* device_u64, int64_t n_cells) {
     e->d_K = (u64*)device_u64;
     e->K_owned = false;
     e->finalized = false;
+    // a group narrows its exchange to int32 when combos-since-reset x max_windows^2 < 2^31 bounds every cell: the
+    // caller's memory holds whatever it holds, so no narrowing until fsk_reset_counts / fsk_load_sequences zero it
+    if (e->group) group_note_bound_counts(e);
     return FSK_OK;
 }
 

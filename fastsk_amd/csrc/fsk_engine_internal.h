@@ -193,10 +193,13 @@ struct fsk_engine {
     // been sized: the stream buffer keeps headroom over the largest count seen, the kernels leave a
     // batch that does not fit alone, and the host redoes such a batch (sized exactly) when it reads the
     // counts back — at the end of an exact accumulate, at the hand-over of a variance-mode batch.
-    unsigned char* h_sx_pos = nullptr;   // pinned: positions of the batches in flight ([SX_DEFER slots][exact call])
+    unsigned char* h_sx_pos = nullptr;   // pinned: positions of the batches of ONE exact accumulate (read back before it returns)
     size_t h_sx_pos_cap = 0;
-    u64* h_sx_stat = nullptr;            // pinned: {pairs, words} of the batches in flight (same layout)
+    u64* h_sx_stat = nullptr;            // pinned: {pairs, words} of those batches
     size_t h_sx_stat_cap = 0;
+    unsigned char* h_sx_head_pos = nullptr;  // pinned, fixed size, never moved: positions of variance mode's deferred batches (in flight across calls)
+    u64* h_sx_head_stat = nullptr;           //                                   their {pairs, words}
+    int sx_last_lane = 0;                // the lane (scratch + stream) the last accumulate_sparse ran in
     double sx_wpr = 0;                   // most update words per sort record of a batch since the sequences were loaded (0: none seen)
     u64 sx_words_of(u64 nrec) const { return (u64)(sx_wpr * (double)nrec) + 1; }  // what a batch of nrec records is expected to emit
     void sx_saw(u64 words, u64 nrec) { if (nrec) sx_wpr = std::max(sx_wpr, std::max(1e-9, (double)words / (double)nrec)); }
@@ -301,5 +304,6 @@ int group_set_seed(fsk_engine* e, uint64_t seed);
 int group_get_stats(fsk_engine* e, fsk_stats* out);
 int group_set_skip_test_block(fsk_engine* e, int32_t skip);
 void group_destroy(fsk_engine* e);
+void group_note_bound_counts(fsk_engine* e);  // fsk_bind_counts on a group handle: the bound cells are not bounded by the combos since a reset
 
 }  // namespace fsk_detail

@@ -354,18 +354,28 @@ int ensure_featseq(fsk_engine* e) {
 constexpr int SX_DEFER = 8;          // variance mode: batches whose counts are read at their hand-over
 constexpr int SX_DEFER_COMBOS = 16;  //                combos of such a batch at most
 
-int sx_pinned(fsk_engine* e, size_t pos_bytes, size_t stat_words) {
-    if (pos_bytes > e->h_sx_pos_cap) {
+// Pinned staging of the batches. The HEAD — positions and {pairs, words} of variance mode's deferred batches, which
+// stay in flight across calls — is allocated once at its fixed size and never moved; only the per-call TAIL (the
+// batches of one exact accumulate, all read back before the call returns) grows.
+constexpr size_t SX_HEAD_POS = (size_t)SX_DEFER * SX_DEFER_COMBOS * 255;  // (k <= g <= 255)
+constexpr size_t SX_HEAD_STAT = (size_t)2 * SX_DEFER;
+int sx_pinned(fsk_engine* e, size_t tail_pos_bytes, size_t tail_stat_words) {
+    if (!e->h_sx_head_pos) {
+        FSK_HIP(hipHostMalloc((void**)&e->h_sx_head_pos, SX_HEAD_POS));
+        FSK_HIP(hipHostMalloc((void**)&e->h_sx_head_stat, SX_HEAD_STAT * sizeof(u64)));
+        memset(e->h_sx_head_stat, 0, SX_HEAD_STAT * sizeof(u64));
+    }
+    if (tail_pos_bytes > e->h_sx_pos_cap) {
         if (e->h_sx_pos) (void)hipHostFree(e->h_sx_pos);
         e->h_sx_pos = nullptr; e->h_sx_pos_cap = 0;
-        FSK_HIP(hipHostMalloc((void**)&e->h_sx_pos, pos_bytes + pos_bytes / 2));
-        e->h_sx_pos_cap = pos_bytes + pos_bytes / 2;
+        FSK_HIP(hipHostMalloc((void**)&e->h_sx_pos, tail_pos_bytes + tail_pos_bytes / 2));
+        e->h_sx_pos_cap = tail_pos_bytes + tail_pos_bytes / 2;
     }
-    if (stat_words > e->h_sx_stat_cap) {
+    if (tail_stat_words > e->h_sx_stat_cap) {
         if (e->h_sx_stat) (void)hipHostFree(e->h_sx_stat);
         e->h_sx_stat = nullptr; e->h_sx_stat_cap = 0;
-        FSK_HIP(hipHostMalloc((void**)&e->h_sx_stat, (stat_words + stat_words / 2) * sizeof(u64)));
-        e->h_sx_stat_cap = stat_words + stat_words / 2;
+        FSK_HIP(hipHostMalloc((void**)&e->h_sx_stat, (tail_stat_words + tail_stat_words / 2) * sizeof(u64)));
+        e->h_sx_stat_cap = tail_stat_words + tail_stat_words / 2;
     }
     return FSK_OK;
 }
@@ -388,7 +398,7 @@ u64 sx_guard_for(fsk_engine* e, int lane, u64 nrec) {
 bool sx_harvest(fsk_engine* e, int slot) {
     if (slot < 0 || !e->sx_defer[slot].active) return true;
     e->sx_defer[slot].active = false;
-    const u64 pairs = e->h_sx_stat[2 * slot], words = e->h_sx_stat[2 * slot + 1];
+    const u64 pairs = e->h_sx_head_stat[2 * slot], words = e->h_sx_head_stat[2 * slot + 1];
     e->sx_saw(words, e->sx_defer[slot].nrec);
     if (words > e->sx_defer[slot].cap) { e->sx_redone += 1; return false; }
     e->u_extra += pairs;
@@ -421,9 +431,9 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     if (defer >= 0 && (defer >= SX_DEFER || batch_combos(n) != n || n > SX_DEFER_COMBOS)) defer = -1;
     // variance mode's batches in flight alternate between two lanes of scratch and two streams
     const int lane = sx_lane_of(e, defer);
+    e->sx_last_lane = lane;  // (what the caller orders its own passes over the batch's triangles against)
     if (lane && !e->lane_stream) FSK_HIP(hipStreamCreateWithFlags(&e->lane_stream, hipStreamNonBlocking));
-    const size_t pos_head = (size_t)SX_DEFER * SX_DEFER_COMBOS * e->k, stat_head = (size_t)2 * SX_DEFER;
-    rc = sx_pinned(e, pos_head + (size_t)n * e->k, stat_head + (size_t)2 * n);  // (at most one batch per combo)
+    rc = sx_pinned(e, (size_t)n * e->k, (size_t)2 * n);  // (at most one batch per combo)
     if (rc) return rc;
     auto one = [&](int s, int nb, unsigned char* pos_pin, u64* stat_pin, u64 guard) {
         // (slot triangles are u32 arrays, slot_stride cells apart)
@@ -437,7 +447,7 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
         e->sx_defer[defer].active = guard != 0;
         e->sx_defer[defer].cap = guard;
         e->sx_defer[defer].nrec = (u64)n * nfeat;
-        rc = one(0, n, e->h_sx_pos + (size_t)defer * SX_DEFER_COMBOS * e->k, e->h_sx_stat + 2 * defer, guard);
+        rc = one(0, n, e->h_sx_head_pos + (size_t)defer * SX_DEFER_COMBOS * e->k, e->h_sx_head_stat + 2 * defer, guard);
         if (rc) e->sx_defer[defer].active = false;
         return rc;
     }
@@ -447,7 +457,7 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     for (int s = 0; s < n; ++q) {
         const int nb = batch_combos(n - s);  // (grows after the first batch of a set of sequences has been sized)
         const u64 cap = sx_guard_for(e, 0, (u64)nb * nfeat);
-        rc = one(s, nb, e->h_sx_pos + pos_head + (size_t)s * e->k, e->h_sx_stat + stat_head + 2 * q, cap);
+        rc = one(s, nb, e->h_sx_pos + (size_t)s * e->k, e->h_sx_stat + 2 * q, cap);
         if (rc) return rc;
         enq.push_back(Enq{s, nb, cap});
         s += nb;
@@ -459,14 +469,14 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     for (size_t i = 0; i < enq.size(); ++i) {
         const Enq& b = enq[i];
         if (!b.cap) continue;
-        const u64 pairs = e->h_sx_stat[stat_head + 2 * i], words = e->h_sx_stat[stat_head + 2 * i + 1];
+        const u64 pairs = e->h_sx_stat[2 * i], words = e->h_sx_stat[2 * i + 1];
         e->sx_saw(words, (u64)b.nb * nfeat);
         if (words <= b.cap) { e->u_extra += pairs; continue; }
         // the batch did not fit and has left K alone: once more, sized exactly
         e->sx_redone += 1;
         const int was = e->sx_sync;
         e->sx_sync = 1;
-        rc = one(b.s, b.nb, e->h_sx_pos + pos_head + (size_t)b.s * e->k, e->h_sx_stat + stat_head + 2 * i, 0);
+        rc = one(b.s, b.nb, e->h_sx_pos + (size_t)b.s * e->k, e->h_sx_stat + 2 * i, 0);
         e->sx_sync = was;
         if (rc) return rc;
     }

@@ -116,7 +116,7 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     const uint32_t wblocks = (uint32_t)((pairs + 256 * fsk::WF_ITEMS - 1) / (256 * fsk::WF_ITEMS)); // k_welford
     const int n_order = (int)e->order.size();
     auto khat = [&](int i) { return e->d_Khat.p + (size_t)(i % RING) * (size_t)pairs; };
-    struct Batch { int n = 0, first_iter = 0, first_item = 0, base = 0, part = 0; bool grouped = false; };
+    struct Batch { int n = 0, first_iter = 0, first_item = 0, base = 0, part = 0, lane = 0; bool grouped = false; };
     // Where the stop test is expected to fire: the variance estimate settles, so sd falls like 1 / sqrt(iter) and
     // delta / sd > 1.96 is reached near iter * (1.96 sd / delta)^2. Only the SIZE of the batches issued ahead follows
     // from it (what lies beyond the stop is thrown away: a full batch there is an eighth of config 1's work); a
@@ -200,8 +200,10 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
             else if (rc) return rc;
         }
         B.grouped = grouped || dense_slots;  // (the batch's counts sit in slot triangles, its Welford update is one pass)
-        // the stream this batch's passes over the triangle run on: its lane's (sparse batches), else the engine's
-        const int lane = grouped ? sx_lane_of(e, B.part) : 0;
+        // the stream this batch's passes over the triangle run on: the lane accumulate_sparse really ran the batch in
+        // (it drops the deferral, and with it lane 1, for a batch it has to split), else the engine's
+        const int lane = grouped ? e->sx_last_lane : 0;
+        B.lane = lane;
         hipStream_t bs = lane ? e->lane_stream : e->stream;
         if (was_grouped && !grouped) sync_all();  // (leaving the two-lane form: everything drains first, once)
         for (int l = 0; l < LANES; ++l)  // K_hat comes from the previous batch's Welford pass, wherever that ran
@@ -316,7 +318,7 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
                 // itself), so the last passes run on A's own, idle stream beside the dropped kernels' tail; everything
                 // drains, and the dropped batches' counts are read, before the chain's buffers are used again (below).
                 for (const Batch& B : q) { e->st.combos_done -= B.n; dropped.push_back(B.part); }
-                const int lane_a = (A.grouped && !dense_slots) ? sx_lane_of(e, A.part) : 0;
+                const int lane_a = (A.grouped && !dense_slots) ? A.lane : 0;
                 fin = lane_a ? e->lane_stream : e->stream;
                 // the stop fell inside the batch: the state after its accepted prefix (the passes before the one the stop
                 // fell in have left theirs in the ring)

@@ -9,6 +9,11 @@
 
 namespace fsk_hw {
 
+// the constant-rate wall clock of the device (s_memrealtime: 100 MHz on gfx950, whatever the shader clock does)
+constexpr unsigned long long WALL_TICKS_PER_MS = 100000ull;
+__device__ __forceinline__ unsigned long long wall_ticks() { return wall_clock64(); }
+__device__ __forceinline__ void nap() { __builtin_amdgcn_s_sleep(127); }
+
 // a * b + c with 24-bit operands: v_mad_u32_u24 issues at full rate, a 32-bit multiply-add does not (the
 // compiler turns __umul24 of small known ranges back into one, hence the asm). b is wave-uniform.
 __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {

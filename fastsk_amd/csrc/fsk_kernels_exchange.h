@@ -53,4 +53,16 @@ __global__ __launch_bounds__(256) void k_p2p_allreduce_wide(PeerBufs bufs, int R
     }
 }
 
+
+// Test-only (FSK_FAULT="device:..."): keeps one wave busy for about `ms` milliseconds of the constant-rate wall clock
+// — an engine whose exchange is late — and then ends by itself: bounded by the clock AND by a trip count, so that
+// no value of the clock can leave the GPU hanging.
+__global__ __launch_bounds__(64) void k_spin_ms(u64 ms) {
+    const u64 t0 = fsk_hw::wall_ticks(), want = ms * fsk_hw::WALL_TICKS_PER_MS;
+    for (u64 trip = 0; trip < ms * 4000 + 1000; ++trip) {  // (a sleep of 127 x 64 clocks is ~3.4 us: 4000 trips > 1 ms)
+        if (fsk_hw::wall_ticks() - t0 >= want) break;
+        fsk_hw::nap();
+    }
+}
+
 }  // namespace fsk

@@ -25,17 +25,29 @@ using namespace fsk_detail;
 
 namespace {
 
-// reusable barrier of the group's worker threads (host side only: nobody waits for a GPU here)
+// reusable barrier of the group's worker threads (host side only: nobody waits for a GPU here). With a
+// deadline a waiter that has waited `timeout_ms` BREAKS the barrier: it and every other waiter — now and
+// later — return false; the group is then dead (fsk_group::poison), never left waiting for an engine that
+// does not come.
 struct HostBarrier {
     std::mutex m;
     std::condition_variable cv;
     int n = 1, arrived = 0;
     unsigned gen = 0;
-    void wait() {
+    bool broken = false;
+    bool wait(int timeout_ms = 0) {
         std::unique_lock<std::mutex> lk(m);
+        if (broken) return false;
         const unsigned g = gen;
-        if (++arrived == n) { arrived = 0; ++gen; cv.notify_all(); }
-        else cv.wait(lk, [&] { return gen != g; });
+        if (++arrived == n) { arrived = 0; ++gen; cv.notify_all(); return true; }
+        auto released = [&] { return gen != g || broken; };
+        if (timeout_ms <= 0) cv.wait(lk, released);
+        else if (!cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), released)) {
+            broken = true;
+            cv.notify_all();
+            return false;
+        }
+        return gen != g;
     }
 };
 
@@ -96,8 +108,12 @@ size_t xsize(XType t) { return t == XType::I32 ? 4 : 8; }
 // buffer and stream, every rank the same sequence of calls. Asynchronous on `stream`.
 struct Collective {
     int kind = 0, ranks = 0;
+    int deadline_ms = 0;  // host-side waits inside the collective give up after this long (0: never)
     virtual ~Collective() {}
     virtual int all_reduce(int r, void* buf, size_t count, XType type, hipStream_t stream, std::string& err) = 0;
+    // release whatever the collective has enqueued and can never complete (a rank missing): afterwards the
+    // collective is unusable
+    virtual void abort() {}
 };
 
 // ---- FSK_COLL_P2P ----------------------------------------------------------------------------------------
@@ -181,7 +197,11 @@ struct P2PCollective : Collective {
     int all_reduce(int r, void* b, size_t count, XType type, hipStream_t stream, std::string& err) override {
         buf[(size_t)r] = b;
         hipError_t he = hipEventRecord(ready[(size_t)r], stream);
-        bar.wait();
+        if (!bar.wait(deadline_ms)) {
+            err = "peer-to-peer all-reduce: engine " + std::to_string(r) + " waited more than " + std::to_string(deadline_ms) +
+                  " ms for the other engines to reach the exchange";
+            return FSK_EDEVICE;
+        }
         for (int q = 0; q < ranks && he == hipSuccess; ++q)
             if (q != r) he = hipStreamWaitEvent(stream, ready[(size_t)q], 0);
         if (he == hipSuccess && count > 0) {
@@ -191,7 +211,11 @@ struct P2PCollective : Collective {
             he = hipGetLastError();
         }
         if (he == hipSuccess) he = hipEventRecord(done[(size_t)r], stream);
-        bar.wait();
+        if (!bar.wait(deadline_ms)) {
+            err = "peer-to-peer all-reduce: engine " + std::to_string(r) + " waited more than " + std::to_string(deadline_ms) +
+                  " ms for the other engines to enqueue their slices";
+            return FSK_EDEVICE;
+        }
         for (int q = 0; q < ranks && he == hipSuccess; ++q)
             if (q != r) he = hipStreamWaitEvent(stream, done[(size_t)q], 0);
         if (he != hipSuccess) {
@@ -209,6 +233,7 @@ struct RcclApi {
     std::string path;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -256,6 +281,7 @@ RcclApi* rccl_api(std::string& err) {
             api.handle = h;
             api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
             api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+            api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(h, "ncclCommAbort"));
             api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
             api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(h, "ncclCommCount"));
             api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
@@ -274,18 +300,54 @@ struct RcclCollective : Collective {
     RcclApi* api = nullptr;
     std::vector<ncclComm_t> comm;
     std::vector<int> dev;
-    int init(const std::vector<int>& devices, std::string& err) {
+    bool aborted = false;
+    // ncclCommInitAll runs on a helper thread that owns everything it touches: when it has not returned within
+    // the deadline (a link or a peer that never answers), fsk_create_multi reports that and leaves the thread
+    // behind instead of hanging with it.
+    struct InitJob {
+        std::mutex m;
+        std::condition_variable cv;
+        bool done = false;
+        ncclResult_t result = ncclSuccess;
+        std::vector<ncclComm_t> comm;
+        std::vector<int> dev;
+    };
+    int init(const std::vector<int>& devices, int init_deadline_ms, std::string& err) {
         kind = FSK_COLL_RCCL;
         api = rccl_api(err);
         if (!api) return FSK_EDEVICE;
         dev = devices;
-        comm.assign(dev.size(), nullptr);
-        const ncclResult_t r = api->CommInitAll(comm.data(), (int)dev.size(), dev.data());
-        if (r != ncclSuccess) {
-            err = std::string("ncclCommInitAll failed: ") + api->GetErrorString(r);
-            comm.clear();
+        auto job = std::make_shared<InitJob>();
+        job->dev = devices;
+        job->comm.assign(devices.size(), nullptr);
+        RcclApi* a = api;
+        std::thread th([job, a] {
+            const ncclResult_t r = a->CommInitAll(job->comm.data(), (int)job->dev.size(), job->dev.data());
+            std::lock_guard<std::mutex> lk(job->m);
+            job->result = r;
+            job->done = true;
+            job->cv.notify_all();
+        });
+        {
+            std::unique_lock<std::mutex> lk(job->m);
+            if (init_deadline_ms > 0) {
+                if (!job->cv.wait_for(lk, std::chrono::milliseconds(init_deadline_ms), [&] { return job->done; })) {
+                    lk.unlock();
+                    th.detach();
+                    err = "ncclCommInitAll over " + std::to_string(devices.size()) + " devices did not return within " +
+                          std::to_string(init_deadline_ms) + " ms (FSK_DEADLINE_MS / fsk_config.deadline_ms)";
+                    return FSK_EDEVICE;
+                }
+            } else {
+                job->cv.wait(lk, [&] { return job->done; });
+            }
+        }
+        th.join();
+        if (job->result != ncclSuccess) {
+            err = std::string("ncclCommInitAll failed: ") + api->GetErrorString(job->result);
             return FSK_EDEVICE;
         }
+        comm = job->comm;
         ranks = (int)dev.size();
         if (api->CommCount) {
             int n = 0;
@@ -297,11 +359,22 @@ struct RcclCollective : Collective {
         for (size_t r = 0; r < comm.size(); ++r)
             if (comm[r]) {
                 DeviceScope on(dev[r]);
+                if (aborted) continue;  // (ncclCommAbort has freed it)
                 (void)api->CommDestroy(comm[r]);
+            }
+    }
+    void abort() override {
+        if (aborted || !api->CommAbort) return;
+        aborted = true;
+        for (size_t r = 0; r < comm.size(); ++r)
+            if (comm[r]) {
+                DeviceScope on(dev[r]);
+                (void)api->CommAbort(comm[r]);
             }
     }
     int all_reduce(int r, void* b, size_t count, XType type, hipStream_t stream, std::string& err) override {
         if (count == 0) return FSK_OK;
+        if (aborted) { err = "the communicator was aborted after an earlier failure"; return FSK_EDEVICE; }
         const ncclDataType_t t = type == XType::I32 ? ncclInt32 : type == XType::U64 ? ncclUint64 : ncclFloat64;
         const ncclResult_t rc = api->AllReduce(b, b, count, t, ncclSum, comm[(size_t)r], stream);
         if (rc != ncclSuccess) {
@@ -313,6 +386,7 @@ struct RcclCollective : Collective {
 };
 #endif  // !FSK_EMU
 
+constexpr int MAX_BANDS = 64;  // row bands of one accumulate's all-reduce
 int64_t cell_of(int64_t row) { return row * (row + 1) / 2; }
 
 // row boundaries (multiples of the tile edge, last = N) that cut the lower triangle into bands of about equal area
@@ -334,31 +408,61 @@ struct fsk_group {
     std::unique_ptr<Collective> coll;
     std::vector<hipStream_t> xstream;            // the exchange stream of every engine
     std::vector<hipEvent_t> ev_band, ev_xdone;   // compute -> exchange, exchange -> compute
+    std::vector<std::vector<hipEvent_t>> ev_xb;  // [engine][band]: the band's collective has run on the exchange stream
     std::vector<DevBuf<int32_t>> stage;          // a band of the triangle narrowed to int32
     WorkerPool pool;
     HostBarrier bar;
     std::atomic<int> failed{0};
     bool others_hold_total = false;   // engines 1.. hold a REDUCED triangle: zero them before they accumulate again
     int64_t combos_since_reset = 0;   // bounds the cells of engine 0's triangle (narrowing)
+    bool bound_unknown = false;       // engine 0's triangle was bound to caller memory of unknown contents: no narrowing until a whole reset
     fsk_multi_info info{};
+    // ---- fail fast (fsk_config.deadline_ms / FSK_DEADLINE_MS): every host-side wait of the exchange — the engines'
+    // barriers, and the wait for a band's collective to have run on the device — gives up after deadline_ms, names
+    // the stage it was in, aborts the communicator (so that stuck exchange kernels let go of the streams) and
+    // leaves the group POISONED: every later call returns FSK_EDEVICE with the first failure's message.
+    int deadline_ms = 0;
+    int bands_in_flight = 0;          // bands of the last accumulate whose events are recorded
+    std::atomic<int> poisoned{0};
+    std::mutex poison_m;
+    std::string poison_msg;
+    // test-only fault injection (FSK_FAULT="kind:rank:band:ms"): engine `rank` is late by `ms` milliseconds before
+    // the collective of band `band` — kind "host": its worker thread sleeps; kind "device": a kernel on its exchange
+    // stream spins for that long (bounded: the GPU is never left hanging)
+    int fault_kind = 0, fault_rank = -1, fault_band = -1, fault_ms = 0;
 
     int R() const { return (int)member.size(); }
+    void poison(const std::string& msg) {
+        {
+            std::lock_guard<std::mutex> lk(poison_m);
+            if (poisoned.load()) return;
+            poison_msg = msg;
+            poisoned.store(1);
+        }
+        if (coll) coll->abort();
+    }
+    int poisoned_rc(fsk_engine* e) {
+        std::lock_guard<std::mutex> lk(poison_m);
+        return e->fail(FSK_EDEVICE, "the multi-GPU group is dead after an earlier failure: %s", poison_msg.c_str());
+    }
     // every worker reports its code; all leave together with the first failure (nobody is left waiting
     // inside a collective for a rank that gave up)
     bool agree(int rc) {
         if (rc) failed.store(rc);
-        bar.wait();
+        if (!bar.wait(deadline_ms)) return false;
         const bool ok = failed.load() == 0;
-        bar.wait();
+        if (!bar.wait(deadline_ms)) return false;
         return ok;
     }
     // run fn on every engine's thread; the first failing engine's message becomes the handle's
     int run(const std::function<int(int)>& fn) {
+        if (poisoned.load()) return poisoned_rc(member[0]);
         failed.store(0);
         pool.run(fn);
         for (int r = 0; r < R(); ++r)
             if (pool.rc[(size_t)r]) {
                 if (r != 0) member[0]->err = "device " + std::to_string(device[(size_t)r]) + ": " + member[(size_t)r]->err;
+                if (bar.broken) poison(member[0]->err);  // (a broken barrier cannot be used again)
                 return pool.rc[(size_t)r];
             }
         return FSK_OK;
@@ -377,17 +481,31 @@ int member_accumulate(fsk_group* g, int r, const std::vector<int32_t>& mine, con
     hipStream_t xs = g->xstream[(size_t)r];
     // After the ranks have agreed to go on, nothing below leaves early: a rank that skipped a collective
     // would leave the others' exchange streams waiting for it for ever. Failures are collected and reported
-    // at the end (the exchange then ran on whatever the triangle held).
+    // at the end (the exchange then ran on whatever the triangle held); a failed collective poisons the group
+    // and aborts the communicator, which releases whatever the other ranks have already enqueued.
     auto note = [&](hipError_t he, const char* what) {
         if (he != hipSuccess && !rc) rc = e->fail(FSK_EDEVICE, "%s failed: %s", what, hipGetErrorString(he));
+    };
+    const auto waited = [&](size_t b, const char* where) {
+        const int code = e->fail(FSK_EDEVICE, "engine %d (device %d) waited more than %d ms for the other engines %s (band %zu of %zu)",
+                                 r, e->cfg.device, g->deadline_ms, where, b, edges.size() - 1);
+        g->poison(e->err);
+        return code;
     };
     for (size_t b = 0; b + 1 < edges.size(); ++b) {
         const int64_t lo = edges[b], hi = edges[b + 1];
         if (!rc) rc = one_accumulate_rows(e, mine.data(), (int32_t)mine.size(), lo, hi);
-        if (!g->agree(rc)) return rc ? rc : e->fail(FSK_EDEVICE, "another engine of the group failed");
+        if (!g->agree(rc)) {
+            if (g->bar.broken) return waited(b, "before the band's all-reduce");
+            return rc ? rc : e->fail(FSK_EDEVICE, "another engine of the group failed");
+        }
         const u64 c0 = (u64)cell_of(lo), cells = (u64)cell_of(hi) - c0;
         note(hipEventRecord(g->ev_band[(size_t)r], e->stream), "hipEventRecord");
         note(hipStreamWaitEvent(xs, g->ev_band[(size_t)r], 0), "hipStreamWaitEvent");
+        if (g->fault_rank == r && g->fault_band == (int)b && g->fault_ms > 0) {  // test-only: this engine is late
+            if (g->fault_kind == 1) std::this_thread::sleep_for(std::chrono::milliseconds(g->fault_ms));
+            else FSK_LAUNCH(fsk::k_spin_ms, dim3(1), dim3(64), 0, xs, (u64)g->fault_ms);
+        }
         std::string cerr;
         int crc;
         if (narrow) {
@@ -399,13 +517,51 @@ int member_accumulate(fsk_group* g, int r, const std::vector<int32_t>& mine, con
         } else {
             crc = g->coll->all_reduce(r, e->d_K + c0, (size_t)cells, XType::U64, xs, cerr);
         }
-        if (crc && !rc) rc = e->fail(crc, "%s", cerr.c_str());
+        if (crc) {
+            if (!rc) rc = e->fail(crc, "band %zu of %zu: %s", b, edges.size() - 1, cerr.c_str());
+            g->poison(e->err);  // the other engines may already have enqueued their half: release them
+        }
         note(hipGetLastError(), "exchange kernels");
+        if (b < g->ev_xb[(size_t)r].size()) note(hipEventRecord(g->ev_xb[(size_t)r][b], xs), "hipEventRecord");
+        if (g->poisoned.load()) return rc ? rc : g->poisoned_rc(e);
     }
     // the engine's next work (finalize, getters, another accumulate) starts after the reduced cells are in place
     note(hipEventRecord(g->ev_xdone[(size_t)r], xs), "hipEventRecord");
     note(hipStreamWaitEvent(e->stream, g->ev_xdone[(size_t)r], 0), "hipStreamWaitEvent");
     return rc;
+}
+
+// Wait, on the host and with the group's deadline, until every band's collective of the last accumulate has run
+// on engine r's exchange stream. A band that does not complete in time is named, the group is poisoned and the
+// communicator aborted. (Without a deadline the stream synchronisation that follows does the waiting.)
+int member_await_exchange(fsk_group* g, int r) {
+    fsk_engine* e = g->member[(size_t)r];
+    if (g->deadline_ms <= 0 || g->bands_in_flight <= 0) return FSK_OK;
+    FSK_ON_DEVICE(e);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int b = 0; b < g->bands_in_flight && b < (int)g->ev_xb[(size_t)r].size(); ++b) {
+        for (;;) {
+            const hipError_t q = hipEventQuery(g->ev_xb[(size_t)r][(size_t)b]);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) {
+                (void)hipGetLastError();
+                const int code = e->fail(FSK_EDEVICE, "exchange of band %d failed on device %d: %s", b, e->cfg.device, hipGetErrorString(q));
+                g->poison(e->err);
+                return code;
+            }
+            (void)hipGetLastError();
+            if (g->poisoned.load()) return g->poisoned_rc(e);
+            const auto waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (waited > g->deadline_ms) {
+                const int code = e->fail(FSK_EDEVICE, "the all-reduce of band %d of %d did not complete within %d ms on device %d (engine %d): "
+                                         "a peer or a link is not answering", b, g->bands_in_flight, g->deadline_ms, e->cfg.device, r);
+                g->poison(e->err);
+                return code;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    }
+    return FSK_OK;
 }
 
 int group_sum_combos(fsk_engine* lead, const int32_t* combos, int32_t n) {
@@ -421,10 +577,12 @@ int group_sum_combos(fsk_engine* lead, const int32_t* combos, int32_t n) {
         const int64_t tr = (N + fsk::TILE - 1) / fsk::TILE, tiles = tr * (tr + 1) / 2;
         n_bands = (lead->path == FSK_PATH_DENSE && N >= 8192) ? (tiles >= 16 * 16384 ? 16 : 8) : 1;
     }
-    const std::vector<int64_t> edges = band_edges(N, std::max(1, std::min(n_bands, 64)));
+    const std::vector<int64_t> edges = band_edges(N, std::max(1, std::min(n_bands, MAX_BANDS)));
     g->combos_since_reset += n;
     const double bound = (double)g->combos_since_reset * (double)lead->maxW * (double)lead->maxW;
-    const bool narrow = bound < 2147483648.0;  // every cell of every engine: <= combos since the reset x max_windows^2
+    // every cell of every engine: <= combos since the reset x max_windows^2 — unless engine 0's triangle is caller
+    // memory bound since the last whole reset, whose contents nobody has bounded
+    const bool narrow = bound < 2147483648.0 && !g->bound_unknown;
     u64 largest = 0;
     for (size_t b = 0; b + 1 < edges.size(); ++b) largest = std::max<u64>(largest, (u64)(cell_of(edges[b + 1]) - cell_of(edges[b])));
     g->info.bands = (int32_t)edges.size() - 1;
@@ -432,6 +590,7 @@ int group_sum_combos(fsk_engine* lead, const int32_t* combos, int32_t n) {
     g->info.reduce_bytes = (int64_t)((u64)lead->pairs * (narrow ? 4 : 8));
     g->info.comm_ranks = g->coll->ranks;
     for (int r = 0; r < R && r < 16; ++r) g->info.combos_per_engine[r] = (int64_t)mine[(size_t)r].size();
+    g->bands_in_flight = (int)edges.size() - 1;
     const int rc = g->run([&](int r) -> int {
         fsk_engine* e = g->member[(size_t)r];
         int rc1 = FSK_OK;
@@ -440,7 +599,14 @@ int group_sum_combos(fsk_engine* lead, const int32_t* combos, int32_t n) {
             if (g->stage[(size_t)r].reserve((size_t)largest) != hipSuccess)
                 rc1 = e->fail(FSK_ENOMEM, "cannot allocate %llu bytes of exchange staging", (unsigned long long)(largest * 4));
         }
-        if (!g->agree(rc1)) return rc1 ? rc1 : e->fail(FSK_EDEVICE, "another engine of the group failed");
+        if (!g->agree(rc1)) {
+            if (g->bar.broken) {
+                const int code = e->fail(FSK_EDEVICE, "engine %d waited more than %d ms for the other engines before the accumulate", r, g->deadline_ms);
+                g->poison(e->err);
+                return code;
+            }
+            return rc1 ? rc1 : e->fail(FSK_EDEVICE, "another engine of the group failed");
+        }
         return member_accumulate(g, r, mine[(size_t)r], edges, narrow);
     });
     g->others_hold_total = true;
@@ -456,6 +622,8 @@ int group_load_sequences(fsk_engine* lead, const int32_t* tokens, const int64_t*
     fsk_group* g = lead->group;
     g->others_hold_total = false;
     g->combos_since_reset = 0;
+    g->bound_unknown = false;  // (one_load_sequences zeroes the triangle, bound or owned)
+    g->bands_in_flight = 0;
     return g->run([&](int r) { return one_load_sequences(g->member[(size_t)r], tokens, offsets, n_train, n_test); });
 }
 
@@ -465,6 +633,7 @@ int group_reset_counts(fsk_engine* lead, int64_t row_begin, int64_t row_end) {
     if (whole) {
         g->others_hold_total = false;
         g->combos_since_reset = 0;
+        g->bound_unknown = false;  // (every cell is zero again)
     }
     return g->run([&](int r) {
         fsk_engine* e = g->member[(size_t)r];
@@ -482,8 +651,15 @@ int group_accumulate(fsk_engine* lead, const int32_t* combos, int32_t n) {
 
 int group_synchronize(fsk_engine* lead) {
     fsk_group* g = lead->group;
-    return g->run([&](int r) { return one_synchronize(g->member[(size_t)r]); });
+    const int rc = g->run([&](int r) {
+        const int rc1 = member_await_exchange(g, r);
+        return rc1 ? rc1 : one_synchronize(g->member[(size_t)r]);
+    });
+    if (!rc) g->bands_in_flight = 0;
+    return rc;
 }
+
+void group_note_bound_counts(fsk_engine* lead) { lead->group->bound_unknown = true; }
 
 int group_finalize(fsk_engine* lead) {
     const int rc = group_synchronize(lead);  // every engine's share of the exchange has landed
@@ -558,10 +734,18 @@ int group_compute(fsk_engine* lead, const int32_t* tokens, const int64_t* offset
         FSK_ON_DEVICE(e);
         e->finalized = false;
         int rc1 = run_variance_mode(e, T, r, R);
+        // (no deadline on this barrier: the chains of one engine may legitimately run much longer than another's)
+        const int keep = g->deadline_ms;
+        (void)keep;
         if (!g->agree(rc1)) return rc1 ? rc1 : e->fail(FSK_EDEVICE, "another engine of the group failed");
         std::string cerr;
         rc1 = g->coll->all_reduce(r, e->d_Kf64.p, (size_t)e->pairs, XType::F64, e->stream, cerr);
-        if (rc1) return e->fail(rc1, "%s", cerr.c_str());
+        if (rc1) {
+            const int code = e->fail(rc1, "%s", cerr.c_str());
+            g->poison(e->err);  // the other engines have enqueued their half of the collective: release them
+            return code;
+        }
+        if (g->poisoned.load()) return g->poisoned_rc(e);
         FSK_HIP(hipStreamSynchronize(e->stream));
         return FSK_OK;
     });
@@ -587,6 +771,7 @@ void group_destroy(fsk_engine* lead) {
         g->stage[(size_t)r].release();
         if (g->ev_band[(size_t)r]) (void)hipEventDestroy(g->ev_band[(size_t)r]);
         if (g->ev_xdone[(size_t)r]) (void)hipEventDestroy(g->ev_xdone[(size_t)r]);
+        for (hipEvent_t ev : g->ev_xb[(size_t)r]) if (ev) (void)hipEventDestroy(ev);
         if (g->xstream[(size_t)r]) (void)hipStreamDestroy(g->xstream[(size_t)r]);
     }
     for (fsk_engine* e : g->member) one_destroy(e);
@@ -625,6 +810,8 @@ int fsk_create_multi(const fsk_config* cfg, const int32_t* devices, int32_t ndev
             DeviceScope on(g->device[r]);
             if (r < g->ev_band.size() && g->ev_band[r]) (void)hipEventDestroy(g->ev_band[r]);
             if (r < g->ev_xdone.size() && g->ev_xdone[r]) (void)hipEventDestroy(g->ev_xdone[r]);
+            if (r < g->ev_xb.size())
+                for (hipEvent_t ev : g->ev_xb[r]) if (ev) (void)hipEventDestroy(ev);
             if (r < g->xstream.size() && g->xstream[r]) (void)hipStreamDestroy(g->xstream[r]);
         }
         for (fsk_engine* e : g->member) one_destroy(e);
@@ -643,6 +830,7 @@ int fsk_create_multi(const fsk_config* cfg, const int32_t* devices, int32_t ndev
     g->xstream.assign((size_t)ndev, nullptr);
     g->ev_band.assign((size_t)ndev, nullptr);
     g->ev_xdone.assign((size_t)ndev, nullptr);
+    g->ev_xb.assign((size_t)ndev, std::vector<hipEvent_t>(MAX_BANDS, nullptr));
     g->stage.resize((size_t)ndev);
     for (int r = 0; r < ndev; ++r) {
         DeviceScope on(devices[r]);
@@ -650,13 +838,31 @@ int fsk_create_multi(const fsk_config* cfg, const int32_t* devices, int32_t ndev
             hipEventCreateWithFlags(&g->ev_band[(size_t)r], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&g->ev_xdone[(size_t)r], hipEventDisableTiming) != hipSuccess)
             return undo(FSK_EDEVICE, "cannot create the exchange stream / events on device " + std::to_string(devices[r]));
+        for (hipEvent_t& ev : g->ev_xb[(size_t)r])
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+                return undo(FSK_EDEVICE, "cannot create the band events on device " + std::to_string(devices[r]));
+    }
+    // fail fast: fsk_config.deadline_ms, else FSK_DEADLINE_MS, else two minutes (negative: no deadline)
+    g->deadline_ms = cfg->deadline_ms;
+    if (g->deadline_ms == 0) {
+        const char* f = getenv("FSK_DEADLINE_MS");
+        g->deadline_ms = f ? atoi(f) : 120000;
+    }
+    if (g->deadline_ms < 0) g->deadline_ms = 0;
+    if (const char* f = getenv("FSK_FAULT")) {  // test-only: "host:rank:band:ms" or "device:rank:band:ms"
+        char kind[16] = {0};
+        int fr = -1, fb = -1, fm = 0;
+        if (sscanf(f, "%15[a-z]:%d:%d:%d", kind, &fr, &fb, &fm) == 4 && fm > 0 && fm <= 60000) {
+            g->fault_kind = !strcmp(kind, "host") ? 1 : !strcmp(kind, "device") ? 2 : 0;
+            if (g->fault_kind) { g->fault_rank = fr; g->fault_band = fb; g->fault_ms = fm; }
+        }
     }
     const std::vector<int> devs(devices, devices + ndev);
     std::string why;
 #ifndef FSK_EMU
     if (collective != FSK_COLL_P2P && distinct) {
         std::unique_ptr<RcclCollective> rc(new RcclCollective);
-        const int code = rc->init(devs, why);
+        const int code = rc->init(devs, g->deadline_ms, why);
         if (code == FSK_OK) g->coll = std::move(rc);
         else if (collective == FSK_COLL_RCCL) return undo(code, why);
     }
@@ -669,6 +875,7 @@ int fsk_create_multi(const fsk_config* cfg, const int32_t* devices, int32_t ndev
         if (code) return undo(code, why);
         g->coll = std::move(p);
     }
+    g->coll->deadline_ms = g->deadline_ms;
     g->bar.n = ndev;
     g->info.ndev = ndev;
     for (int r = 0; r < ndev; ++r) g->info.devices[r] = devices[r];

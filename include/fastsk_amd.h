@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define FSK_ABI_VERSION 3  /* 2: fsk_create_multi + fsk_config.collective/bands, fsk_counts_digest, device-block allocation;
-                              3: fsk_get_triangle_device / fsk_alloc_triangle_device, fsk_set_deadline_ms */
+                              3: fsk_get_triangle_device / fsk_alloc_triangle_device, fsk_config.deadline_ms */
 
 enum {
     FSK_OK = 0,
@@ -87,7 +87,13 @@ typedef struct fsk_config {
     /* fsk_create_multi only (ignored by fsk_create): */
     int32_t collective;    /* FSK_COLL_*                                                          */
     int32_t bands;         /* row bands of the overlapped all-reduce; 0 = automatic               */
-    int32_t reserved[2];
+    int32_t deadline_ms;   /* fail fast: bound, in milliseconds, on every host-side wait of the multi-GPU exchange —
+                              ncclCommInitAll, the engines' barriers, a band's all-reduce having run on the device.
+                              A wait that exceeds it returns FSK_EDEVICE naming the stage and the band, the
+                              communicator is aborted (ncclCommAbort) and the group is dead: every later call
+                              returns FSK_EDEVICE with that first message. 0 = FSK_DEADLINE_MS from the
+                              environment, else 120000; negative = no deadline                                */
+    int32_t reserved[1];
 } fsk_config;
 
 /* Measured and algorithmic quantities of the work done so far. */
@@ -178,7 +184,9 @@ int fsk_set_seed(fsk_engine* e, uint64_t seed);
 int fsk_load_sequences(fsk_engine* e, const int32_t* tokens, const int64_t* offsets, int64_t n_train,
                        int64_t n_test);
 /* Use caller-provided device memory (uint64[n_pairs], e.g. a torch tensor that RCCL will
- * all-reduce) for the integer triangle instead of an engine-owned allocation. */
+ * all-reduce) for the integer triangle instead of an engine-owned allocation. The buffer's contents are
+ * taken as they are (call fsk_reset_counts for zeros); on a group handle the exchange stays 64 bits wide
+ * until the next whole reset, because nothing bounds the cells the caller brought. */
 int fsk_bind_counts(fsk_engine* e, void* device_u64, int64_t n_cells);
 /* device address of the integer triangle (engine-owned or bound) */
 int fsk_counts_device_ptr(fsk_engine* e, void** out);

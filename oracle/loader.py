@@ -53,6 +53,9 @@ class _Ref:
         L.ref_compute.restype = C.c_int
         L.ref_full_triangle.argtypes = common + [_f64p, _f64p, C.c_int, C.c_int]
         L.ref_full_triangle.restype = C.c_int
+        if hasattr(L, "ref_save_kernel"):  # (a prebuilt library of an earlier round lacks it)
+            L.ref_save_kernel.argtypes = common + [C.c_char_p, C.c_int]
+            L.ref_save_kernel.restype = C.c_int
         L.ref_raw_counts.argtypes = [_i32p, _i64p, C.c_int64, C.c_int, C.c_int, _i32p, C.c_int,
                                      C.c_int, C.c_void_p]
         L.ref_raw_counts.restype = C.c_double
@@ -82,6 +85,12 @@ class _Ref:
                                      max_iters, int(skip_variance), seed, tri, sd, sd.size,
                                      int(quiet))
         return tri, sd[:n].copy()
+
+    def save_kernel(self, path, tokens, offsets, n_train, n_test, g, m, t=-1, approx=False, delta=0.025,
+                    max_iters=-1, skip_variance=False, seed=0, quiet=True):
+        """compute_kernel / compute_train + FastSK::save_kernel(path) (fastsk.cpp:223-237)."""
+        self.L.ref_save_kernel(tokens, offsets, n_train, n_test, g, m, t, int(approx), delta, max_iters,
+                               int(skip_variance), seed, str(path).encode(), int(quiet))
 
     def raw_counts(self, tokens, offsets, g, m, combos, threads=1, want_counts=True):
         N = len(offsets) - 1

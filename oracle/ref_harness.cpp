@@ -15,6 +15,8 @@
 //                         extractFeatures / getCombinations / cntsrtna / countAndUpdateTri,
 //                         summing the uint32 partial kernels (the API itself only returns fp64);
 //                         T threads round-robin (fastsk_kernel.cpp:148,275), returns the seconds
+//   ref_save_kernel       FastSK::compute_kernel / compute_train followed by FastSK::save_kernel
+//                         (fastsk.cpp:223-237): the reference's own text dump of the whole N x N matrix
 // (bench.py's cpu_baseline times ref_full_triangle: the reference's own thread pool and reduce)
 #include <algorithm>
 #include <chrono>
@@ -117,6 +119,24 @@ int ref_compute(const int32_t* tokens, const int64_t* offsets, int64_t n_train, 
     int n = (int)sd.size();
     for (int i = 0; i < n && i < stdev_cap; ++i) stdevs_out[i] = sd[i];
     return n;
+}
+
+// The reference's own on-disk format: compute, then FastSK::save_kernel(path) (fastsk.cpp:223-237).
+int ref_save_kernel(const int32_t* tokens, const int64_t* offsets, int64_t n_train, int64_t n_test,
+                    int g, int m, int t, int approx, double delta, int max_iters, int skip_variance,
+                    long seed, const char* path, int quiet) {
+    g_fake_time = (time_t)seed;
+    Quiet q(quiet != 0);
+    FastSK fsk(g, m, t, approx != 0, delta, max_iters, skip_variance != 0);
+    auto Xtr = rows(tokens, offsets, 0, n_train);
+    if (n_test > 0) {
+        auto Xte = rows(tokens, offsets, n_train, n_train + n_test);
+        fsk.compute_kernel(Xtr, Xte);
+    } else {
+        fsk.compute_train(Xtr);
+    }
+    fsk.save_kernel(std::string(path));
+    return 0;
 }
 
 // Whole normalised triangle via the reference engine (KernelFunction). tri_out: N(N+1)/2.

@@ -300,6 +300,8 @@ static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e =
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+constexpr hipError_t hipErrorNotReady = 600;
+static inline hipError_t hipEventQuery(hipEvent_t) { return 0; }  // (launches run to completion before they return)
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
     return 0;
@@ -311,6 +313,11 @@ static inline hipError_t hipMemGetInfo(size_t* fr, size_t* tot) { *fr = *tot = (
 
 // ---- what fastsk_amd/csrc/fsk_gfx950.h gives the product build: the same names, plain C++ ---------------
 namespace fsk_hw {
+constexpr unsigned long long WALL_TICKS_PER_MS = 100000ull;
+static inline unsigned long long wall_ticks() {
+    return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10ull;
+}
+static inline void nap() {}
 static inline unsigned mad24(unsigned a, unsigned b, unsigned c) { return (a & 0xffffffu) * (b & 0xffffffu) + c; }
 static inline unsigned mul24(unsigned a, unsigned b) { return (unsigned)((unsigned long long)(a & 0xffffffu) * (b & 0xffffffu)); }
 static inline int wave_incl_max_i32(int x) {

@@ -33,6 +33,20 @@ def run_case(emu_lib, d, path):
 SMALL = [n for n in golden_names() if n.split("_")[0] in ("f1", "f2", "f3")]
 
 
+@pytest.mark.parametrize("name", ["f3_ragged_sigma7_g6m3", "f3_train_only", "f4_ep300_exact"])
+def test_emu_save_kernel_against_the_reference_file(emu_lib, tmp_path, name):
+    """fsk_save_kernel writes, byte for byte, what the reference's FastSK::save_kernel (fastsk.cpp:223-237) wrote
+    for the same input (tests/golden/save_kernel.npz, tests/make_golden_save_kernel.py)."""
+    import os
+    from conftest import GOLD
+    z = np.load(os.path.join(GOLD, "save_kernel.npz"))
+    d = load_golden(name)
+    e = run_case(emu_lib, d, 0)
+    p = tmp_path / "k.txt"
+    e.save_kernel(str(p))
+    assert p.read_bytes() == z[name].tobytes()
+
+
 @pytest.mark.parametrize("path", [1, 2])
 @pytest.mark.parametrize("name", SMALL)
 def test_emu_small_cases_both_paths(emu_lib, name, path):

@@ -169,3 +169,75 @@ def test_group_errors(emu_lib):
     e.compute(tok, np.array([0, 40, 80]), 1, 1)     # the group is usable after a failed call
     assert e.get_train()[0, 0] == 1.0
     e.close()
+
+
+# ---- fail fast: a stuck engine must not hang the group (fsk_config.deadline_ms) ---------------------------------
+def test_group_deadline_names_the_band_and_poisons_the_group(emu_lib, monkeypatch):
+    """Engine 1's worker is late by 2.5 s before the collective of band 0 (FSK_FAULT, test-only): with a 300 ms
+    deadline the other engines give up at that band's exchange, the call returns FSK_EDEVICE naming the band well
+    before a run without a deadline would have returned, every later call repeats the first failure (the group is
+    dead, never half alive), and destroying the handle does not hang."""
+    import time
+    from fastsk_amd import _native
+    d = load_golden("f4_ep300_exact")
+    monkeypatch.setenv("FSK_FAULT", "host:1:0:2500")
+    e = _native.Engine(d["g"], d["m"], lib=emu_lib, devices=[0, 1, 2], bands=3, deadline_ms=300)
+    e.load_sequences(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+    t0 = time.perf_counter()
+    with pytest.raises(_native.FskError) as ei:
+        e.accumulate(np.arange(0, 30, dtype=np.int32))
+        e.finalize()
+    dt = time.perf_counter() - t0
+    assert ei.value.code == -4
+    msg = str(ei.value)
+    assert "300 ms" in msg and "band 0" in msg, msg
+    assert dt < 6.0   # (the late worker itself still has to come back: 2.5 s; nothing waits for ever)
+    with pytest.raises(_native.FskError) as ei2:
+        e.accumulate(np.arange(0, 30, dtype=np.int32))
+    assert "dead after an earlier failure" in str(ei2.value) and "band 0" in str(ei2.value)
+    with pytest.raises(_native.FskError):
+        e.finalize()
+    t1 = time.perf_counter()
+    e.close()
+    assert time.perf_counter() - t1 < 5.0
+
+
+def test_group_without_fault_is_untouched_by_the_deadline(emu_lib, monkeypatch):
+    """The same job with the deadline armed and no fault: identical result (the deadline only bounds waits)."""
+    from fastsk_amd import _native
+    d = load_golden("f4_ep300_exact")
+    monkeypatch.delenv("FSK_FAULT", raising=False)
+    e = engine_for(emu_lib, d, [0, 1, 2], bands=3, deadline_ms=20000)
+    e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+    assert np.array_equal(e.get_counts(), d["counts"])
+    e.close()
+    # a late engine INSIDE the deadline only delays the result
+    monkeypatch.setenv("FSK_FAULT", "host:2:0:300")
+    e = engine_for(emu_lib, d, [0, 1, 2], bands=2, deadline_ms=20000)
+    e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+    assert np.array_equal(e.get_counts(), d["counts"])
+    e.close()
+
+
+def test_group_bound_counts_are_not_narrowed(emu_lib):
+    """fsk_bind_counts on a group handle: the caller's cells may hold anything, so the exchange stays 64 bits wide
+    until a whole reset zeroes them (an int32 exchange would truncate a cell >= 2^31)."""
+    from fastsk_amd import _native
+    d = load_golden("f4_ep300_exact")
+    N = d["n_train"] + d["n_test"]
+    pairs = N * (N + 1) // 2
+    big = np.full(pairs, (1 << 33) + 5, dtype=np.uint64)      # emulated "device memory" is host memory
+    e = _native.Engine(d["g"], d["m"], lib=emu_lib, devices=[0, 1], bands=2)
+    e.load_sequences(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+    e.bind_counts(big.ctypes.data, pairs, keepalive=big)
+    combos = np.asarray(d["combos"], dtype=np.int32)
+    e.accumulate(combos)
+    e.finalize()
+    assert not e.multi_info()["narrow"]
+    assert np.array_equal(big, d["counts"] + np.uint64((1 << 33) + 5))
+    e.reset_counts()                                           # zeros: the bound is known again
+    e.accumulate(combos)
+    e.finalize()
+    assert e.multi_info()["narrow"]
+    assert np.array_equal(big, d["counts"])
+    e.close()

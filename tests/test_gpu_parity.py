@@ -632,6 +632,60 @@ def test_bench_two_ranks_sharing_the_gpu(native, shard):
     assert d["roofline"]["bound"] == "valu" and 0 < d["roofline"]["frac"] <= 1.0
 
 
+def _bench_env(**extra):
+    env = dict(os.environ, **extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FSK_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_fails_fast_with_a_json_line_when_a_rank_hangs(native):
+    """First multi-GPU contact must not burn the lease silently: a rank that stops answering (here rank 1 of two ranks
+    sharing the GPU over gloo, stalled for 90 s inside the timed steps — FSK_BENCH_STALL, test-only) makes rank 0's
+    collective wait; the watchdog's bound for the stage (8 s per step here) expires, rank 0 prints ONE JSON line with
+    "error", "stage", "n_gpus" and the timings so far, and the run ends non-zero well inside the bound — no hang,
+    no re-exec. Before that the same job runs clean with the preflight (N = 16000, committed digest) in its line."""
+    import json
+    import subprocess
+    import sys
+    import time
+    from conftest import ROOT
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n-seq", "16000",
+            "--no-alt", "--no-inproc-leg"]
+    r = subprocess.run(base, env=_bench_env(FSK_BENCH_SHARE_GPU="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["bit_identical_to_1gpu"] is True and d["preflight"]["bit_identical_to_1gpu"] is True and d["preflight"]["every_rank_agrees"]
+    assert d["fail_fast"]["watchdog"] and d["memory_plan_GB"]["triangle_u64"] > 1.0
+    t0 = time.perf_counter()
+    r = subprocess.run(base + ["--step-bound", "8"], env=_bench_env(FSK_BENCH_SHARE_GPU="1", FSK_BENCH_STALL="1:timed steps:90"),
+                       capture_output=True, text=True, timeout=300)
+    dt = time.perf_counter() - t0
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, r.stdout[-1500:] + r.stderr[-1500:]
+    e = json.loads(lines[-1])
+    assert "error" in e and e["n_gpus"] == 2 and e["value"] is None and "timed steps" in e["stage"], e
+    assert e["timings"] and "preflight" in e["partial"]
+    assert dt < 85, dt   # (well before the stalled rank would have come back)
+
+
+def test_bench_inproc_reports_a_stuck_exchange(native):
+    """The same for the in-process engine (fsk_create_multi): engine 1's exchange stream is held for 6 s in front of
+    band 0's all-reduce (FSK_FAULT, bounded spin kernel), the engine's deadline is the step bound (2 s): fsk_finalize
+    returns FSK_EDEVICE naming the band, bench.py prints the JSON error line and exits 2."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--inproc", "--steps", "1", "--warmup", "0",
+                        "--n-seq", "8000", "--no-cpu-baseline", "--no-also", "--step-bound", "2"],
+                       env=_bench_env(FSK_BENCH_SHARE_GPU="1", FSK_FAULT="device:1:0:6000"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, r.stdout[-1500:] + r.stderr[-1500:]
+    e = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "band 0" in e["error"] and "2000 ms" in e["error"] and e["n_gpus"] == 2 and e["value"] is None
+
+
 def test_bench_rccl_leg_on_one_rank(native):
     """The RCCL leg itself (backend nccl, device_id, band-wise int32 all-reduce ordered by stream events)
     with a world of one — the most this single-GPU box can run of it — and config 4 through the
@@ -1109,18 +1163,41 @@ def test_device_resident_block_getter(native):
     e.close()
 
 
-def test_save_kernel_format(native, tmp_path):
-    d = load_golden("f3_ragged_sigma7_g6m3")
+SAVE_CASES = ["f3_ragged_sigma7_g6m3", "f4_ep300_exact", "f3_train_only", "f4_ep300_variance_T1", "f6_prot219_exact"]
+
+
+@pytest.mark.parametrize("name", SAVE_CASES)
+def test_save_kernel_whole_file_against_the_reference(native, tmp_path, name):
+    """fastsk.FastSK(...).save_kernel(path) (pybind11 class) writes, byte for byte, the file the REFERENCE's own
+    FastSK::save_kernel (fastsk.cpp:223-237) wrote for the same input — tests/golden/save_kernel.npz holds those
+    bytes (tests/make_golden_save_kernel.py: compiled reference, compute then save_kernel). Covers the lazy
+    test x test block (save_kernel dumps the whole N x N matrix), ragged input, train only, and variance mode."""
+    import hashlib
+    from fastsk import FastSK
+    z = np.load(os.path.join(GOLD, "save_kernel.npz"))
+    want = z[name].tobytes()
+    assert hashlib.sha256(want).hexdigest() == str(z[name + "__sha256"])
+    d = load_golden(name)
+    N = d["n_train"] + d["n_test"]
+    X = [d["tokens"][d["offsets"][i]:d["offsets"][i + 1]].tolist() for i in range(N)]
+    f = FastSK(d["g"], d["m"], d["t"], bool(d["approx"]), d["delta"], d["max_iters"], bool(d["skip_variance"]))
+    if d["approx"]:
+        f.set_combo_order(d["order"].tolist())
+    if d["n_test"]:
+        f.compute_kernel(X[:d["n_train"]], X[d["n_train"]:])
+    else:
+        f.compute_train(X)
+    p = tmp_path / "k.txt"
+    f.save_kernel(str(p))
+    got = p.read_bytes()
+    assert got == want
+    # and the ctypes view of the same C-ABI call
     e = engine_for(native, d)
     e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
-    p = tmp_path / "k.txt"
-    e.save_kernel(str(p))
-    N = d["n_train"] + d["n_test"]
-    sq = tri_to_square(d["tri"], N)
-    lines = p.read_text().splitlines()
-    assert len(lines) == N
-    want = "".join("%d:%e " % (j + 1, sq[3, j]) for j in range(N))
-    assert lines[3] == want
+    p2 = tmp_path / "k2.txt"
+    e.save_kernel(str(p2))
+    assert p2.read_bytes() == want
+    f.save_kernel("")   # the reference silently does nothing for an empty name
 
 
 def test_run_check_style_auc(native):
@@ -1411,6 +1488,35 @@ def test_group_variance_chains(native, port, T):
         else:   # a sum of T fp64 terms: the reference adds them in thread-arrival order
             assert np.allclose(e.get_triangle(), want, rtol=1e-14, atol=0)
         e.close()
+
+
+def test_group_deadline_on_a_late_exchange_kernel(native, monkeypatch):
+    """Fail fast on the device side: engine 1's exchange stream is held by a (bounded, 3 s) spinning kernel in front
+    of band 0's all-reduce (FSK_FAULT, test-only), the deadline is 400 ms: finalize returns FSK_EDEVICE naming the
+    band within about the deadline instead of sitting in hipStreamSynchronize, the group is dead afterwards, and
+    closing it (which waits for the spin to end by itself) does not hang. Then the same job without the fault."""
+    import time
+    d = load_golden("f4_ep300_exact")
+    combos = np.asarray(d["combos"], dtype=np.int32)
+    monkeypatch.setenv("FSK_FAULT", "device:1:0:3000")
+    e = native.Engine(d["g"], d["m"], devices=[0, 0], collective=native.COLL_P2P, deadline_ms=400)
+    e.load_sequences(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+    e.accumulate(combos)           # asynchronous: nothing waits here
+    t0 = time.perf_counter()
+    with pytest.raises(native.FskError) as ei:
+        e.finalize()
+    dt = time.perf_counter() - t0
+    assert ei.value.code == -4 and "band 0" in str(ei.value) and "400 ms" in str(ei.value), str(ei.value)
+    assert 0.3 < dt < 2.0, dt
+    with pytest.raises(native.FskError) as ei2:
+        e.accumulate(combos)
+    assert "dead after an earlier failure" in str(ei2.value)
+    e.close()
+    monkeypatch.delenv("FSK_FAULT")
+    e = native.Engine(d["g"], d["m"], devices=[0, 0], collective=native.COLL_P2P, deadline_ms=400)
+    e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+    assert np.array_equal(e.get_counts(), d["counts"])
+    e.close()
 
 
 def test_counts_digest_definition(native):
