@@ -292,6 +292,7 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     { const char* f = getenv("FSK_COMPACT"); e->force_compact = f ? atoi(f) : -1; }
     { const char* f = getenv("FSK_SPARSE_GLOBAL"); e->force_global_pairs = f ? atoi(f) : 0; }
     { const char* f = getenv("FSK_VARIANCE_DENSE_SLOTS"); if (f) e->variance_dense_slots = atoi(f); }
+    { const char* f = getenv("FSK_VAR_AHEAD"); if (f && atoi(f) > 0) e->var_ahead = atoi(f); }
     { const char* f = getenv("FSK_SEG_SCAN_CHUNKED"); if (f) e->force_seg_chunks = atoi(f); }
     { const char* f = getenv("FSK_SPARSE_SYNC"); if (f) e->sx_sync = atoi(f); }
     { const char* f = getenv("FSK_SPARSE_GUARD_CAP"); if (f && atoll(f) > 0) e->sx_guard_cap = (u64)atoll(f); }
@@ -644,8 +645,8 @@ int fsk_detail::one_load_sequences(fsk_engine* e, const int32_t* tokens, const i
     } else {
         FSK_HIP(hipMemsetAsync(e->d_K, 0, (size_t)e->pairs * sizeof(u64), e->stream));
     }
-    FSK_HIP(e->d_U.reserve(1));
-    FSK_HIP(hipMemsetAsync(e->d_U.p, 0, sizeof(u64), e->stream));
+    FSK_HIP(e->d_U.reserve(2));  // [0] update count U (multi-chunk dense launches), [1] remainder row products of the dense tile launches
+    FSK_HIP(hipMemsetAsync(e->d_U.p, 0, 2 * sizeof(u64), e->stream));
     e->loaded = true; e->finalized = false; e->result_f64 = false;
     e->stdevs.clear();
     fsk_stats& st = e->st;
@@ -1133,15 +1134,20 @@ int fsk_free_device(fsk_engine* e, void* device_ptr) {
 }  // extern "C"
 
 int fsk_detail::one_get_stats(fsk_engine* e, fsk_stats* out) {
+    u64 rem_rows = 0;
     if (e->d_U.p && e->loaded) {
         DeviceScope on_device(e->cfg.device);
-        u64 U = 0;
+        u64 U[2] = {0, 0};
         if (hipStreamSynchronize(e->stream) == hipSuccess && fetch_pending_u(e) == FSK_OK &&
-            hipMemcpy(&U, e->d_U.p, sizeof U, hipMemcpyDeviceToHost) == hipSuccess)
-            e->st.cell_updates = U + e->u_extra;
+            hipMemcpy(U, e->d_U.p, sizeof U, hipMemcpyDeviceToHost) == hipSuccess) {
+            e->st.cell_updates = U[0] + e->u_extra;
+            rem_rows = U[1];
+        }
     }
     e->st.batches_redone = (double)e->sx_redone;
     *out = e->st;
+    // (every flagged-row remainder product is one more dot8 per cell of its tile: 8 count-MACs x 128 x 128)
+    out->dense_macs += rem_rows * (u64)fsk::TILE * fsk::TILE * 8;
     return FSK_OK;
 }
 

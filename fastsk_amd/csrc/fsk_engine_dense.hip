@@ -300,6 +300,10 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
                 if (rcz) return rcz;
             }
         }
+        if (e->cfg.profile)  // the flagged rows' remainder products of this launch, for fsk_stats.dense_macs (read by fsk_get_stats)
+            FSK_LAUNCH(fsk::k_dense_remainder_rows, dim3((uint32_t)((n_tiles + 255) / 256), (uint32_t)nb), dim3(256), 0, e->stream,
+                       (const uint32_t*)e->d_rowmask.p, (const uint32_t*)e->d_tiletab.p, (uint32_t)n_tiles, (uint32_t)nb, nst, compact ? 1 : 0,
+                       e->d_U.p + 1);
         e->tic();
         if (compact && e->compact_dma)
             FSK_LAUNCH(fsk::k_dense_tile_dma_compact, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C4.p, e->d_C4H.p,
@@ -316,7 +320,7 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
                        e->d_rowmask.p, e->d_tiletab.p, nb, Vq8, nst, (uint32_t)e->N, K, slots_per_split);
         e->toc(&e->st.ms_tile);
         e->st.n_tile_launches += 1;
-        u64 row_sum = (u64)Vq8 * (u64)nb;  // dword rows multiplied per tile (flagged-row remainders not counted)
+        u64 row_sum = (u64)Vq8 * (u64)nb;  // dword rows multiplied per tile (the flagged rows' remainder products are added by fsk_get_stats)
         if (compact && (int)e->h_vc_cache.size() == nb) {
             row_sum = 0;
             for (uint16_t v : e->h_vc_cache) row_sum += (v + 7u) / 8u;

@@ -115,6 +115,7 @@ struct fsk_engine {
     // them (dense dataflow, one workgroup per tile): rows [lazy_lo, lazy_hi) are zero by contract
     // but not in memory until a tile launch stores them or materialise_zero() fills them.
     int64_t lazy_lo = -1, lazy_hi = -1;
+    int var_ahead = 8;             // variance mode: iterations per batch issued ahead of the stop test (FSK_VAR_AHEAD=n: tuning)
     int variance_dense_slots = 1;  // FSK_VARIANCE_DENSE_SLOTS=0: zero fill + k_welford per iteration instead (testing)
     bool store_next = false;  // variance mode, dense dataflow: the next (one-combo, whole-triangle) tile launch stores into the K it is given
     uint32_t* h_stage = nullptr;         // pinned: the packed sequences on their way to the device (fsk_load_sequences)

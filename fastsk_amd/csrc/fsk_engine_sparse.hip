@@ -103,7 +103,10 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         FSK_HIP(hipMemcpy(e->d_owner_r0.p, e->h_owner_r0.data(), e->h_owner_r0.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         e->owner_ready = true;
     }
-    const uint32_t nchunks = (ntiles + fsk::UC_CHUNK - 1) / fsk::UC_CHUNK;
+    // tiles per chunk of the column scans: 64, fewer for a batch of few tiles (variance mode's: a few thousand) so that the
+    // chunk kernels have a few hundred workgroups and short chains of dependent steps
+    const uint32_t uc = ntiles >= 16384u ? (uint32_t)fsk::UC_CHUNK : ntiles >= 4096u ? 16u : 8u;
+    const uint32_t nchunks = (ntiles + uc - 1) / uc;
     if (lists) {
         FSK_HIP(S.d_ucount.reserve((size_t)O * ntiles));
         FSK_HIP(S.d_uchunk.reserve((size_t)O * nchunks));
@@ -232,10 +235,10 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     u64 words = 0;
     if (lists) {  // where every (tile, owner) share of the update streams starts (+ the batch's pair and word totals)
         FSK_LAUNCH(fsk::k_sx_ucol_sum, dim3(nchunks), dim3(256), 0, stream, (const uint32_t*)S.d_ucount.p, ntiles, O, S.d_uchunk.p,
-                   (const u64*)S.d_tile_stat.p, S.d_sxstat.p, stat_pin);
+                   (const u64*)S.d_tile_stat.p, S.d_sxstat.p, stat_pin, uc);
         FSK_LAUNCH(fsk::k_sx_ucol_scan, dim3(O), dim3(256), 0, stream, S.d_uchunk.p, nchunks, O, S.d_utot.p);
         FSK_LAUNCH(fsk::k_sx_ucol_apply, dim3(nchunks), dim3(256), 0, stream, S.d_ucount.p, ntiles, O, (const uint32_t*)S.d_uchunk.p,
-                   (const uint32_t*)S.d_utot.p, S.d_list_off.p);
+                   (const uint32_t*)S.d_utot.p, S.d_list_off.p, uc);
         e->st.launches += 3;
     } else {
         FSK_LAUNCH(fsk::k_sx_stat_sum, dim3(32), dim3(256), 0, stream, (const u64*)S.d_tile_stat.p, ntiles, S.d_sxstat.p, stat_pin);

@@ -41,6 +41,10 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     const int64_t pairs = e->pairs;
     const int64_t train_pairs = (int64_t)((e->n_train / (double)2) * (e->n_train + 1));
     const size_t tp = (size_t)std::max<int64_t>(1, train_pairs);
+    // strides of the per-iteration arrays — slot triangles, the K_hat ring, the products — padded to multiples of 4 cells:
+    // every array then starts 16-byte aligned and k_welford_batch_v moves 16 bytes per access (cells in [pairs, ps) of a
+    // slot hold nothing anybody reads)
+    const size_t ps = ((size_t)pairs + 3) & ~(size_t)3, tps = (tp + 3) & ~(size_t)3;
     // The stop test of iteration i needs avg_variance, a SEQUENTIAL fp64 sum in triangle-index
     // order (fastsk_kernel.cpp:116-131), to the last bit. It is computed on the device
     // (enqueue_sequential_sum), so only 8 bytes per iteration come back; the engine still runs AHEAD
@@ -57,7 +61,8 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     // (two batches in flight, one per lane. Measured with three and four — the issue of a batch waits for the sums
     // of the oldest one in flight, a latency a third batch would cover —: config 1 6.4 -> 6.8 -> 7.4 ms; the GPU is
     // busy as it is, and what the extra batches add are iterations beyond the stop.)
-    constexpr int AHEAD = 8, MAX_DEPTH = 2, LANES = 2;
+    constexpr int MAX_AHEAD = 16, MAX_DEPTH = 2, LANES = 2;
+    const int AHEAD = std::max(1, std::min(MAX_AHEAD, e->var_ahead));  // iterations per batch (FSK_VAR_AHEAD; 8: see above)
     const int DEPTH = MAX_DEPTH, INFLIGHT = MAX_DEPTH;
     const int RING = DEPTH * AHEAD + 1;
     const bool trace = getenv("FSK_TRACE") != nullptr;  // stderr: where the wall time of this mode goes
@@ -68,8 +73,8 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     const size_t nblk = (tp + fsk::SQ_BLOCK - 1) / fsk::SQ_BLOCK;
     const size_t slots = (size_t)DEPTH * AHEAD;
     FSK_HIP(e->d_Kf64.reserve((size_t)pairs));
-    FSK_HIP(e->d_Khat.reserve((size_t)pairs * RING));
-    FSK_HIP(e->d_prod.reserve(tp * slots));
+    FSK_HIP(e->d_Khat.reserve(ps * RING));
+    FSK_HIP(e->d_prod.reserve(tps * slots));
     FSK_HIP(e->d_bsum.reserve(nblk * slots + slots));
     FSK_HIP(e->d_seqblk.reserve(nblk * slots * (sizeof(fsk::SeqBlk) + 2 * fsk::SQ_GROUPS * sizeof(fsk::SeqGrp))));
     fsk::SeqGrp* const seq_grp = reinterpret_cast<fsk::SeqGrp*>(e->d_seqblk.p + nblk * slots * sizeof(fsk::SeqBlk));
@@ -115,7 +120,7 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     const uint32_t blocks = (uint32_t)((pairs + 255) / 256);                                       // one cell per thread
     const uint32_t wblocks = (uint32_t)((pairs + 256 * fsk::WF_ITEMS - 1) / (256 * fsk::WF_ITEMS)); // k_welford
     const int n_order = (int)e->order.size();
-    auto khat = [&](int i) { return e->d_Khat.p + (size_t)(i % RING) * (size_t)pairs; };
+    auto khat = [&](int i) { return e->d_Khat.p + (size_t)(i % RING) * ps; };
     struct Batch { int n = 0, first_iter = 0, first_item = 0, base = 0, part = 0, lane = 0; bool grouped = false; };
     // Where the stop test is expected to fire: the variance estimate settles, so sd falls like 1 / sqrt(iter) and
     // delta / sd > 1.96 is reached near iter * (1.96 sd / delta)^2. Only the SIZE of the batches issued ahead follows
@@ -161,10 +166,10 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     const bool dense_slots = e->path == FSK_PATH_DENSE && e->tile_dma && !e->compact && !(e->cfg.skip_test_block && e->n_test > 0) &&
                              (u64)pairs * AHEAD * DEPTH * sizeof(u64) <= ((u64)8 << 30) && e->variance_dense_slots;
     // (one set of slot triangles per batch in flight: a stop inside a batch runs its Welford prefix again)
-    if (grouped) FSK_HIP(e->d_Kslots.reserve(((size_t)pairs * AHEAD * DEPTH + 1) / 2));
-    if (dense_slots) FSK_HIP(e->d_Kslots.reserve((size_t)pairs * AHEAD * DEPTH));
-    auto slots_of = [&](int part) { return reinterpret_cast<uint32_t*>(e->d_Kslots.p) + (size_t)part * AHEAD * (size_t)pairs; };
-    auto slots64_of = [&](int part) { return e->d_Kslots.p + (size_t)part * AHEAD * (size_t)pairs; };
+    if (grouped) FSK_HIP(e->d_Kslots.reserve((ps * AHEAD * DEPTH + 1) / 2));
+    if (dense_slots) FSK_HIP(e->d_Kslots.reserve(ps * AHEAD * DEPTH));
+    auto slots_of = [&](int part) { return reinterpret_cast<uint32_t*>(e->d_Kslots.p) + (size_t)part * AHEAD * ps; };
+    auto slots64_of = [&](int part) { return e->d_Kslots.p + (size_t)part * AHEAD * ps; };
     // The Welford pass of a batch: k_welford_batch carries up to WF_SLOTS iterations in registers, a larger batch takes
     // several passes (each leaves the state after its last iteration in the ring). `first` .. `first + count`: the
     // batch's slots to fold, from the state after slot first - 1; with_sums = 0: states only (a stop inside the batch).
@@ -172,16 +177,18 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
         for (int c = first; c < first + count; c += fsk::WF_SLOTS) {
             const int nc = std::min((int)fsk::WF_SLOTS, first + count - c);
             const size_t slot = (size_t)B.part * AHEAD + c;
+            fsk::WfRecip rr;  // 1 / iteration number of every slot of the pass (the IEEE quotient, as the kernels compute it)
+            for (int q = 0; q < fsk::WF_SLOTS; ++q) rr.r[q] = 1.0 / ((double)(B.first_iter + c) + (double)q);
             if (u64_slots)
-                FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<u64>), dim3(wblocks), dim3(256), 0, st, (const u64*)slots64_of(B.part) + (size_t)c * pairs,
-                           nc, (const double*)khat(B.base + c), khat(B.base + c + nc), with_sums ? e->d_prod.p + slot * tp : (double*)nullptr,
-                           (u64)tp, (u64)pairs, (u64)train_pairs, (double)(B.first_iter + c), with_sums ? e->d_bsum.p + slot * nblk : (double*)nullptr,
-                           (uint32_t)nblk, with_sums);
+                FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch_v<u64>), dim3(wblocks), dim3(256), 0, st, (const u64*)slots64_of(B.part) + (size_t)c * ps,
+                           (u64)ps, nc, (const double*)khat(B.base + c), khat(B.base + c + nc), with_sums ? e->d_prod.p + slot * tps : (double*)nullptr,
+                           (u64)tps, (u64)pairs, (u64)train_pairs, (double)(B.first_iter + c), rr,
+                           with_sums ? e->d_bsum.p + slot * nblk : (double*)nullptr, (uint32_t)nblk, with_sums);
             else
-                FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch<uint32_t>), dim3(wblocks), dim3(256), 0, st,
-                           (const uint32_t*)slots_of(B.part) + (size_t)c * pairs, nc, (const double*)khat(B.base + c), khat(B.base + c + nc),
-                           with_sums ? e->d_prod.p + slot * tp : (double*)nullptr, (u64)tp, (u64)pairs, (u64)train_pairs,
-                           (double)(B.first_iter + c), with_sums ? e->d_bsum.p + slot * nblk : (double*)nullptr, (uint32_t)nblk, with_sums);
+                FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch_v<uint32_t>), dim3(wblocks), dim3(256), 0, st,
+                           (const uint32_t*)slots_of(B.part) + (size_t)c * ps, (u64)ps, nc, (const double*)khat(B.base + c), khat(B.base + c + nc),
+                           with_sums ? e->d_prod.p + slot * tps : (double*)nullptr, (u64)tps, (u64)pairs, (u64)train_pairs,
+                           (double)(B.first_iter + c), rr, with_sums ? e->d_bsum.p + slot * nblk : (double*)nullptr, (uint32_t)nblk, with_sums);
         }
         return FSK_OK;
     };
@@ -193,9 +200,9 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     auto issue = [&](Batch& B) -> int {
         const bool was_grouped = grouped;
         if (grouped) {
-            int32_t combos[AHEAD];
+            int32_t combos[MAX_AHEAD];
             for (int b = 0; b < B.n; ++b) combos[b] = e->order[B.first_item + b * T];
-            int rc = do_accumulate(e, combos, B.n, reinterpret_cast<u64*>(slots_of(B.part)), 0, -1, (u64)pairs, B.part);
+            int rc = do_accumulate(e, combos, B.n, reinterpret_cast<u64*>(slots_of(B.part)), 0, -1, (u64)ps, B.part);
             if (rc == FSK_RETRY_UNGROUPED) grouped = false;  // too many updates for one stream: from here on one iteration at a time
             else if (rc) return rc;
         }
@@ -215,7 +222,7 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
             for (int b = 0; b < B.n; ++b) {
                 int32_t combo = e->order[B.first_item + b * T];
                 e->store_next = true;
-                int rc = do_accumulate(e, &combo, 1, slots64_of(B.part) + (size_t)b * pairs);
+                int rc = do_accumulate(e, &combo, 1, slots64_of(B.part) + (size_t)b * ps);
                 e->store_next = false;
                 if (rc) return rc;
             }
@@ -229,7 +236,7 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
             int rc = do_accumulate(e, &combo, 1, e->d_K);
             if (rc) return rc;
             FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford<u64>), dim3(wblocks), dim3(256), 0, e->stream, (const u64*)e->d_K, (const double*)khat(B.base + b),
-                       khat(B.base + b + 1), e->d_prod.p + slot * tp, (u64)pairs, (u64)train_pairs, (double)(B.first_iter + b),
+                       khat(B.base + b + 1), e->d_prod.p + slot * tps, (u64)pairs, (u64)train_pairs, (double)(B.first_iter + b),
                        e->d_bsum.p + slot * nblk);
         }
         // the batch's sums: block totals on all CUs, then one wave per iteration walks its blocks — on a
@@ -237,9 +244,9 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
         const size_t slot0 = (size_t)B.part * AHEAD;
         FSK_HIP(hipEventRecord(ev_wf[lane], bs));  // the state after this batch is on its way
         wf_set[lane] = true;
-        int rc = enqueue_sequential_sum(e, e->d_prod.p + slot0 * tp, (u64)train_pairs, e->d_bsum.p + slot0 * nblk,
+        int rc = enqueue_sequential_sum(e, e->d_prod.p + slot0 * tps, (u64)train_pairs, e->d_bsum.p + slot0 * nblk,
                                         reinterpret_cast<fsk::SeqBlk*>(e->d_seqblk.p) + slot0 * nblk,
-                                        seq_grp + slot0 * nblk * (2 * fsk::SQ_GROUPS), h_avg + slot0, B.n, (u64)tp,
+                                        seq_grp + slot0 * nblk * (2 * fsk::SQ_GROUPS), h_avg + slot0, B.n, (u64)tps,
                                         e->chain_stream, ev_hand[B.part], bs);  // (the sums land in pinned host memory)
         if (rc) return rc;
         FSK_HIP(hipEventRecord(ev_done[B.part], e->chain_stream));

@@ -293,6 +293,28 @@ __global__ __launch_bounds__(64) void k_dense_distinct(const uint32_t* C4, const
     if (r == 0 && u) atomicAdd(U, u);
 }
 
+// The remainder terms of the tile kernels, counted (profiling aid: fsk_stats.dense_macs prices what the kernels really
+// multiply). A count above 15 lives in the hi plane; a dword row of a (panel, combo) block whose hi plane is not all zero is
+// FLAGGED in rowmask, and for every flagged row of a tile the tile kernel adds the exact remainder 16 (hi_i lo_j + lo_i hi_j)
+// + 256 hi_i hi_j: three more dot8 per cell (the key-compacted kernels: only the terms whose side is flagged — A, B, A and B).
+// out += the number of such extra row products over the launch's tiles x combos. grid = (ceil(tiles / 256), combos).
+__global__ __launch_bounds__(256) void k_dense_remainder_rows(const uint32_t* rowmask, const uint32_t* tiletab, uint32_t n_tiles,
+                                                              uint32_t n_slots, uint32_t nst, int side_aware, u64* out) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x, sl = blockIdx.y;
+    u64 rows = 0;
+    if (t < n_tiles) {
+        const uint32_t tt = tiletab[t], ti = tt >> 16, tj = tt & 0xffffu;
+        const size_t np = (size_t)n_slots * nst;
+        for (uint32_t st = 0; st < nst; ++st) {
+            const size_t a = ((size_t)(ti * 2u) * n_slots + sl) * nst + st, b = ((size_t)(tj * 2u) * n_slots + sl) * nst + st;
+            const uint32_t mA = rowmask[a] | rowmask[a + np], mB = rowmask[b] | rowmask[b + np];
+            rows += side_aware ? (u64)(__popc(mA) + __popc(mB) + __popc(mA & mB)) : (u64)3 * (u64)__popc(mA | mB);
+        }
+    }
+    rows = fsk_hw::wave_sum_u64(rows);
+    if ((threadIdx.x & 63u) == 0 && rows) atomicAdd(out, rows);
+}
+
 #define FSK_TILE_KERNEL k_dense_tile
 #define FSK_TILE_COMPACT 0
 #include "fsk_tile_kernel.inc"

@@ -119,7 +119,8 @@ typedef struct fsk_stats {
     double ms_pairs;         /* sparse: per-run pair atomics                                    */
     double ms_total;         /* whole accumulate calls                                          */
     int64_t n_tile_launches; /* launches of the tile kernel (for per-launch averages)           */
-    uint64_t dense_macs;     /* 8-bit multiply-adds issued by the tile kernel                   */
+    uint64_t dense_macs;     /* count multiply-adds issued by the tile kernel: 8 per dword row and cell, the exact
+                                remainder products of the rows with counts above 15 included (profile = 1)  */
     uint64_t panel_bytes;    /* bytes of count panels written (= read at least once)            */
     double u4_tile_launches; /* launches of the 4-bit tile kernel (v_dot8_u32_u4)                */
     double max_windows;      /* max over sequences of (length - g + 1): bounds a cell per combo  */

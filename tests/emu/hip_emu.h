@@ -41,6 +41,7 @@ struct dim3 {
 struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
 struct ulonglong2 { unsigned long long x, y; };
+struct double2 { double x, y; };
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 
