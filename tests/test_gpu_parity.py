@@ -1160,6 +1160,9 @@ def test_device_resident_block_getter(native):
     assert t.is_cuda and np.array_equal(t.cpu().numpy(), d["train"])
     t = e.get_block_torch(d["n_train"], d["n_train"] + d["n_test"], 0, d["n_train"])
     assert np.array_equal(t.cpu().numpy(), d["test"])
+    # fsk_get_triangle_device: the reference's K itself (fastsk_kernel.cpp:96-103 over every cell), written on the device
+    tri = e.get_triangle_torch()
+    assert tri.is_cuda and np.array_equal(tri.cpu().numpy(), d["tri"]) and np.array_equal(e.get_triangle(), d["tri"])
     e.close()
 
 
