@@ -300,6 +300,9 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     { const char* f = getenv("FSK_TILE_SPLITS"); e->force_splits = f ? atoi(f) : 0; }
     { const char* f = getenv("FSK_TILE_DMA"); e->tile_dma = f ? atoi(f) : 1; }
     { const char* f = getenv("FSK_SPARSE_LANES"); if (f) e->sx_two_lanes = atoi(f) >= 2; }
+    { const char* f = getenv("FSK_SPARSE_BATCH_RECORDS"); if (f && atoll(f) > 0) e->sx_batch_records = (size_t)atoll(f); }
+    { const char* f = getenv("FSK_SPARSE_EXACT_PARTS"); if (f && atoi(f) > 0) e->sx_exact_parts = atoi(f); }
+    { const char* f = getenv("FSK_SPARSE_EXACT_LANES"); if (f) e->sx_exact_lanes = atoi(f); }
     { const char* f = getenv("FSK_COMPACT_DMA"); e->compact_dma = f ? atoi(f) : 1; }
     { const char* f = getenv("FSK_EXTRACT_SLOTS"); if (f) e->extract_slots = atoi(f); }
     { const char* f = getenv("FSK_DENSE_CHUNK"); e->force_chunk = f ? (uint32_t)atoi(f) : 0u; }
@@ -339,6 +342,7 @@ void fsk_detail::one_destroy(fsk_engine* e) {
     if (e->h_sx_head_pos) (void)hipHostFree(e->h_sx_head_pos);
     if (e->h_sx_head_stat) (void)hipHostFree(e->h_sx_head_stat);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
+    for (auto& ev : e->ev_lane) if (ev) (void)hipEventDestroy(ev);
     if (e->ev_out) (void)hipEventDestroy(e->ev_out);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
     if (e->chain_stream) { (void)hipStreamSynchronize(e->chain_stream); (void)hipStreamDestroy(e->chain_stream); }

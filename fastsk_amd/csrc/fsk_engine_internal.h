@@ -175,6 +175,10 @@ struct fsk_engine {
     SxScratch sxs[2];                     // lane 0: every exact accumulate; lanes 0 and 1: variance mode's batches in flight
     hipStream_t lane_stream = nullptr;    // lane 1's stream (lane 0 runs on `stream`)
     int sx_two_lanes = 1;                 // FSK_SPARSE_LANES=1: variance mode on one stream (testing)
+    size_t sx_batch_records = 0;          // FSK_SPARSE_BATCH_RECORDS=n: records per batch at most (testing / tuning; 0: SPARSE_MAX_RECORDS)
+    int sx_exact_parts = 1;               // FSK_SPARSE_EXACT_PARTS=n: in two lanes, what is left goes in n batches at least (tuning)
+    int sx_exact_lanes = 0;               // FSK_SPARSE_EXACT_LANES=1 / 2: the batches of an exact accumulate never / always in two lanes (0: from six batches on)
+    hipEvent_t ev_lane[4] = {nullptr, nullptr, nullptr, nullptr};  // exact accumulate in two lanes: fork, join, K handed on by lane 0 / 1
     DevBuf<uint32_t> d_owner_r0;
     DevBuf<u64> d_U;
     std::vector<uint32_t> h_owner_r0;     // owner bands of K: rows [r0[o], r0[o+1])

@@ -57,7 +57,11 @@ void plan_owner_bands(fsk_engine* e) {
 // counts and sizes the streams exactly; else it only enqueues, for streams of at most guard_cap words.
 template <typename RecT>
 int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t row0, int64_t row1, u64 slot_stride,
-                 unsigned char* pos_pin, u64* stat_pin, u64 guard_cap, int lane) {
+                 unsigned char* pos_pin, u64* stat_pin, u64 guard_cap, int lane, size_t pos_off = 0, hipEvent_t k_wait = nullptr,
+                 hipEvent_t k_done = nullptr) {
+    // pos_off: where this batch's positions lie in e->d_pos (the batches of one exact accumulate, in flight in two lanes, each
+    // have their own piece); k_wait / k_done: the kernels that touch K wait for the first and are followed by the second (a
+    // band with one part adds into K with a plain read-modify-write: the consume passes of the two lanes may not overlap)
     SxScratch& S = e->sxs[lane];
     hipStream_t stream = lane ? e->lane_stream : e->stream;
     const uint32_t nfeat = (uint32_t)e->nfeat;
@@ -96,7 +100,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     }
     FSK_HIP(S.d_sxstat.reserve(3));
     FSK_HIP(S.d_tile_stat.reserve((size_t)2 * ntiles));
-    FSK_HIP(e->d_pos.reserve((size_t)nb * e->k));
+    FSK_HIP(e->d_pos.reserve(pos_off + (size_t)nb * e->k));
     if (!e->owner_ready) {
         FSK_HIP(e->d_owner_r0.reserve(e->h_owner_r0.size()));
         // (once per set of sequences, and every lane's kernels read it: a synchronous copy)
@@ -126,14 +130,14 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     } else {
         for (int s = 0; s < nb; ++s)
             memcpy(pos_pin + (size_t)s * e->k, &e->all_pos[(size_t)combos[s] * e->k], e->k);
-        FSK_HIP(hipMemcpyAsync(e->d_pos.p, pos_pin, (size_t)nb * e->k, hipMemcpyHostToDevice, stream));
+        FSK_HIP(hipMemcpyAsync(e->d_pos.p + pos_off, pos_pin, (size_t)nb * e->k, hipMemcpyHostToDevice, stream));
         FSK_HIP(hipMemsetAsync(S.d_sxstat.p, 0, 3 * sizeof(u64), stream));
     }
 
     RecT* rec[2] = {(RecT*)S.d_keys[0].p, (RecT*)S.d_keys[1].p};
 
     e->tic();
-    const uint8_t* const pos_tab = by_id ? (const uint8_t*)e->d_allpos.p : (const uint8_t*)e->d_pos.p;
+    const uint8_t* const pos_tab = by_id ? (const uint8_t*)e->d_allpos.p : (const uint8_t*)e->d_pos.p + pos_off;
     u64* const zeroed_stats = by_id ? S.d_sxstat.p : (u64*)nullptr;
     const int ww = e->win_words;
     constexpr bool R32 = sizeof(RecT) == 4;
@@ -286,6 +290,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             // part (up to sx_cap cells) outweighs the words it summed
             const uint32_t target = (uint32_t)std::max<u64>((u64)4 * e->sx_cap, (words + 1023) / 1024);
             const uint32_t max_parts = O + (uint32_t)(((guarded ? guard_cap : words) + target - 1) / target);
+            if (k_wait) FSK_HIP(hipStreamWaitEvent(stream, k_wait, 0));
             if (slot_stride != 0) {  // one triangle per slot: a slot's words of a stream are one contiguous piece
                 FSK_LAUNCH(fsk::k_sx_consume<true>, dim3(O, e->sx_rounds_slot, nb), dim3(fsk::CS_THREADS), lds_slot, stream, (const uint32_t*)S.d_ulist.p,
                            (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)nullptr, O, target,
@@ -301,6 +306,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             e->st.launches += 2;
         }
     } else {
+        if (k_wait) FSK_HIP(hipStreamWaitEvent(stream, k_wait, 0));
         if (packed) {
             auto k_emit = skipping ? fsk::k_sx_emit<true, true, true> : fsk::k_sx_emit<true, false, true>;
             FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, reinterpret_cast<const uint32_t*>(S.d_E.p),
@@ -318,11 +324,13 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         e->st.launches += 1;
     }
     // the diagonal's combo-independent part (the streams and the atomics above carry the rest)
+    if (k_wait && use_lists && !(words > 0 || slot_stride != 0)) FSK_HIP(hipStreamWaitEvent(stream, k_wait, 0));
     if (row1 > row0)
         FSK_LAUNCH(fsk::k_sx_diag_windows, dim3((uint32_t)((row1 - row0 + 255) / 256), slot_stride ? nb : 1), dim3(256), 0, stream,
                    (const uint32_t*)e->d_fstart.p, (uint32_t)row0, (uint32_t)row1, (uint32_t)nb, K, slot_stride,
                    use_lists ? (const u64*)S.d_sxstat.p : (const u64*)nullptr, cap_words);
     e->st.launches += 1;
+    if (k_done) FSK_HIP(hipEventRecord(k_done, stream));
     e->toc(&e->st.ms_pairs);
     FSK_HIP(hipGetLastError());
     return FSK_OK;
@@ -424,7 +432,7 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     const size_t nfeat = (size_t)std::max<int64_t>(1, e->nfeat);
     const u64 by_cells = std::max<u64>(1, 0xffffffffull / std::max<u64>(1, (u64)e->maxW * e->maxW));
     auto batch_combos = [&](int left) {
-        size_t recs = SPARSE_MAX_RECORDS;
+        size_t recs = e->sx_batch_records ? e->sx_batch_records : SPARSE_MAX_RECORDS;
         if (e->sx_wpr == 0) recs = std::min<size_t>(recs, (size_t)1 << 25);
         else recs = std::min<size_t>(recs, (size_t)std::max(1.0, (double)(e->sx_max_words / 2) / e->sx_wpr));
         const u64 B = std::max<u64>(1, std::min<u64>({(u64)(recs / nfeat), (u64)left, by_cells, (u64)65535}));  // (65535: grid.y)
@@ -438,32 +446,79 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     if (lane && !e->lane_stream) FSK_HIP(hipStreamCreateWithFlags(&e->lane_stream, hipStreamNonBlocking));
     rc = sx_pinned(e, (size_t)n * e->k, (size_t)2 * n);  // (at most one batch per combo)
     if (rc) return rc;
-    auto one = [&](int s, int nb, unsigned char* pos_pin, u64* stat_pin, u64 guard) {
+    auto one = [&](int s, int nb, unsigned char* pos_pin, u64* stat_pin, u64 guard, int ln, size_t pos_off = 0, hipEvent_t k_wait = nullptr,
+                   hipEvent_t k_done = nullptr) {
         // (slot triangles are u32 arrays, slot_stride cells apart)
         u64* Kb = slot_stride ? reinterpret_cast<u64*>(reinterpret_cast<uint32_t*>(K) + (u64)s * slot_stride) : K;
-        return recbits <= 32   ? sparse_batch<uint32_t>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard, lane)
-               : recbits <= 64 ? sparse_batch<u64>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard, lane)
-                               : sparse_batch<u128>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard, lane);
+        return recbits <= 32   ? sparse_batch<uint32_t>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard, ln, pos_off, k_wait, k_done)
+               : recbits <= 64 ? sparse_batch<u64>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard, ln, pos_off, k_wait, k_done)
+                               : sparse_batch<u128>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard, ln, pos_off, k_wait, k_done);
     };
     if (defer >= 0) {
         const u64 guard = sx_guard_for(e, lane, (u64)n * nfeat);
         e->sx_defer[defer].active = guard != 0;
         e->sx_defer[defer].cap = guard;
         e->sx_defer[defer].nrec = (u64)n * nfeat;
-        rc = one(0, n, e->h_sx_head_pos + (size_t)defer * SX_DEFER_COMBOS * e->k, e->h_sx_head_stat + 2 * defer, guard);
+        rc = one(0, n, e->h_sx_head_pos + (size_t)defer * SX_DEFER_COMBOS * e->k, e->h_sx_head_stat + 2 * defer, guard, lane);
         if (rc) e->sx_defer[defer].active = false;
         return rc;
     }
+    // An exact accumulate of MANY batches runs them in TWO LANES (a scratch set and a stream each, as variance mode's): the
+    // batches enqueued under a guard alternate between the lanes, so that one batch's sort and segment kernels (bound by the
+    // instructions they issue) share the GPU with the other's emit / consume (bound by latency and bandwidth). What orders
+    // the lanes is K: a batch's consume pass waits for the previous batch's (ev_lane), everything before it is per lane.
+    // Measured (profiles/r04_exact_lanes_ab.txt): the large-g regime (EP300, g = 20: ~40 batches of 2^24.7 records, sized by
+    // their update words) 1.735 -> 1.66-1.68 s; config 4 (three batches of 2^27 records) 10.1 -> 10.4-10.8 ms — big batches
+    // fill the GPU by themselves and two of them at once only share its caches — hence: from six batches on.
+    const int nb0 = batch_combos(n);
+    const bool many = (n + nb0 - 1) / nb0 >= 6;
+    const bool two = (e->sx_exact_lanes >= 2 || (e->sx_exact_lanes == 0 && many)) && !e->cfg.profile && !e->sx_sync && slot_stride == 0 && nb0 < n;
+    if (two) {
+        if (!e->lane_stream) FSK_HIP(hipStreamCreateWithFlags(&e->lane_stream, hipStreamNonBlocking));
+        for (auto& ev : e->ev_lane)
+            if (!ev) FSK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        FSK_HIP(e->d_pos.reserve((size_t)n * e->k));  // (never grown while a batch in flight reads its piece)
+    }
     struct Enq { int s, nb; u64 cap; };  // batches enqueued under a guard (not sized exactly): checked below
     std::vector<Enq> enq;
-    int q = 0;
+    int q = 0, next_lane = 0, prev_lane = -1;
+    bool lane1_started = false;
     for (int s = 0; s < n; ++q) {
-        const int nb = batch_combos(n - s);  // (grows after the first batch of a set of sequences has been sized)
-        const u64 cap = sx_guard_for(e, 0, (u64)nb * nfeat);
-        rc = one(s, nb, e->h_sx_pos + (size_t)s * e->k, e->h_sx_stat + 2 * q, cap);
-        if (rc) return rc;
+        int nb = batch_combos(n - s);  // (grows after the first batch of a set of sequences has been sized)
+        if (two && e->sx_wpr != 0) {
+            // (two lanes want batches to alternate: what is left goes in an even number of equal batches, four at least
+            // while a batch still has a few dozen combos)
+            const int left = n - s;
+            int parts = (left + nb - 1) / nb;
+            parts = std::max(parts, std::min(e->sx_exact_parts, std::max(1, left / 32)));
+            nb = std::min(nb, (left + parts - 1) / parts);
+        }
+        int ln = two ? next_lane : 0;
+        u64 cap = sx_guard_for(e, ln, (u64)nb * nfeat);
+        if (cap == 0 && ln != 0) { ln = 0; cap = sx_guard_for(e, 0, (u64)nb * nfeat); }  // (a batch that waits for its size: lane 0)
+        hipEvent_t k_wait = nullptr, k_done = nullptr;
+        if (two) {
+            if (ln == 1 && !lane1_started) {  // lane 1 starts after what the engine's stream holds so far
+                FSK_HIP(hipEventRecord(e->ev_lane[0], e->stream));
+                FSK_HIP(hipStreamWaitEvent(e->lane_stream, e->ev_lane[0], 0));
+                lane1_started = true;
+            }
+            if (prev_lane >= 0 && prev_lane != ln) k_wait = e->ev_lane[2 + prev_lane];
+            k_done = e->ev_lane[2 + ln];
+        }
+        rc = one(s, nb, e->h_sx_pos + (size_t)s * e->k, e->h_sx_stat + 2 * q, cap, ln, two ? (size_t)s * e->k : 0, k_wait, k_done);
+        if (rc) {
+            if (lane1_started) (void)hipStreamSynchronize(e->lane_stream);
+            return rc;
+        }
         enq.push_back(Enq{s, nb, cap});
         s += nb;
+        prev_lane = ln;
+        next_lane = ln ^ 1;
+    }
+    if (lane1_started) {  // the engine's stream continues after lane 1's last batch
+        FSK_HIP(hipEventRecord(e->ev_lane[1], e->lane_stream));
+        FSK_HIP(hipStreamWaitEvent(e->stream, e->ev_lane[1], 0));
     }
     bool waiting = false;
     for (const Enq& b : enq) waiting |= b.cap != 0;
@@ -479,7 +534,7 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
         e->sx_redone += 1;
         const int was = e->sx_sync;
         e->sx_sync = 1;
-        rc = one(b.s, b.nb, e->h_sx_pos + (size_t)b.s * e->k, e->h_sx_stat + 2 * i, 0);
+        rc = one(b.s, b.nb, e->h_sx_pos + (size_t)b.s * e->k, e->h_sx_stat + 2 * i, 0, 0);
         e->sx_sync = was;
         if (rc) return rc;
     }

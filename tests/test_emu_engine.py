@@ -622,6 +622,33 @@ def test_emu_sparse_batches_enqueued_ahead_of_their_size(emu_lib, port, monkeypa
     e.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"FSK_SPARSE_EXACT_LANES": "2"}, {"FSK_SPARSE_EXACT_LANES": "1"}, {"FSK_SPARSE_GUARD_CAP": "100"}])
+def test_emu_sparse_exact_accumulate_in_two_lanes(emu_lib, port, monkeypatch, env):
+    """Sparse dataflow: the batches of ONE exact accumulate alternate between two lanes (scratch + stream), their consume
+    passes ordered by events; the same counts and U as on one stream, also when every guarded batch is redone."""
+    from fastsk_amd import _native
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    d = load_golden("f5_prot11_exact")
+    nfeat = int(sum(max(0, int(b) - int(a) - d["g"] + 1) for a, b in zip(d["offsets"][:-1], d["offsets"][1:])))
+    monkeypatch.setenv("FSK_SPARSE_BATCH_RECORDS", str(3 * nfeat))  # (three combos a batch)
+    combos = np.arange(0, 210, 9, dtype=np.int32)
+    want, _, U = port.raw_counts(d["tokens"], d["offsets"], d["g"], d["m"], combos)
+    e = _native.Engine(d["g"], d["m"], path=2, lib=emu_lib)
+    e.load_sequences(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+    first = e.stats()["launches"]
+    e.accumulate(combos[:4])   # (sizes the streams: two batches)
+    e.accumulate(combos[4:])   # (seven batches, none of which waits for its size)
+    e.finalize()
+    assert np.array_equal(e.get_counts(), want)
+    st = e.stats()
+    assert st["cell_updates"] == U and st["combos_done"] == combos.size
+    assert st["launches"] - first > 9 * 15
+    if "FSK_SPARSE_GUARD_CAP" in env:
+        assert st["batches_redone"] >= 7
+    e.close()
+
+
 @pytest.mark.parametrize("max_words", ["3000", "40000"])
 def test_emu_sparse_batches_sized_by_words_per_record(emu_lib, port, monkeypatch, max_words):
     """Sparse dataflow: once a batch of a set of sequences has been counted, later batches take as many

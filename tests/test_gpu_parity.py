@@ -985,6 +985,33 @@ def test_sparse_batches_enqueued_ahead_of_their_size(native, port, monkeypatch, 
     e.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"FSK_SPARSE_EXACT_LANES": "2"}, {"FSK_SPARSE_EXACT_LANES": "1"}, {"FSK_SPARSE_GUARD_CAP": "5000"}, {"FSK_SPARSE_GLOBAL": "1"}])
+def test_sparse_exact_accumulate_in_two_lanes(native, port, monkeypatch, env):
+    """Sparse dataflow: the batches of ONE exact accumulate alternate between two lanes (a scratch set and a stream each);
+    their consume passes — plain read-modify-writes of K — are ordered by events. Same counts and U as on one stream,
+    with every guarded batch redone, and with atomics instead of streams; repeated, so that a race would show."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    tokens, offsets = synthetic_dna(900, 120, seed=33)
+    g, m = 12, 6
+    nfeat = 900 * (120 - g + 1)
+    monkeypatch.setenv("FSK_SPARSE_BATCH_RECORDS", str(6 * nfeat))  # (six combos a batch)
+    combos = np.arange(0, port.num_combos(g, m), 7, dtype=np.int32)
+    want, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=8)
+    e = native.Engine(g, m, path=2)
+    e.load_sequences(tokens, offsets, 600, 300)
+    for rep in range(3):
+        e.reset_counts()
+        e.accumulate(combos)
+        e.finalize()
+        assert np.array_equal(e.get_counts(), want), rep
+    st = e.stats()
+    assert st["cell_updates"] == 3 * U
+    if "FSK_SPARSE_GUARD_CAP" in env:
+        assert st["batches_redone"] > 0
+    e.close()
+
+
 @pytest.mark.parametrize("env", [{"FSK_SPARSE_GLOBAL": "1"}, {"FSK_LIST_MAX_WORDS": "200000"}, {}, {"FSK_SPARSE_SYNC": "1"},
                                  {"FSK_SPARSE_GUARD_CAP": "5000"}])
 def test_variance_mode_sparse_forms(native, monkeypatch, env):

@@ -19,7 +19,9 @@ for name in sys.argv[1].split(","):
     for _ in range(7):
         t0 = time.perf_counter(); e.compute(tokens, offsets, ntr, nte); best = min(best, time.perf_counter() - t0)
     st = e.stats()
-    out[name] = {"ms": round(best * 1e3, 3), "issued": st["combos_issued"], "done": st["combos_done"], "stdevs": len(e.get_stdevs())}
+    dg = e.counts_digest() if not d["approx"] else (0, 0)
+    out[name] = {"ms": round(best * 1e3, 3), "issued": st["combos_issued"], "done": st["combos_done"], "stdevs": len(e.get_stdevs()),
+                 "launches": st["launches"] // 8, "digest": format(int(dg[0]), "x") + "." + format(int(dg[1]), "x")}
     e.close()
 print(json.dumps(out))
 ''' % (ROOT, ROOT)
