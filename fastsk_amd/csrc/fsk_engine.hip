@@ -305,6 +305,7 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     { const char* f = getenv("FSK_SPARSE_EXACT_LANES"); if (f) e->sx_exact_lanes = atoi(f); }
     { const char* f = getenv("FSK_COMPACT_DMA"); e->compact_dma = f ? atoi(f) : 1; }
     { const char* f = getenv("FSK_EXTRACT_SLOTS"); if (f) e->extract_slots = atoi(f); }
+    { const char* f = getenv("FSK_COUNT_SLOTS"); e->force_count_slots = f ? atoi(f) : 0; }
     { const char* f = getenv("FSK_DENSE_CHUNK"); e->force_chunk = f ? (uint32_t)atoi(f) : 0u; }
     if (hipStreamCreate(&e->stream) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
         hipEventCreate(&e->ev1) != hipSuccess) {

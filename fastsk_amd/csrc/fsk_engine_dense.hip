@@ -172,8 +172,10 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
             FSK_HIP(hipStreamSynchronize(e->stream));  // `pos` is a pageable temporary
             // ---- segment counts
             // up to 16 combos share one staging of a panel's symbols, fewer when that would leave the
-            // launch with less than ~1024 workgroups (few sequences)
-            const int slots_per_chunk = std::max(1, std::min({nb, 16, (int)((u64)nb * panels_pad / 1024)}));
+            // launch with less than ~512 workgroups (few sequences; with 1024 as the floor config 3 ran 11 combos a
+            // staging in 1130 workgroups: 16 a staging in 791 is 0.1-0.15 ms faster per count pass, FSK_COUNT_SLOTS sweep)
+            int slots_per_chunk = std::max(1, std::min({nb, 16, (int)((u64)nb * panels_pad / 512)}));
+            if (e->force_count_slots > 0) slots_per_chunk = std::max(1, std::min(nb, e->force_count_slots));
             const int n_chunks = (nb + slots_per_chunk - 1) / slots_per_chunk;
             e->tic();
             const dim3 cgrid(panels_pad, n_chunks);
@@ -271,7 +273,9 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
                 rows_per_combo = std::max(1.0, sum / nb);
             }
             const int slots = compact ? 768 : 1024;
-            int per = std::max(2, (int)std::ceil(600.0 / rows_per_combo));
+            // (key-compacted panels — the direct-to-LDS compact kernel, 768 resident slots: about 350 rows; config 3
+            // 6 -> 10 splits, 5.6 -> 5.5 ms)
+            int per = std::max(2, (int)std::ceil((compact ? 350.0 : 600.0) / rows_per_combo));
             n_splits = std::max(1, (nb + per - 1) / per);
             // ... and about 16k workgroups are enough: beyond that more splits only add flushes
             n_splits = std::min(n_splits, (int)((16384 + n_tiles - 1) / n_tiles));

@@ -138,6 +138,7 @@ struct fsk_engine {
     std::vector<uint32_t> h_len, h_fstart;
     bool featseq_ready = false;
     int force_splits = 0;      // FSK_TILE_SPLITS=n: combo splits per tile (tuning)
+    int force_count_slots = 0; // FSK_COUNT_SLOTS=n: combos that share one staging of a panel in k_dense_count (tuning)
     uint32_t force_chunk = 0;  // FSK_DENSE_CHUNK=n: cap the count kernel's staging chunk (testing)
 
     // combos
