@@ -303,6 +303,7 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     { const char* f = getenv("FSK_SPARSE_BATCH_RECORDS"); if (f && atoll(f) > 0) e->sx_batch_records = (size_t)atoll(f); }
     { const char* f = getenv("FSK_SPARSE_EXACT_PARTS"); if (f && atoi(f) > 0) e->sx_exact_parts = atoi(f); }
     { const char* f = getenv("FSK_SPARSE_EXACT_LANES"); if (f) e->sx_exact_lanes = atoi(f); }
+    { const char* f = getenv("FSK_COMPACT_RARE"); e->force_compact_rare = f ? atoi(f) : -1; }
     { const char* f = getenv("FSK_COMPACT_DMA"); e->compact_dma = f ? atoi(f) : 1; }
     { const char* f = getenv("FSK_EXTRACT_SLOTS"); if (f) e->extract_slots = atoi(f); }
     { const char* f = getenv("FSK_COUNT_SLOTS"); e->force_count_slots = f ? atoi(f) : 0; }
@@ -333,7 +334,7 @@ void fsk_detail::one_destroy(fsk_engine* e) {
     if (e->chain_stream) (void)hipStreamSynchronize(e->chain_stream);  // (variance mode may leave a dropped batch's sums running)
     e->d_words.release(); e->d_wstart.release(); e->d_len.release(); e->d_fstart.release(); e->d_featseq.release(); e->d_win.release();
     e->d_pos.release(); e->d_allpos.release(); e->d_bsum.release(); e->d_seqblk.release(); e->K_store.release(); e->d_Kf64.release(); e->d_Khat.release(); e->d_prod.release();
-    e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_Kslots.release(); e->d_cell_idx.release(); e->d_C4.release(); e->d_C4H.release(); e->d_rowmask.release(); e->d_flag.release(); e->d_tiletab.release(); e->d_keybits.release(); e->d_lut.release(); e->d_vc.release();
+    e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_Kslots.release(); e->d_cell_idx.release(); e->d_C4.release(); e->d_C4H.release(); e->d_rowmask.release(); e->d_flag.release(); e->d_tiletab.release(); e->d_rare.release(); e->d_rare_n.release(); e->d_keybits.release(); e->d_lut.release(); e->d_vc.release();
     if (e->lane_stream) { (void)hipStreamSynchronize(e->lane_stream); (void)hipStreamDestroy(e->lane_stream); }
     for (auto& lane : e->sxs) lane.release();
     e->d_owner_r0.release(); e->d_U.release(); e->d_U2.release();
@@ -620,6 +621,22 @@ int fsk_detail::one_load_sequences(fsk_engine* e, const int32_t* tokens, const i
         for (uint32_t r = 0; r < sigma; ++r) rarest = std::min(rarest, sym_freq[r]);
         e->compact = sigma >= 3 && V >= 64 && V <= 4096 && rarest * 50 < total;
         if (e->force_compact >= 0) e->compact = e->force_compact != 0 && V <= 4096;
+        // ... and the keys that occur follow from the places of the rare symbols when those are few (g windows per place
+        // and combo are marked instead of every window) and every key of common symbols can be taken as present (16
+        // windows per such key at least: one that is missing only costs an empty panel row)
+        e->rare_mask = 0; e->rare_places = 0; e->rare_ready = false;
+        int64_t places = 0;
+        uint32_t common = 0;
+        for (uint32_t r = 0; r < sigma && r < 32u; ++r) {
+            if (sym_freq[r] * 50 < total) { e->rare_mask |= 1u << r; places += sym_freq[r]; }
+            else ++common;
+        }
+        double common_keys = 1;
+        for (int c = 0; c < e->k; ++c) common_keys *= (double)common;
+        e->compact_rare = e->compact && sigma <= 32 && common >= 1 && places > 0 && places < ((int64_t)1 << 24) &&
+                          places * (int64_t)g * 8 < std::max<int64_t>(1, nfeat) && (double)nfeat >= 16.0 * common_keys;
+        if (e->force_compact_rare >= 0) e->compact_rare = e->compact && e->force_compact_rare != 0 && sigma <= 32 && places < ((int64_t)1 << 24);
+        e->rare_places = (uint32_t)places;
     }
     FSK_HIP(e->d_words.reserve(n_words_alloc));
     FSK_HIP(e->d_wstart.reserve((size_t)N));

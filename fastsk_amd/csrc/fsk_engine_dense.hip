@@ -184,10 +184,28 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
             auto k_count_lut = fsk::k_dense_count<false, true>;
             auto k_count = fsk::k_dense_count<false, false>;
             if (compact) {  // which keys occur per combo -> rank tables -> compacted panels
-                FSK_HIP(hipMemsetAsync(e->d_keybits.p, 0, (size_t)nb * Vw * sizeof(uint32_t), e->stream));
-                FSK_LAUNCH(k_mark, cgrid, dim3(256), lds, e->stream, e->view(), e->cfg.g,
-                           e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C4.p, e->d_C4H.p,
-                           e->d_rowmask.p, nst, e->d_flag.p, Vkeys, (const uint16_t*)nullptr, (const uint16_t*)nullptr, e->d_keybits.p, kc_rows);
+                if (e->compact_rare) {  // from the places of the rare symbols (listed once per set of sequences)
+                    const uint32_t cap = std::max(1u, e->rare_places);
+                    if (!e->rare_ready) {
+                        FSK_HIP(e->d_rare.reserve(cap));
+                        FSK_HIP(e->d_rare_n.reserve(1));
+                        FSK_HIP(hipMemsetAsync(e->d_rare_n.p, 0, sizeof(uint32_t), e->stream));
+                        FSK_LAUNCH(fsk::k_dense_rare_scan, dim3((uint32_t)((e->N + 3) / 4)), dim3(256), 0, e->stream, e->view(), e->rare_mask,
+                                   e->d_rare.p, cap, e->d_rare_n.p);
+                        e->rare_ready = true;
+                    }
+                    FSK_LAUNCH(fsk::k_dense_keybits_init, dim3((Vw + 255u) / 256u, (uint32_t)nb), dim3(256), 0, e->stream, e->d_keybits.p, Vkeys,
+                               e->k, e->sigma, e->rare_mask);
+                    const uint32_t mblocks = (uint32_t)std::max<u64>(1, std::min<u64>(((u64)cap * (u64)e->cfg.g + 255) / 256, 64));
+                    FSK_LAUNCH(fsk::k_dense_mark_rare, dim3(mblocks, (uint32_t)nb), dim3(256), 0, e->stream, e->view(), (const u64*)e->d_rare.p,
+                               (const uint32_t*)e->d_rare_n.p, cap, e->cfg.g, e->k, e->sigma, (const uint8_t*)e->d_pos.p, Vkeys, e->d_keybits.p);
+                    e->st.launches += 1;
+                } else {
+                    FSK_HIP(hipMemsetAsync(e->d_keybits.p, 0, (size_t)nb * Vw * sizeof(uint32_t), e->stream));
+                    FSK_LAUNCH(k_mark, cgrid, dim3(256), lds, e->stream, e->view(), e->cfg.g,
+                               e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C4.p, e->d_C4H.p,
+                               e->d_rowmask.p, nst, e->d_flag.p, Vkeys, (const uint16_t*)nullptr, (const uint16_t*)nullptr, e->d_keybits.p, kc_rows);
+                }
                 FSK_LAUNCH(fsk::k_dense_keylut, dim3(nb), dim3(256), 0, e->stream, e->d_keybits.p, Vkeys, e->d_lut.p, e->d_vc.p);
                 FSK_LAUNCH(k_count_lut, cgrid, dim3(256), lds, e->stream, e->view(), e->cfg.g,
                            e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C4.p, e->d_C4H.p,

@@ -165,6 +165,13 @@ struct fsk_engine {
     DevBuf<uint32_t> d_keybits;   // key compaction: per-combo bitmap of the keys that occur
     DevBuf<uint16_t> d_lut, d_vc; //                  rank table and key count per combo
     bool compact = false;         // decided at load: the alphabet has a rare symbol
+    // key compaction from the places of the rare symbols (k_dense_rare_scan / k_dense_mark_rare) instead of a marking pass
+    // over every window: decided at load (few places, plenty of windows per common key); FSK_COMPACT_RARE=0: never (testing)
+    bool compact_rare = false, rare_ready = false;
+    uint32_t rare_mask = 0, rare_places = 0;
+    int force_compact_rare = -1;
+    DevBuf<u64> d_rare;
+    DevBuf<uint32_t> d_rare_n;
     std::vector<uint16_t> h_vc_cache;
     double vc_sum = 0, vc_n = 0;
     int force_compact = -1;       // FSK_COMPACT=0/1 overrides (testing)

@@ -248,6 +248,65 @@ __global__ __launch_bounds__(256) void k_dense_count(SeqView S, int g, int k, ui
     if (!MARK && seen > 255u) atomicOr(overflow_flag, 1u);
 }
 
+// Key compaction without the marking pass over every window (k_dense_count<true, .>): when the alphabet's rare symbols
+// (an 'n' in DNA) occur at a few places only, the keys a combo can meet are (i) every key made of common symbols alone —
+// the same set for all combos, taken as present — and (ii) the keys of the windows that hold a rare symbol at a KEPT
+// position. k_dense_rare_scan lists the places once per set of sequences; per accumulate k_dense_keybits_init writes (i)
+// into every combo's bitmap and k_dense_mark_rare adds (ii): g windows per place and combo instead of all of them. A key
+// of (i) that no window has costs an empty panel row, never a wrong count (the tables map it like any other).
+// grid = ceil(N / 4), block = 256: one wave per sequence.
+__global__ __launch_bounds__(256) void k_dense_rare_scan(SeqView S, uint32_t rare_mask, u64* list, uint32_t cap, uint32_t* count) {
+    const uint32_t seq = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (seq >= S.n_seq) return;
+    const uint32_t len = S.len[seq], wbase = S.wstart[seq];
+    for (uint32_t p = lane; p < len; p += 64u) {
+        const uint32_t sym = fetch_sym(S.words, wbase, p, S.bits);
+        if ((rare_mask >> sym) & 1u) {
+            const uint32_t at = atomicAdd(count, 1u);
+            if (at < cap) list[at] = ((u64)seq << 32) | p;
+        }
+    }
+}
+
+// grid = (ceil(Vw / 256), n_slots): word i of every combo's bitmap = the keys 32 i .. 32 i + 31 whose digits are all common
+__global__ __launch_bounds__(256) void k_dense_keybits_init(uint32_t* keybits, uint32_t V, int k, uint32_t sigma, uint32_t rare_mask) {
+    const uint32_t Vw = (V + 31u) >> 5, i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= Vw) return;
+    uint32_t word = 0;
+    for (uint32_t b = 0; b < 32u; ++b) {
+        uint32_t x = 32u * i + b;
+        if (x >= V) break;
+        bool ok = true;
+        for (int c = 0; c < k; ++c) { ok = ok && !((rare_mask >> (x % sigma)) & 1u); x /= sigma; }
+        if (ok) word |= 1u << b;
+    }
+    keybits[(size_t)blockIdx.y * Vw + i] = word;
+}
+
+// grid = (blocks, n_slots), block = 256: thread = (place, window offset d): the window that starts d symbols before the place
+// holds the rare symbol at its position d — when the combo keeps that position, the window's key gets its bit
+__global__ __launch_bounds__(256) void k_dense_mark_rare(SeqView S, const u64* list, const uint32_t* count, uint32_t cap, int g, int k,
+                                                         uint32_t sigma, const uint8_t* combo_pos, uint32_t V, uint32_t* keybits) {
+    const uint32_t slot = blockIdx.y, Vw = (V + 31u) >> 5;
+    const uint32_t n = *count < cap ? *count : cap;
+    const u64 work = (u64)n * (u64)g;
+    const uint8_t* pos = combo_pos + (size_t)slot * k;
+    for (u64 t = (u64)blockIdx.x * 256u + threadIdx.x; t < work; t += (u64)gridDim.x * 256u) {
+        const uint32_t ent = (uint32_t)(t / (u64)g), d = (uint32_t)(t % (u64)g);
+        const u64 rec = list[ent];
+        const uint32_t seq = (uint32_t)(rec >> 32), p = (uint32_t)rec;
+        const uint32_t len = S.len[seq];
+        if (p < d || p - d + (uint32_t)g > len) continue;  // no such window
+        bool kept = false;
+        for (int c = 0; c < k; ++c) kept = kept || (uint32_t)pos[c] == d;
+        if (!kept) continue;
+        const uint32_t j = p - d, wbase = S.wstart[seq];
+        uint32_t key = 0;
+        for (int c = 0; c < k; ++c) key = key * sigma + fetch_sym(S.words, wbase, j + (uint32_t)pos[c], S.bits);
+        atomicOr(&keybits[(size_t)slot * Vw + (key >> 5)], 1u << (key & 31u));
+    }
+}
+
 // Key compaction table of one combo: rank of every key that occurs, 0xFFFF otherwise; vc = how
 // many occur. grid = n_slots, block = 256. V <= 8192 (256 bitmap words).
 __global__ __launch_bounds__(256) void k_dense_keylut(const uint32_t* keybits, uint32_t V, uint16_t* lut_g, uint16_t* vc) {

@@ -697,13 +697,17 @@ def test_emu_variance_mode_sparse_fallbacks(emu_lib, monkeypatch, env):
     e.close()
 
 
-@pytest.mark.parametrize("g,m,force", [(8, 4, None), (9, 4, None), (8, 4, "1"), (7, 5, "1")])
-def test_emu_key_compaction_rare_symbol(emu_lib, port, monkeypatch, g, m, force):
+@pytest.mark.parametrize("g,m,force,rare", [(8, 4, None, None), (9, 4, None, "1"), (8, 4, "1", "1"), (7, 5, "1", "1"), (8, 4, "1", "0"),
+                                            (7, 5, "1", "0")])
+def test_emu_key_compaction_rare_symbol(emu_lib, port, monkeypatch, g, m, force, rare):
     """DNA with a few 'n': the 5^k key space is mostly empty; the dense dataflow counts only the
-    keys that occur (per-combo rank table) and must still match the oracle bit for bit."""
+    keys that occur (per-combo rank table) and must still match the oracle bit for bit — with the keys found by
+    a marking pass over every window (FSK_COMPACT_RARE=0) and from the places of the rare symbol alone (=1)."""
     from fastsk_amd import _native
     if force is not None:
         monkeypatch.setenv("FSK_COMPACT", force)
+    if rare is not None:
+        monkeypatch.setenv("FSK_COMPACT_RARE", rare)
     rng = np.random.default_rng(g * 7 + m)
     X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(g, 80, size=150)]
     for i in (3, 70, 149):

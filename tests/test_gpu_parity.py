@@ -1367,13 +1367,15 @@ def test_sparse_pair_accumulation_variants(native, port, monkeypatch, global_pai
     e.close()
 
 
-@pytest.mark.parametrize("force", [None, "0", "1", "regs"])
+@pytest.mark.parametrize("force", [None, "0", "1", "regs", "mark"])
 def test_key_compaction_rare_symbol(native, port, monkeypatch, force):
     """DNA with a few 'n' (config-3-like): key compaction on (auto / forced; through the direct-to-LDS compact
     tile kernel, the default, and the register-staged one) and off give the oracle's counts; with compaction
     the tile kernel multiplies far fewer keys than 5^4."""
     if force == "regs":
         monkeypatch.setenv("FSK_COMPACT_DMA", "0")
+    elif force == "mark":  # (the keys that occur from a marking pass over every window, not from the places of the rare symbol)
+        monkeypatch.setenv("FSK_COMPACT_RARE", "0")
     elif force is not None:
         monkeypatch.setenv("FSK_COMPACT", force)
     rng = np.random.default_rng(77)
