@@ -5,11 +5,11 @@
 # and the micro-benchmarks. Raw output lands in gpurun_out/prof/ and gpurun_out/pmc/;
 # tools/collect_profiles.py turns it into the files under profiles/.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
 rm -rf "$O"; mkdir -p "$O"
-cd "$R" && python3 bench.py --steps 2 --warmup 1 > "$O/bench.json" 2> "$O/bench.err"
+cd "$R" && python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$O/bench.json" 2> "$O/bench.err"
 FSK_BENCH_FORCE_DIST=1 MASTER_PORT=29777 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also > "$O/bench_rccl_world1.json" 2> "$O/bench_rccl_world1.err"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-also > "$O/bench_under_rocprof.json" 2> "$O/stats.err"
