@@ -27,6 +27,11 @@ def main(iters=150, seed=0):
         if N > 3 and rng.random() < 0.5:  # low-complexity rows: counts above 15 / 255
             X[int(rng.integers(N))][:] = 1
             j = int(rng.integers(N)); X[j][: len(X[j]) // 2] = 2
+        if sigma >= 3 and N > 8 and rng.random() < 0.5:  # a rare symbol at a few places (the alphabet's last one, elsewhere remapped)
+            for i in range(N):
+                X[i][X[i] == sigma] = 1 + (i % (sigma - 1))
+            for i in rng.choice(N, size=min(N, 5), replace=False):
+                X[int(i)][int(rng.integers(len(X[int(i)])))] = sigma
         tokens, offsets = _native.flatten(X)
         nc = _native.library().num_combos(g, m)
         combos = np.unique(rng.integers(0, nc, size=int(rng.integers(1, 24)))).astype(np.int32)
@@ -44,6 +49,15 @@ def main(iters=150, seed=0):
             os.environ.pop("FSK_SPARSE_GUARD_CAP", None)
             if name == "sparse" and rng.random() < 0.3:
                 os.environ["FSK_SPARSE_GUARD_CAP"] = str(int(rng.choice([1, 64, 5000])))
+            # (round 4) key compaction from the places of the rare symbols, forced on and off; a rare symbol planted in half
+            # of the cases; the batches of an exact accumulate in two lanes, with batches of a few combos
+            for v in ("FSK_COMPACT_RARE", "FSK_SPARSE_EXACT_LANES", "FSK_SPARSE_BATCH_RECORDS"):
+                os.environ.pop(v, None)
+            if name == "dense_compact":
+                os.environ["FSK_COMPACT_RARE"] = str(int(rng.integers(0, 2)))
+            if path == 2 and rng.random() < 0.5:
+                os.environ["FSK_SPARSE_EXACT_LANES"] = "2"
+                os.environ["FSK_SPARSE_BATCH_RECORDS"] = str(max(1, int(rng.integers(1, 5)) * int(sum(max(0, int(L) - g + 1) for L in lens))))
             if os.environ.get("FSK_STRESS_VERBOSE"):
                 print("   %s guard=%s" % (name, os.environ.get("FSK_SPARSE_GUARD_CAP")), flush=True)
             e = _native.Engine(g, m, path=path)
