@@ -191,7 +191,8 @@ def config_roofline(st, wall_s):
            "frac_of_hbm_peak": alg / 1e9 / wall_s / HBM_PEAK_GBS,
            "kernel_ms": {k[3:]: round(st[k], 3) for k in ("ms_count", "ms_tile", "ms_extract", "ms_sort", "ms_segment", "ms_pairs") if st[k]}}
     if st["path_used"] == 1 and st["ms_tile"] > 0:
-        out["valu_frac"] = st["dense_macs"] / (st["ms_tile"] * 1e-3) / 1e12 / VALU_DOT8_PEAK_TMACS
+        out["valu_frac"] = st["dense_macs"] / (st["ms_tile"] * 1e-3) / 1e12 / VALU_DOT8_PEAK_TMACS   # over the tile launch (HIP events)
+        out["valu_frac_of_call"] = st["dense_macs"] / wall_s / 1e12 / VALU_DOT8_PEAK_TMACS         # over the whole fsk_compute call (load, counting, tile launch, finalize)
         out["bound"] = "valu (v_dot8 issue); frac_of_hbm_peak prices a dataflow this kernel does not run"
     else:
         out["bound"] = "hbm"
