@@ -10,7 +10,8 @@ from conftest import load_tokens
 from fastsk_amd import _native
 tokens, offsets, ntr, nte, _, _ = load_tokens("EP300")
 g, m = int(sys.argv[1]), int(sys.argv[2])
-e = _native.Engine(g, m)
+lib = _native.Library(os.environ['AB_LIB']) if os.environ.get('AB_LIB') else None
+e = _native.Engine(g, m, lib=lib) if lib else _native.Engine(g, m)
 e.compute(tokens, offsets, ntr, nte)
 best = 1e9
 for _ in range(3):
