@@ -292,6 +292,7 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     { const char* f = getenv("FSK_COMPACT"); e->force_compact = f ? atoi(f) : -1; }
     { const char* f = getenv("FSK_SPARSE_GLOBAL"); e->force_global_pairs = f ? atoi(f) : 0; }
     { const char* f = getenv("FSK_VARIANCE_DENSE_SLOTS"); if (f) e->variance_dense_slots = atoi(f); }
+    { const char* f = getenv("FSK_VAR_SLOTS16"); if (f) e->allow_slots16 = atoi(f); }
     { const char* f = getenv("FSK_VAR_AHEAD"); if (f && atoi(f) > 0) e->var_ahead = atoi(f); }
     { const char* f = getenv("FSK_SEG_SCAN_CHUNKED"); if (f) e->force_seg_chunks = atoi(f); }
     { const char* f = getenv("FSK_SPARSE_SYNC"); if (f) e->sx_sync = atoi(f); }
@@ -343,6 +344,7 @@ void fsk_detail::one_destroy(fsk_engine* e) {
     if (e->h_sx_stat) (void)hipHostFree(e->h_sx_stat);
     if (e->h_sx_head_pos) (void)hipHostFree(e->h_sx_head_pos);
     if (e->h_sx_head_stat) (void)hipHostFree(e->h_sx_head_stat);
+    if (e->h_sx_head_flag) (void)hipHostFree(e->h_sx_head_flag);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     for (auto& ev : e->ev_lane) if (ev) (void)hipEventDestroy(ev);
     if (e->ev_out) (void)hipEventDestroy(e->ev_out);
@@ -604,6 +606,7 @@ int fsk_detail::one_load_sequences(fsk_engine* e, const int32_t* tokens, const i
     e->lazy_lo = e->lazy_hi = -1;  // (the triangle is zeroed, or promised to be, below)
     e->u_known = false; e->u_pending = false; e->u_extra = 0; e->u_value = 0;
     e->sx_wpr = 0;
+    e->slots16_ok = true;
     for (auto& d : e->sx_defer) d.active = false;
     if (e->V > DENSE_MAX_KEYS) e->Vq = 1;  // unused on the sparse path
     {   // sparse dataflow: sort record = (k-mer << sx_sb) | sequence id; owner bands of K

@@ -212,6 +212,15 @@ struct fsk_engine {
     size_t h_sx_stat_cap = 0;
     unsigned char* h_sx_head_pos = nullptr;  // pinned, fixed size, never moved: positions of variance mode's deferred batches (in flight across calls)
     u64* h_sx_head_stat = nullptr;           //                                   their {pairs, words}
+    // variance mode, grouped sparse batches: u16 slot triangles (half the bytes between k_sx_consume and the Welford pass); a
+    // sum above 65535 raises the batch's flag in pinned memory and the batch is redone with u32 triangles, which the
+    // sequences then keep (slots16_ok). FSK_VAR_SLOTS16=0: never.
+    bool sx_slot16 = false;              // set by run_variance_mode around the accumulate of a deferred batch
+    bool sx_slot16_used = false;         // what accumulate_sparse really did
+    bool slots16_ok = true;
+    int allow_slots16 = 1;
+    uint32_t* h_sx_head_flag = nullptr;  // pinned, fixed size: one overflow flag per deferred batch
+    uint32_t* sx_ovf_now = nullptr;      // the flag of the batch being enqueued
     int sx_last_lane = 0;                // the lane (scratch + stream) the last accumulate_sparse ran in
     double sx_wpr = 0;                   // most update words per sort record of a batch since the sequences were loaded (0: none seen)
     u64 sx_words_of(u64 nrec) const { return (u64)(sx_wpr * (double)nrec) + 1; }  // what a batch of nrec records is expected to emit

@@ -80,6 +80,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     const uint32_t tpg = (nfeat + fsk::SG_TILE - 1) / fsk::SG_TILE;   // segment tiles per slot
     const uint32_t ntiles = tpg * (uint32_t)nb;
     const bool lists = e->sx_lists && !e->force_global_pairs;
+    const bool slot16 = slot_stride != 0 && e->sx_slot16_used;  // (u16 slot triangles: set by accumulate_sparse for a deferred batch)
     const uint32_t O = e->n_owners;
     for (int b = 0; b < 2; ++b) FSK_HIP(S.d_keys[b].reserve(nrec * sizeof(RecT)));
     FSK_HIP(S.d_blockhist.reserve((size_t)256 * tps * nb));
@@ -292,15 +293,25 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             const uint32_t max_parts = O + (uint32_t)(((guarded ? guard_cap : words) + target - 1) / target);
             if (k_wait) FSK_HIP(hipStreamWaitEvent(stream, k_wait, 0));
             if (slot_stride != 0) {  // one triangle per slot: a slot's words of a stream are one contiguous piece
-                FSK_LAUNCH(fsk::k_sx_consume<true>, dim3(O, e->sx_rounds_slot, nb), dim3(fsk::CS_THREADS), lds_slot, stream, (const uint32_t*)S.d_ulist.p,
-                           (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)nullptr, O, target,
-                           e->sx_cap_slot, e->sx_pb, K, (const uint32_t*)S.d_ucount.p, tpg, slot_stride, (const u64*)S.d_sxstat.p, cap_words);
+                if (slot16) {
+                    auto k_cs16 = fsk::k_sx_consume<true, true>;
+                    FSK_HIP(fsk_hw::allow_dynamic_lds(k_cs16, lds_slot));
+                    FSK_LAUNCH(k_cs16, dim3(O, e->sx_rounds_slot, nb), dim3(fsk::CS_THREADS), lds_slot, stream, (const uint32_t*)S.d_ulist.p,
+                               (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)nullptr, O, target,
+                               e->sx_cap_slot, e->sx_pb, K, (const uint32_t*)S.d_ucount.p, tpg, slot_stride, (const u64*)S.d_sxstat.p, cap_words,
+                               e->sx_ovf_now);
+                } else {
+                    FSK_LAUNCH(fsk::k_sx_consume<true>, dim3(O, e->sx_rounds_slot, nb), dim3(fsk::CS_THREADS), lds_slot, stream, (const uint32_t*)S.d_ulist.p,
+                               (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)nullptr, O, target,
+                               e->sx_cap_slot, e->sx_pb, K, (const uint32_t*)S.d_ucount.p, tpg, slot_stride, (const u64*)S.d_sxstat.p, cap_words,
+                               (uint32_t*)nullptr);
+                }
             } else {
                 FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, stream, (const uint32_t*)S.d_list_off.p, O, target, S.d_part_base.p,
                            (const u64*)S.d_sxstat.p, cap_words);
                 FSK_LAUNCH(fsk::k_sx_consume<false>, dim3(max_parts, e->sx_rounds), dim3(fsk::CS_THREADS), lds, stream, (const uint32_t*)S.d_ulist.p,
                            (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)S.d_part_base.p, O, target,
-                           e->sx_cap, e->sx_pb, K, (const uint32_t*)nullptr, tpg, (u64)0, (const u64*)S.d_sxstat.p, cap_words);
+                           e->sx_cap, e->sx_pb, K, (const uint32_t*)nullptr, tpg, (u64)0, (const u64*)S.d_sxstat.p, cap_words, (uint32_t*)nullptr);
                 e->st.launches += 1;
             }
             e->st.launches += 2;
@@ -328,7 +339,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     if (row1 > row0)
         FSK_LAUNCH(fsk::k_sx_diag_windows, dim3((uint32_t)((row1 - row0 + 255) / 256), slot_stride ? nb : 1), dim3(256), 0, stream,
                    (const uint32_t*)e->d_fstart.p, (uint32_t)row0, (uint32_t)row1, (uint32_t)nb, K, slot_stride,
-                   use_lists ? (const u64*)S.d_sxstat.p : (const u64*)nullptr, cap_words);
+                   use_lists ? (const u64*)S.d_sxstat.p : (const u64*)nullptr, cap_words, slot16 ? 1 : 0, slot16 ? e->sx_ovf_now : (uint32_t*)nullptr);
     e->st.launches += 1;
     if (k_done) FSK_HIP(hipEventRecord(k_done, stream));
     e->toc(&e->st.ms_pairs);
@@ -375,6 +386,8 @@ int sx_pinned(fsk_engine* e, size_t tail_pos_bytes, size_t tail_stat_words) {
         FSK_HIP(hipHostMalloc((void**)&e->h_sx_head_pos, SX_HEAD_POS));
         FSK_HIP(hipHostMalloc((void**)&e->h_sx_head_stat, SX_HEAD_STAT * sizeof(u64)));
         memset(e->h_sx_head_stat, 0, SX_HEAD_STAT * sizeof(u64));
+        FSK_HIP(hipHostMalloc((void**)&e->h_sx_head_flag, SX_DEFER * sizeof(uint32_t)));
+        memset(e->h_sx_head_flag, 0, SX_DEFER * sizeof(uint32_t));
     }
     if (tail_pos_bytes > e->h_sx_pos_cap) {
         if (e->h_sx_pos) (void)hipHostFree(e->h_sx_pos);
@@ -407,7 +420,18 @@ u64 sx_guard_for(fsk_engine* e, int lane, u64 nrec) {
 
 // the counts of deferred batch `slot` (its kernels have finished): false when it has to be redone
 bool sx_harvest(fsk_engine* e, int slot) {
-    if (slot < 0 || !e->sx_defer[slot].active) return true;
+    if (slot < 0) return true;
+    if (e->h_sx_head_flag && e->h_sx_head_flag[slot]) {  // a sum did not fit its u16 slot triangle (k_sx_consume): u32 from here on
+        e->h_sx_head_flag[slot] = 0u;
+        e->slots16_ok = false;
+        e->sx_redone += 1;
+        if (e->sx_defer[slot].active) {
+            e->sx_defer[slot].active = false;
+            e->sx_saw(e->h_sx_head_stat[2 * slot + 1], e->sx_defer[slot].nrec);
+        }
+        return false;
+    }
+    if (!e->sx_defer[slot].active) return true;
     e->sx_defer[slot].active = false;
     const u64 pairs = e->h_sx_head_stat[2 * slot], words = e->h_sx_head_stat[2 * slot + 1];
     e->sx_saw(words, e->sx_defer[slot].nrec);
@@ -454,7 +478,11 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
                : recbits <= 64 ? sparse_batch<u64>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard, ln, pos_off, k_wait, k_done)
                                : sparse_batch<u128>(e, combos + s, nb, Kb, row0, row1, slot_stride, pos_pin, stat_pin, guard, ln, pos_off, k_wait, k_done);
     };
+    e->sx_slot16_used = false;
     if (defer >= 0) {
+        e->sx_slot16_used = e->sx_slot16 && slot_stride != 0 && e->sx_lists && !e->force_global_pairs;
+        e->sx_ovf_now = e->h_sx_head_flag + defer;
+        e->h_sx_head_flag[defer] = 0u;
         const u64 guard = sx_guard_for(e, lane, (u64)n * nfeat);
         e->sx_defer[defer].active = guard != 0;
         e->sx_defer[defer].cap = guard;

@@ -121,7 +121,7 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     const uint32_t wblocks = (uint32_t)((pairs + 256 * fsk::WF_ITEMS - 1) / (256 * fsk::WF_ITEMS)); // k_welford
     const int n_order = (int)e->order.size();
     auto khat = [&](int i) { return e->d_Khat.p + (size_t)(i % RING) * ps; };
-    struct Batch { int n = 0, first_iter = 0, first_item = 0, base = 0, part = 0, lane = 0; bool grouped = false; };
+    struct Batch { int n = 0, first_iter = 0, first_item = 0, base = 0, part = 0, lane = 0; bool grouped = false, s16 = false; };
     // Where the stop test is expected to fire: the variance estimate settles, so sd falls like 1 / sqrt(iter) and
     // delta / sd > 1.96 is reached near iter * (1.96 sd / delta)^2. Only the SIZE of the batches issued ahead follows
     // from it (what lies beyond the stop is thrown away: a full batch there is an eighth of config 1's work); a
@@ -179,7 +179,12 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
             const size_t slot = (size_t)B.part * AHEAD + c;
             fsk::WfRecip rr;  // 1 / iteration number of every slot of the pass (the IEEE quotient, as the kernels compute it)
             for (int q = 0; q < fsk::WF_SLOTS; ++q) rr.r[q] = 1.0 / ((double)(B.first_iter + c) + (double)q);
-            if (u64_slots)
+            if (B.s16 && !u64_slots)  // (u16 slot triangles: the same cells, `ps` apart, in half the bytes)
+                FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch_v<uint16_t>), dim3(wblocks), dim3(256), 0, st,
+                           reinterpret_cast<const uint16_t*>(slots_of(B.part)) + (size_t)c * ps, (u64)ps, nc, (const double*)khat(B.base + c), khat(B.base + c + nc),
+                           with_sums ? e->d_prod.p + slot * tps : (double*)nullptr, (u64)tps, (u64)pairs, (u64)train_pairs,
+                           (double)(B.first_iter + c), rr, with_sums ? e->d_bsum.p + slot * nblk : (double*)nullptr, (uint32_t)nblk, with_sums);
+            else if (u64_slots)
                 FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_welford_batch_v<u64>), dim3(wblocks), dim3(256), 0, st, (const u64*)slots64_of(B.part) + (size_t)c * ps,
                            (u64)ps, nc, (const double*)khat(B.base + c), khat(B.base + c + nc), with_sums ? e->d_prod.p + slot * tps : (double*)nullptr,
                            (u64)tps, (u64)pairs, (u64)train_pairs, (double)(B.first_iter + c), rr,
@@ -202,7 +207,10 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
         if (grouped) {
             int32_t combos[MAX_AHEAD];
             for (int b = 0; b < B.n; ++b) combos[b] = e->order[B.first_item + b * T];
+            e->sx_slot16 = e->allow_slots16 && e->slots16_ok;  // (u16 slot triangles until a sum of these sequences has not fit one)
             int rc = do_accumulate(e, combos, B.n, reinterpret_cast<u64*>(slots_of(B.part)), 0, -1, (u64)ps, B.part);
+            e->sx_slot16 = false;
+            B.s16 = e->sx_slot16_used;
             if (rc == FSK_RETRY_UNGROUPED) grouped = false;  // too many updates for one stream: from here on one iteration at a time
             else if (rc) return rc;
         }

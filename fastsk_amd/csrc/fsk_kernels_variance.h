@@ -125,6 +125,13 @@ template <> struct WfVec<uint32_t> {
         x[0] = (double)v.x; x[1] = (double)v.y; x[2] = (double)v.z; x[3] = (double)v.w;
     }
 };
+template <> struct WfVec<uint16_t> {  // (u16 slot triangles, 8 bytes per load: half the bytes of the u32 form for the same cells)
+    static constexpr int V = 4;
+    static __device__ __forceinline__ void load(const uint16_t* p, double (&x)[4]) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p);
+        x[0] = (double)(v.x & 0xffffu); x[1] = (double)(v.x >> 16); x[2] = (double)(v.y & 0xffffu); x[3] = (double)(v.y >> 16);
+    }
+};
 template <> struct WfVec<u64> {
     static constexpr int V = 2;
     static __device__ __forceinline__ void load(const u64* p, double (&x)[2]) {

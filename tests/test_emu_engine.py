@@ -160,7 +160,7 @@ def poly_a_sequences(n=24, L=300, seed=11):
     return X
 
 
-@pytest.mark.parametrize("form", ["dense_slots", "dense_fill", "sparse"])
+@pytest.mark.parametrize("form", ["dense_slots", "dense_fill", "sparse", "sparse_u32"])
 def test_emu_variance_mode_count_above_255(emu_lib, port, form, monkeypatch):
     """Variance mode on the dense dataflow keeps one triangle per iteration in flight and lets the
     tile launch STORE into it; an iteration whose counts overflow the panels is diverted to the
@@ -172,12 +172,20 @@ def test_emu_variance_mode_count_above_255(emu_lib, port, form, monkeypatch):
     g, m, T = 5, 2, 2
     order = np.random.default_rng(3).permutation(port.num_combos(g, m)).astype(np.int32)
     want, sd, _ = port.compute(tok, off, 16, 8, g, m, t=T, approx=True, delta=0.025, max_iters=-1, order=order)
-    e = _native.Engine(g, m, t=T, approx=True, path=2 if form == "sparse" else 1, lib=emu_lib)
+    if form == "sparse_u32":
+        monkeypatch.setenv("FSK_VAR_SLOTS16", "0")
+    e = _native.Engine(g, m, t=T, approx=True, path=2 if form.startswith("sparse") else 1, lib=emu_lib)
     e.set_combo_order(order)
     e.compute(tok, off, 16, 8)
     assert e.stats()["max_windows"] > 255
     assert np.array_equal(e.get_stdevs(), sd)
     assert np.array_equal(e.get_triangle(), want)
+    # (sparse dataflow: the slot triangles are u16 until a sum does not fit — two 286-window runs of one k-mer meet in a
+    # cell of 81,796 — and that batch is redone with u32 triangles, which the sequences then keep)
+    if form == "sparse":
+        assert e.stats()["batches_redone"] == 1
+    if form == "sparse_u32":
+        assert e.stats()["batches_redone"] == 0
     e.close()
 
 

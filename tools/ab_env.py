@@ -21,7 +21,7 @@ for name in sys.argv[1].split(","):
     st = e.stats()
     dg = e.counts_digest() if not d["approx"] else (0, 0)
     out[name] = {"ms": round(best * 1e3, 3), "issued": st["combos_issued"], "done": st["combos_done"], "stdevs": len(e.get_stdevs()),
-                 "launches": st["launches"] // 8, "digest": format(int(dg[0]), "x") + "." + format(int(dg[1]), "x")}
+                 "launches": st["launches"] // 8, "redone": st["batches_redone"], "digest": format(int(dg[0]), "x") + "." + format(int(dg[1]), "x")}
     e.close()
 print(json.dumps(out))
 ''' % (ROOT, ROOT)
