@@ -499,7 +499,14 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     // their update words) 1.735 -> 1.66-1.68 s; config 4 (three batches of 2^27 records) 10.1 -> 10.4-10.8 ms — big batches
     // fill the GPU by themselves and two of them at once only share its caches — hence: from six batches on.
     const int nb0 = batch_combos(n);
-    const bool many = (n + nb0 - 1) / nb0 >= 6;
+    // (how many batches the call takes once its first batch has been sized: the 2^25-record cap of a first batch — every
+    // fsk_compute starts with one — says nothing about the batches that follow)
+    int nb_steady = nb0;
+    if (e->sx_wpr == 0) {
+        const size_t recs = e->sx_batch_records ? e->sx_batch_records : SPARSE_MAX_RECORDS;
+        nb_steady = (int)std::max<u64>(1, std::min<u64>({(u64)(recs / nfeat), (u64)n, by_cells, (u64)65535}));
+    }
+    const bool many = (n + nb_steady - 1) / nb_steady >= 6;
     const bool two = (e->sx_exact_lanes >= 2 || (e->sx_exact_lanes == 0 && many)) && !e->cfg.profile && !e->sx_sync && slot_stride == 0 && nb0 < n;
     if (two) {
         if (!e->lane_stream) FSK_HIP(hipStreamCreateWithFlags(&e->lane_stream, hipStreamNonBlocking));

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run one BASELINE config once through the C ABI (for rocprofv3 --pmc passes)."""
+"""Run one BASELINE config once (PROFILE_CALLS=n: n times) through the C ABI (for rocprofv3 --pmc passes)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,5 +13,6 @@ e = _native.Engine(d["g"], d["m"], t=d["t"], approx=bool(d["approx"]), delta=d["
                    skip_variance=bool(d["skip_variance"]))
 if d["approx"]:
     e.set_combo_order(d["order"])
-e.compute(tokens, offsets, ntr, nte)
+for _ in range(int(os.environ.get('PROFILE_CALLS', '1'))):
+    e.compute(tokens, offsets, ntr, nte)
 print(e.stats()["combos_done"])
