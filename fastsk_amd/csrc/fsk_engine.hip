@@ -302,6 +302,7 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     { const char* f = getenv("FSK_TILE_DMA"); e->tile_dma = f ? atoi(f) : 1; }
     { const char* f = getenv("FSK_SPARSE_LANES"); if (f) e->sx_two_lanes = atoi(f) >= 2; }
     { const char* f = getenv("FSK_SPARSE_BATCH_RECORDS"); if (f && atoll(f) > 0) e->sx_batch_records = (size_t)atoll(f); }
+    { const char* f = getenv("FSK_SPARSE_HINT"); if (f) e->sx_hint = atoi(f); }
     { const char* f = getenv("FSK_SPARSE_EXACT_PARTS"); if (f && atoi(f) > 0) e->sx_exact_parts = atoi(f); }
     { const char* f = getenv("FSK_SPARSE_EXACT_LANES"); if (f) e->sx_exact_lanes = atoi(f); }
     { const char* f = getenv("FSK_COMPACT_RARE"); e->force_compact_rare = f ? atoi(f) : -1; }
@@ -605,8 +606,17 @@ int fsk_detail::one_load_sequences(fsk_engine* e, const int32_t* tokens, const i
     e->prep_valid = false; e->tab_n = 0; e->vc_sum = 0; e->vc_n = 0;
     e->lazy_lo = e->lazy_hi = -1;  // (the triangle is zeroed, or promised to be, below)
     e->u_known = false; e->u_pending = false; e->u_extra = 0; e->u_value = 0;
-    e->sx_wpr = 0;
-    e->slots16_ok = true;
+    {
+        // The update words per record seen on the previous set of sequences stay as a HINT when the new set has the same shape
+        // (sequences, windows, alphabet, longest sequence: the same data loaded again, or its next fold): the first batch is then
+        // enqueued under a guard like every later one instead of being capped at 2^25 records and waited for. A hint that is
+        // too low costs what any overflowing guard costs — the batch leaves K alone and is redone sized exactly —, never a
+        // result. FSK_SPARSE_HINT=0: every set of sequences starts from nothing (testing).
+        const bool same = e->sx_hint && e->loaded && e->sx_shape[0] == (u64)N && e->sx_shape[1] == (u64)nfeat && e->sx_shape[2] == (u64)sigma &&
+                          e->sx_shape[3] == (u64)longest;
+        if (!same) { e->sx_wpr = 0; e->slots16_ok = true; }
+        e->sx_shape[0] = (u64)N; e->sx_shape[1] = (u64)nfeat; e->sx_shape[2] = (u64)sigma; e->sx_shape[3] = (u64)longest;
+    }
     for (auto& d : e->sx_defer) d.active = false;
     if (e->V > DENSE_MAX_KEYS) e->Vq = 1;  // unused on the sparse path
     {   // sparse dataflow: sort record = (k-mer << sx_sb) | sequence id; owner bands of K

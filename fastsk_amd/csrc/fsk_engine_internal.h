@@ -222,6 +222,8 @@ struct fsk_engine {
     uint32_t* h_sx_head_flag = nullptr;  // pinned, fixed size: one overflow flag per deferred batch
     uint32_t* sx_ovf_now = nullptr;      // the flag of the batch being enqueued
     int sx_last_lane = 0;                // the lane (scratch + stream) the last accumulate_sparse ran in
+    int sx_hint = 1;                     // FSK_SPARSE_HINT=0: the words per record of the previous set of sequences are never kept as a hint
+    u64 sx_shape[4] = {0, 0, 0, 0};      // sequences, windows, alphabet, longest sequence of the set at hand
     double sx_wpr = 0;                   // most update words per sort record of a batch since the sequences were loaded (0: none seen)
     u64 sx_words_of(u64 nrec) const { return (u64)(sx_wpr * (double)nrec) + 1; }  // what a batch of nrec records is expected to emit
     void sx_saw(u64 words, u64 nrec) { if (nrec) sx_wpr = std::max(sx_wpr, std::max(1e-9, (double)words / (double)nrec)); }

@@ -657,6 +657,36 @@ def test_emu_sparse_exact_accumulate_in_two_lanes(emu_lib, port, monkeypatch, en
     e.close()
 
 
+@pytest.mark.parametrize("hint", [None, "0"])
+def test_emu_sparse_words_per_record_hint_across_loads(emu_lib, port, monkeypatch, hint):
+    """Sparse dataflow: a second set of sequences of the same shape (sequences, windows, alphabet, longest) starts from the
+    words per record of the first as a hint — its first batch is enqueued under a guard instead of waited for —, and a hint
+    that is far too low (low-complexity sequences after random ones) only costs a redone batch."""
+    from fastsk_amd import _native
+    if hint is not None:
+        monkeypatch.setenv("FSK_SPARSE_HINT", hint)
+    rng = np.random.default_rng(5)
+    N, L, g, m = 90, 50, 7, 3
+    A = rng.integers(1, 5, size=(N, L), dtype=np.int32)
+    B = rng.integers(1, 3, size=(N, L), dtype=np.int32)   # two symbols: 16 k-mers, runs through nearly every sequence —
+    B[0, :4] = [1, 2, 3, 4]                                 # twice the update words per record (the alphabet stays the same)
+    combos = np.arange(0, port.num_combos(g, m), 3, dtype=np.int32)
+    e = _native.Engine(g, m, path=2, lib=emu_lib)
+    redone = []
+    for X in (A, B, B):
+        tok, off = _native.flatten(X)
+        want, _, U = port.raw_counts(tok, off, g, m, combos)
+        before = e.stats()["cell_updates"]
+        e.load_sequences(tok, off, 60, 30)
+        e.accumulate(combos)
+        e.finalize()
+        assert np.array_equal(e.get_counts(), want)
+        redone.append(e.stats()["batches_redone"])
+    # (A sized exactly; B's first batch under A's hint overflows and is redone unless hints are off; B again fits its own hint)
+    assert redone == ([0, 1, 1] if hint is None else [0, 0, 0])
+    e.close()
+
+
 @pytest.mark.parametrize("max_words", ["3000", "40000"])
 def test_emu_sparse_batches_sized_by_words_per_record(emu_lib, port, monkeypatch, max_words):
     """Sparse dataflow: once a batch of a set of sequences has been counted, later batches take as many
