@@ -577,3 +577,13 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
 }
 
 }  // namespace fsk_detail
+
+#if defined(FSK_EM_CLOCKS) && FSK_EM_CLOCKS
+// measurement builds only (tools/emit_phases.py): the cycle sums of k_sx_emit's phases since the last call, then zeroed
+extern "C" int fsk_debug_emit_clocks(unsigned long long* out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(fsk::g_em_clk), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(fsk::g_em_clk), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
+
