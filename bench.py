@@ -175,6 +175,55 @@ def cpu_baseline(g, m, L, n_full, budget_s, sizes=(4000, 8000)):
     }
 
 
+def live_traffic(args, dense):
+    """HBM bytes of the dominant kernel (dense: the tile launch; sparse: one pass of the pipeline), measured NOW: two child
+    runs of this script (`--one-pass`: one fsk_compute of the workload, nothing else) under `rocprofv3 --pmc` — FETCH_SIZE,
+    then WRITE_SIZE, never together; `--kernel-trace` only, the program itself after `--`, cwd /tmp. gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE reads
+    half of 16-byte streaming fetches, so it is doubled (an upper bound for narrow reads); both counters are KiB.
+    Returns (bytes or None, note)."""
+    import csv, glob, shutil, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCP_TOOL_LIBRARIES"):
+        return None, "this run is itself under a profiler"
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out_dir = tempfile.mkdtemp(prefix="fsk_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out_dir, "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--one-pass", "--config", str(args.config), "--n-seq", str(args.n_seq), "--seq-len", str(args.seq_len)]
+        if args.g is not None:
+            cmd += ["-g", str(args.g)]
+        if args.m is not None:
+            cmd += ["-m", str(args.m)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=300)
+            files = glob.glob(os.path.join(out_dir, "**", "*_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s pass failed (rc %s): %s" % (counter, r.returncode, (r.stderr or "")[-160:].replace("\n", " "))
+            per_kernel = {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == counter and "fsk::" in row["Kernel_Name"]:
+                        name = row["Kernel_Name"].split("(")[0]
+                        per_kernel.setdefault(name, []).append(float(row["Counter_Value"]))
+            if dense:
+                tile = [v for k, vs in per_kernel.items() if "k_dense_tile" in k for v in vs]
+                if not tile:
+                    return None, "no k_dense_tile dispatch in the --pmc %s pass" % counter
+                got[counter] = max(tile)
+            else:
+                got[counter] = sum(v for k, vs in per_kernel.items() if "k_sx_" in k for v in vs)
+        except Exception as exc:
+            return None, "rocprofv3 --pmc %s pass: %r" % (counter, exc)
+        finally:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    return got["FETCH_SIZE"] * 1024.0 * 2.0 + got["WRITE_SIZE"] * 1024.0, (
+        "measured in THIS run: two child passes of this command under rocprofv3 --pmc (FETCH_SIZE %.0f KiB x 2 for the gfx950 "
+        "16-byte-fetch correction + WRITE_SIZE %.0f KiB), %s" % (got["FETCH_SIZE"], got["WRITE_SIZE"],
+        "the 495-combo tile launch" if dense else "summed over the sparse pipeline's kernels of one pass"))
+
+
 def config_roofline(st, wall_s):
     """SURVEY 8(d) for one whole fsk_compute call: algorithmic bytes = 16*U + per combo (16*P*nfeat + packed
     input), over the wall time of the call, as a fraction of the HBM peak (sparse dataflow); the dense
@@ -432,6 +481,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=260.0, help="budget of the CPU baseline (rows that do not fit are skipped)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra measurements of configs 1-4 (profiling runs)")
+    ap.add_argument("--one-pass", action="store_true", help=argparse.SUPPRESS)  # (live_traffic's child: one fsk_compute, nothing else)
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from profiles/traffic*.json instead of two rocprofv3 --pmc child passes of this command")
     ap.add_argument("--bands", type=int, default=None, help="row bands of the overlapped all-reduce (default: auto)")
     ap.add_argument("--shard", choices=["combos", "rows"], default="combos",
                     help="multi-GPU decomposition reported as `value` (the other one is `alt`)")
@@ -488,8 +540,12 @@ def roofline_of(args, s0, s1, dense, world, combos_rank, share_rows, offsets, n_
         macs = d("dense_macs") / launches
         tmacs = macs / secs / 1e12 if secs > 0 else 0.0
         traffic, traffic_note = None, "no profiles/traffic.json for this launch shape"
+        live_note = None
+        if world == 1 and not args.no_live_traffic and not args.inproc and launches == args.steps:  # (one launch per step: the un-banded form)
+            traffic, live_note = live_traffic(args, True)
+            traffic_note = live_note
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if world == 1 and os.path.exists(tpath):  # (measured on the single-GPU launch: does not describe a rank's band)
+        if traffic is None and world == 1 and os.path.exists(tpath):  # (measured on the single-GPU launch: does not describe a rank's band)
             try:
                 tj = json.load(open(tpath))
                 if tj.get("n_seq") != N or tj.get("combos_per_launch") != int(combos_per_launch):
@@ -501,6 +557,8 @@ def roofline_of(args, s0, s1, dense, world, combos_rank, share_rows, offsets, n_
                     traffic_note = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, NOT this run), commit %s" % tj.get("commit", "?")
             except Exception as exc:
                 traffic_note = "profiles/traffic.json unreadable: %r" % exc
+            if live_note:
+                traffic_note += "; live measurement: " + live_note
         roofline = {
             "bound": "valu", "kernel": "k_dense_tile_dma" if os.environ.get("FSK_TILE_DMA", "1") != "0" else "k_dense_tile",
             "achieved": tmacs, "peak": VALU_DOT8_PEAK_TMACS, "unit": "T count-MAC/s (v_dot8_u32_u4: 64 lanes/clk/CU x 8 MACs, 256 CUs, 2.4 GHz)",
@@ -529,8 +587,12 @@ def roofline_of(args, s0, s1, dense, world, combos_rank, share_rows, offsets, n_
         # measured HBM bytes of one config-4 pass: the sum over the pipeline's kernels of the rocprofv3 --pmc passes in
         # profiles/ (FETCH_SIZE x2 + WRITE_SIZE), accepted only for this workload and these sources
         traffic, traffic_note = None, "not collected in this run (profiles/ holds the rocprofv3 --pmc passes of the sparse kernels)"
+        live_note = None
+        if args.config == 4 and world == 1 and not args.no_live_traffic and not args.inproc:
+            traffic, live_note = live_traffic(args, False)
+            traffic_note = live_note
         tpath = os.path.join(ROOT, "profiles", "traffic_config4.json")
-        if args.config == 4 and world == 1 and os.path.exists(tpath):
+        if traffic is None and args.config == 4 and world == 1 and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("combos") != n_mine:
@@ -542,6 +604,8 @@ def roofline_of(args, s0, s1, dense, world, combos_rank, share_rows, offsets, n_
                     traffic_note = "profiles/traffic_config4.json (sum over the pipeline's kernels of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, NOT this run), commit %s" % tj.get("commit", "?")
             except Exception as exc:
                 traffic_note = "profiles/traffic_config4.json unreadable: %r" % exc
+            if live_note:
+                traffic_note += "; live measurement: " + live_note
         roofline = {
             "bound": "hbm", "kernel": "sparse pipeline (k_sx_extract, k_sx_scan_slot/scatter, k_sx_seg_*, k_sx_emit + k_sx_consume); largest family: %s" % max(fam, key=fam.get),
             "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS, "traffic": traffic,
@@ -667,8 +731,21 @@ def main_inproc(args):
     finish(out, args, N, L, g, m, _native)
 
 
+def main_one_pass(args):
+    """What live_traffic()'s children run under rocprofv3: ONE fsk_compute of the workload (load, every combo once,
+    finalize) and nothing else, so that the counters of the pass can be summed per kernel name."""
+    from fastsk_amd import _native
+    tokens, offsets, N, L, g, m, _, _ = workload_of(args)
+    e = _native.Engine(g, m)
+    e.compute(tokens, offsets, N, 0)
+    print(int(e.stats()["combos_done"]))
+    e.close()
+
+
 def main():
     args = parse_args()
+    if args.one_pass:
+        return main_one_pass(args)
     if args.inproc:
         return main_inproc(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

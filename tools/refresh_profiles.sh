@@ -9,12 +9,12 @@ TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
 rm -rf "$O"; mkdir -p "$O"
-cd "$R" && python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$O/bench.json" 2> "$O/bench.err"
-FSK_BENCH_FORCE_DIST=1 MASTER_PORT=29777 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also > "$O/bench_rccl_world1.json" 2> "$O/bench_rccl_world1.err"
+cd "$R" && python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic > "$O/bench.json" 2> "$O/bench.err"
+FSK_BENCH_FORCE_DIST=1 MASTER_PORT=29777 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also --no-live-traffic > "$O/bench_rccl_world1.json" 2> "$O/bench_rccl_world1.err"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-also > "$O/bench_under_rocprof.json" 2> "$O/stats.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-also --no-live-traffic > "$O/bench_under_rocprof.json" 2> "$O/stats.err"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/pmc_$c" -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-also > /dev/null 2> "$O/pmc_$c.err"
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/pmc_$c" -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-also --no-live-traffic > /dev/null 2> "$O/pmc_$c.err"
 done
 # the sparse pipeline's counter passes at config 4 (traffic_config4.json is built from them)
 (cd "$R" && tools/pmc_passes.sh ${TAG}_cfg4 "$R/tools/profile_one.py" f7_cfg4_prot219_exact > "$O/pmc_cfg4.log" 2>&1)
