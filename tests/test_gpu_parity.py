@@ -921,7 +921,7 @@ def test_variance_mode_stops_anywhere(native, port, path, monkeypatch):
     assert len(lengths) >= 6  # stops landed at many different places inside the batches
 
 
-@pytest.mark.parametrize("form", ["dense_slots", "dense_fill", "sparse"])
+@pytest.mark.parametrize("form", ["dense_slots", "dense_fill", "sparse", "sparse_u32"])
 def test_variance_mode_count_above_255(native, port, form, monkeypatch):
     """Variance mode, dense dataflow, a sequence with more than 255 equal windows: the iteration is
     diverted to the general dataflow, which adds into the iteration's own triangle — zeroed first
@@ -936,12 +936,20 @@ def test_variance_mode_count_above_255(native, port, form, monkeypatch):
     g, m, T = 5, 2, 2
     order = np.random.default_rng(3).permutation(port.num_combos(g, m)).astype(np.int32)
     want, sd, _ = port.compute(tok, off, 16, 8, g, m, t=T, approx=True, delta=0.025, max_iters=-1, order=order)
-    e = native.Engine(g, m, t=T, approx=True, path=2 if form == "sparse" else 1)
+    if form == "sparse_u32":
+        monkeypatch.setenv("FSK_VAR_SLOTS16", "0")
+    e = native.Engine(g, m, t=T, approx=True, path=2 if form.startswith("sparse") else 1)
     e.set_combo_order(order)
     e.compute(tok, off, 16, 8)
     assert e.stats()["max_windows"] > 255
     assert np.array_equal(e.get_stdevs(), sd)
     assert np.array_equal(e.get_triangle(), want)
+    # (sparse dataflow: u16 slot triangles until a sum does not fit one — two 286-window runs of one k-mer meet in a cell of
+    # 81,796 — then that batch once more with u32 triangles, which the sequences keep)
+    if form == "sparse":
+        assert e.stats()["batches_redone"] == 1
+    if form == "sparse_u32":
+        assert e.stats()["batches_redone"] == 0
     e.close()
 
 
@@ -1365,6 +1373,63 @@ def test_sparse_pair_accumulation_variants(native, port, monkeypatch, global_pai
     e.finalize()
     assert np.array_equal(e.get_counts(), want)
     e.close()
+
+
+@pytest.mark.parametrize("hint", [None, "0"])
+def test_sparse_words_per_record_hint_across_loads(native, port, monkeypatch, hint):
+    """Sparse dataflow: a second set of sequences of the same shape starts from the first set's words per record as a hint
+    (its first batch goes out under a guard, at full size); a hint that is far too low costs a redone batch, never a count."""
+    if hint is not None:
+        monkeypatch.setenv("FSK_SPARSE_HINT", hint)
+    rng = np.random.default_rng(5)
+    N, L, g, m = 700, 90, 9, 4
+    A = rng.integers(1, 5, size=(N, L), dtype=np.int32)
+    B = rng.integers(1, 3, size=(N, L), dtype=np.int32)   # two symbols: far more update words per record —
+    B[0, :4] = [1, 2, 3, 4]                                 # (the alphabet stays the same)
+    combos = np.arange(0, port.num_combos(g, m), 4, dtype=np.int32)
+    e = native.Engine(g, m, path=2)
+    redone = []
+    for X in (A, B, B):
+        tok, off = native.flatten(X)
+        want, _, _ = port.raw_counts(tok, off, g, m, combos, threads=8)
+        e.load_sequences(tok, off, 500, 200)
+        e.accumulate(combos)
+        e.finalize()
+        assert np.array_equal(e.get_counts(), want)
+        redone.append(e.stats()["batches_redone"])
+    assert redone == ([0, 1, 1] if hint is None else [0, 0, 0])
+    e.close()
+
+
+def test_key_compaction_two_rare_symbols(native, port):
+    """Key compaction from the places of the rare symbols with TWO of them (an 'n' and an 'r' in DNA: sigma = 6), single
+    places and runs, next to each other and at the sequences' ends; the marking pass over every window gives the same."""
+    rng = np.random.default_rng(78)
+    N, L = 900, 140
+    X = rng.integers(1, 5, size=(N, L), dtype=np.int32)
+    for i in rng.choice(N, size=30, replace=False):
+        X[i, rng.integers(0, L, size=2)] = 5
+    for i in rng.choice(N, size=12, replace=False):
+        X[i, rng.integers(0, L, size=2)] = 6
+    X[3, :5] = 5; X[3, 5:9] = 6; X[4, -6:] = 6; X[7, 60] = 5; X[7, 61] = 6
+    tokens, offsets = native.flatten(X)
+    g, m = 8, 4
+    combos = np.arange(0, port.num_combos(g, m), 3, dtype=np.int32)
+    want, _, _ = port.raw_counts(tokens, offsets, g, m, combos, threads=8)
+    got = {}
+    for rare in ("1", "0"):
+        os.environ["FSK_COMPACT_RARE"] = rare
+        try:
+            e = native.Engine(g, m, path=1)
+            e.load_sequences(tokens, offsets, 600, 300)
+            e.accumulate(combos)
+            e.finalize()
+            got[rare] = (e.get_counts(), e.stats()["compact_keys_avg"])
+            e.close()
+        finally:
+            os.environ.pop("FSK_COMPACT_RARE", None)
+    assert np.array_equal(got["1"][0], want) and np.array_equal(got["0"][0], want)
+    assert 256 <= got["0"][1] <= got["1"][1] < 6 ** 4   # (the places' form takes every common key as present: a superset)
 
 
 @pytest.mark.parametrize("force", [None, "0", "1", "regs", "mark"])
