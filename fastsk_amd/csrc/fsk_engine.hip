@@ -51,7 +51,8 @@ void enumerate_combos(int g, int k, std::vector<uint8_t>& out) {
 int host_threads_for(int64_t work_items) {
     if (work_items < ((int64_t)1 << 18)) return 1;
     const unsigned hw = std::thread::hardware_concurrency();
-    const unsigned want = work_items < ((int64_t)1 << 20) ? 4u : 8u;  // (a thread start costs ~50 us)
+    // (a thread start costs ~50 us; the 3 * 10^7 tokens of the 100,000 x 300 workload are worth 32 of them)
+    const unsigned want = work_items < ((int64_t)1 << 20) ? 4u : work_items < ((int64_t)1 << 23) ? 8u : work_items < ((int64_t)1 << 24) ? 16u : 32u;
     return (int)std::max(1u, std::min(want, hw ? hw : 1u));
 }
 template <typename F>
