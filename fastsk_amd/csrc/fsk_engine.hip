@@ -621,6 +621,9 @@ int fsk_detail::one_load_sequences(fsk_engine* e, const int32_t* tokens, const i
     }
     tl_pack = tl_ms(tl0);
     // ---- commit
+    // (the dense dataflow's tile table depends on the number of sequences and the train / test split alone: a set of the same
+    // shape keeps the one on the device)
+    if (e->N != N || e->n_train != n_train) e->tab_n = 0;
     e->N = N; e->n_train = n_train; e->n_test = n_test; e->nfeat = nfeat;
     e->pairs = N * (N + 1) / 2;
     e->sigma = sigma; e->bits = bits; e->V = V; e->Vq = (uint32_t)((V + 3) / 4);
@@ -628,7 +631,8 @@ int fsk_detail::one_load_sequences(fsk_engine* e, const int32_t* tokens, const i
     e->maxW = (uint32_t)(longest - g + 1);
     e->n_panels = (uint32_t)((N + fsk::PANEL - 1) / fsk::PANEL);
     e->h_len = len32; e->h_fstart = fstart; e->featseq_ready = false;
-    e->prep_valid = false; e->tab_n = 0; e->vc_sum = 0; e->vc_n = 0;
+    e->prep_valid = false; e->vc_sum = 0; e->vc_n = 0;
+
     e->lazy_lo = e->lazy_hi = -1;  // (the triangle is zeroed, or promised to be, below)
     e->u_known = false; e->u_pending = false; e->u_extra = 0; e->u_value = 0;
     {

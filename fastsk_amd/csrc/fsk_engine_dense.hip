@@ -109,7 +109,7 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
     FSK_HIP(e->d_rowmask.reserve((size_t)panels_pad * chunk * nst));
     FSK_HIP(e->d_flag.reserve(2));
     FSK_HIP(e->d_pos.reserve((size_t)chunk * e->k));
-    if (e->tab_t0 != t0 || e->tab_t1 != t1 || e->tab_n == 0) {
+    if (e->tab_t0 != t0 || e->tab_t1 != t1 || e->tab_n == 0 || e->tab_ftt != first_test_tile) {
         std::vector<uint32_t> tab;
         build_tile_table(t0, t1, first_test_tile, tab);
         if (first_test_tile == 0xffffffffu && tab.size() != (u64)t1 * (t1 + 1) / 2 - (u64)t0 * (t0 + 1) / 2)
@@ -117,7 +117,7 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
         FSK_HIP(e->d_tiletab.reserve(tab.size()));
         FSK_HIP(hipMemcpyAsync(e->d_tiletab.p, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
         FSK_HIP(hipStreamSynchronize(e->stream));
-        e->tab_t0 = t0; e->tab_t1 = t1; e->tab_n = (uint32_t)tab.size();
+        e->tab_t0 = t0; e->tab_t1 = t1; e->tab_n = (uint32_t)tab.size(); e->tab_ftt = first_test_tile;
     }
     const u64 n_tiles = e->tab_n;
     const bool compact = e->compact;
@@ -156,6 +156,7 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
     }
     std::vector<uint16_t> h_vc;
     std::vector<uint8_t> pos;
+    const uint8_t* chunk_pos = e->d_pos.p;  // the kept positions of the chunk at hand, on the device
     for (int s = 0; s < n; s += chunk) {
         const int nb = std::min(chunk, n - s);
         // the count panels of an unchanged single-chunk combo list are reused by the FOLLOWING row
@@ -164,12 +165,27 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
                             std::equal(combos, combos + n, e->prep_combos.begin());
         if (!cached) {
             e->prep_valid = false;
-            pos.resize((size_t)nb * e->k);
-            for (int q = 0; q < nb; ++q)
-                memcpy(&pos[(size_t)q * e->k], &e->all_pos[(size_t)combos[s + q] * e->k], e->k);
-            FSK_HIP(hipMemcpyAsync(e->d_pos.p, pos.data(), pos.size(), hipMemcpyHostToDevice, e->stream));
-            FSK_HIP(hipMemsetAsync(e->d_flag.p, 0, sizeof(uint32_t), e->stream));
-            FSK_HIP(hipStreamSynchronize(e->stream));  // `pos` is a pageable temporary
+            // the chunk's kept positions: a run of consecutive combo ids (every exact call: 0, 1, 2, ...) reads them from the
+            // resident table of all combos, uploaded once per engine; any other list is gathered and uploaded
+            bool consecutive = true;
+            for (int q = 1; q < nb && consecutive; ++q) consecutive = combos[s + q] == combos[s] + q;
+            if (consecutive) {
+                if (!e->allpos_ready) {
+                    FSK_HIP(e->d_allpos.reserve(e->all_pos.size()));
+                    FSK_HIP(hipMemcpy(e->d_allpos.p, e->all_pos.data(), e->all_pos.size(), hipMemcpyHostToDevice));
+                    e->allpos_ready = true;
+                }
+                chunk_pos = e->d_allpos.p + (size_t)combos[s] * e->k;
+                FSK_HIP(hipMemsetAsync(e->d_flag.p, 0, sizeof(uint32_t), e->stream));
+            } else {
+                pos.resize((size_t)nb * e->k);
+                for (int q = 0; q < nb; ++q)
+                    memcpy(&pos[(size_t)q * e->k], &e->all_pos[(size_t)combos[s + q] * e->k], e->k);
+                FSK_HIP(hipMemcpyAsync(e->d_pos.p, pos.data(), pos.size(), hipMemcpyHostToDevice, e->stream));
+                FSK_HIP(hipMemsetAsync(e->d_flag.p, 0, sizeof(uint32_t), e->stream));
+                FSK_HIP(hipStreamSynchronize(e->stream));  // `pos` is a pageable temporary
+                chunk_pos = e->d_pos.p;
+            }
             // ---- segment counts
             // up to 16 combos share one staging of a panel's symbols, fewer when that would leave the
             // launch with less than ~512 workgroups (few sequences; with 1024 as the floor config 3 ran 11 combos a
@@ -198,17 +214,17 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
                                e->k, e->sigma, e->rare_mask);
                     const uint32_t mblocks = (uint32_t)std::max<u64>(1, std::min<u64>(((u64)cap * (u64)e->cfg.g + 255) / 256, 64));
                     FSK_LAUNCH(fsk::k_dense_mark_rare, dim3(mblocks, (uint32_t)nb), dim3(256), 0, e->stream, e->view(), (const u64*)e->d_rare.p,
-                               (const uint32_t*)e->d_rare_n.p, cap, e->cfg.g, e->k, e->sigma, (const uint8_t*)e->d_pos.p, Vkeys, e->d_keybits.p);
+                               (const uint32_t*)e->d_rare_n.p, cap, e->cfg.g, e->k, e->sigma, (const uint8_t*)chunk_pos, Vkeys, e->d_keybits.p);
                     e->st.launches += 1;
                 } else {
                     FSK_HIP(hipMemsetAsync(e->d_keybits.p, 0, (size_t)nb * Vw * sizeof(uint32_t), e->stream));
                     FSK_LAUNCH(k_mark, cgrid, dim3(256), lds, e->stream, e->view(), e->cfg.g,
-                               e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C4.p, e->d_C4H.p,
+                               e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, chunk_pos, nb, slots_per_chunk, e->d_C4.p, e->d_C4H.p,
                                e->d_rowmask.p, nst, e->d_flag.p, Vkeys, (const uint16_t*)nullptr, (const uint16_t*)nullptr, e->d_keybits.p, kc_rows);
                 }
                 FSK_LAUNCH(fsk::k_dense_keylut, dim3(nb), dim3(256), 0, e->stream, e->d_keybits.p, Vkeys, e->d_lut.p, e->d_vc.p);
                 FSK_LAUNCH(k_count_lut, cgrid, dim3(256), lds, e->stream, e->view(), e->cfg.g,
-                           e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C4.p, e->d_C4H.p,
+                           e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, chunk_pos, nb, slots_per_chunk, e->d_C4.p, e->d_C4H.p,
                            e->d_rowmask.p, nst, e->d_flag.p, Vkeys, e->d_lut.p, e->d_vc.p, (uint32_t*)nullptr, kc_rows);
                 h_vc.resize((size_t)nb);
                 FSK_HIP(hipMemcpyAsync(h_vc.data(), e->d_vc.p, (size_t)nb * sizeof(uint16_t), hipMemcpyDeviceToHost, e->stream));
@@ -223,7 +239,7 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
                 }
             } else {
                 FSK_LAUNCH(k_count, cgrid, dim3(256), lds, e->stream, e->view(), e->cfg.g,
-                           e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, e->d_pos.p, nb, slots_per_chunk, e->d_C4.p, e->d_C4H.p,
+                           e->k, e->sigma, e->Vq, plan.Vcq, e->maxW, CH, chunk_pos, nb, slots_per_chunk, e->d_C4.p, e->d_C4H.p,
                            e->d_rowmask.p, nst, e->d_flag.p, Vkeys, (const uint16_t*)nullptr, (const uint16_t*)nullptr, (uint32_t*)nullptr, kc_rows);
             }
             e->toc(&e->st.ms_count);

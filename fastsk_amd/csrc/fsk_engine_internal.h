@@ -177,6 +177,7 @@ struct fsk_engine {
     int force_compact = -1;       // FSK_COMPACT=0/1 overrides (testing)
     DevBuf<uint32_t> d_tiletab;
     uint32_t tab_t0 = 0, tab_t1 = 0, tab_n = 0;   // tile-row range the table on the device covers
+    uint32_t tab_ftt = 0xffffffffu;               // ... and the first all-test tile column it was built for (skip_test_block)
     std::vector<int32_t> prep_combos;              // combos whose count panels are resident
     bool prep_valid = false, prep_overflow = false;
     // sparse scratch

@@ -766,6 +766,27 @@ def test_emu_key_compaction_rare_symbol(emu_lib, port, monkeypatch, g, m, force,
     assert st["key_space"] == 5 ** (g - m) and st["compact_keys_avg"] > 0 and st["compact_keys_avg"] < st["key_space"]
 
 
+def test_emu_dense_reloads_keep_or_rebuild_the_tile_table(emu_lib, port):
+    """Dense dataflow, one engine, several sets of sequences: a set with the same number of sequences and the same train / test
+    split keeps the tile table on the device (and reads the kept positions of consecutive combos from the resident table of
+    all combos); another size, another split or a combo list with gaps rebuilds / uploads what it needs."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(9)
+    g, m = 7, 3
+    e = _native.Engine(g, m, path=1, lib=emu_lib)
+    for (N, ntr, combos) in [(200, 150, np.arange(35, dtype=np.int32)), (200, 150, np.arange(5, 30, dtype=np.int32)),
+                             (200, 100, np.array([0, 3, 4, 9, 30], dtype=np.int32)), (140, 140, np.arange(35, dtype=np.int32)),
+                             (330, 200, np.arange(10, 20, dtype=np.int32))]:
+        X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(g, 70, size=N)]
+        tok, off = _native.flatten(X)
+        want, _, _ = port.raw_counts(tok, off, g, m, combos, threads=4)
+        e.load_sequences(tok, off, ntr, N - ntr)
+        e.accumulate(combos)
+        e.finalize()
+        assert np.array_equal(e.get_counts(), want), (N, ntr)
+    e.close()
+
+
 def test_emu_many_flagged_rows_in_one_stage(emu_lib, port):
     """More k-mers with counts above 15 in one 32-row stage than hi-plane rows ride along with
     the prefetch (4): the tile kernel fetches the rest in extra rounds."""
