@@ -195,6 +195,7 @@ struct fsk_engine {
     uint32_t sx_rounds_slot = 1, sx_cap_slot = 0;  // the same for the by-slot form of k_sx_consume (variance mode)
     int sx_pb = 16, sx_sb = 1, sx_keybits = 1, sx_own_shift = 13;
     bool sx_lists = false, owner_ready = false;
+    int64_t owner_N = -1;                 // the number of sequences the owner bands were planned for
     // profile mode, dense dataflow: U of the last single-chunk combo list is kept, so that repeating
     // the same pass (bench steps, row bands of later passes) does not re-read every count panel
     DevBuf<u64> d_U2;

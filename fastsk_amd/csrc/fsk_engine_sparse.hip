@@ -22,6 +22,8 @@ void plan_owner_bands(fsk_engine* e) {
     // of its triangular index, bands hold about 2^t cells (2^t + N at most: the last row of a band is
     // kept whole) and can be empty when a single row is longer than 2^t cells.
     const u64 N = (u64)e->N, cells = N * (N + 1) / 2;
+    if (e->owner_N == e->N && e->n_owners != 0) return;  // (the bands depend on the number of sequences alone: the same plan, and its table stays on the device)
+    e->owner_N = e->N;
     // (as large as ONE round of k_sx_consume takes: with half the bands k_sx_emit bins, scans and offsets half as much per
     // tile and the per-(tile, band) word counts are half the matrix — config 4, N = 2560: 400 -> 200 bands, emit 3.75 ->
     // 3.57 ms, the column scans 0.37 -> 0.26, consume 1.04 -> 1.13)
