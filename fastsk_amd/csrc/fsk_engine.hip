@@ -355,7 +355,7 @@ void fsk_detail::one_destroy(fsk_engine* e) {
     if (e->chain_stream) (void)hipStreamSynchronize(e->chain_stream);  // (variance mode may leave a dropped batch's sums running)
     e->d_words.release(); e->d_wstart.release(); e->d_len.release(); e->d_fstart.release(); e->d_featseq.release(); e->d_win.release();
     e->d_pos.release(); e->d_allpos.release(); e->d_bsum.release(); e->d_seqblk.release(); e->K_store.release(); e->d_Kf64.release(); e->d_Khat.release(); e->d_prod.release();
-    e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_Kslots.release(); e->d_cell_idx.release(); e->d_C4.release(); e->d_C4H.release(); e->d_rowmask.release(); e->d_flag.release(); e->d_tiletab.release(); e->d_rare.release(); e->d_rare_n.release(); e->d_keybits.release(); e->d_lut.release(); e->d_vc.release();
+    e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_Kslots.release(); e->d_cell_idx.release(); e->d_C4.release(); e->d_C4H.release(); e->d_rowmask.release(); e->d_flag.release(); e->d_tiletab.release(); e->d_rare.release(); e->d_rare_n.release(); e->d_common.release(); e->d_keybits.release(); e->d_lut.release(); e->d_vc.release();
     if (e->lane_stream) { (void)hipStreamSynchronize(e->lane_stream); (void)hipStreamDestroy(e->lane_stream); }
     for (auto& lane : e->sxs) lane.release();
     e->d_owner_r0.release(); e->d_U.release(); e->d_U2.release();

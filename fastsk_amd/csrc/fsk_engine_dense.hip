@@ -208,10 +208,13 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
                         FSK_HIP(hipMemsetAsync(e->d_rare_n.p, 0, sizeof(uint32_t), e->stream));
                         FSK_LAUNCH(fsk::k_dense_rare_scan, dim3((uint32_t)((e->N + 3) / 4)), dim3(256), 0, e->stream, e->view(), e->rare_mask,
                                    e->d_rare.p, cap, e->d_rare_n.p);
+                        FSK_HIP(e->d_common.reserve(Vw));
+                        FSK_LAUNCH(fsk::k_dense_common_keys, dim3((Vw + 255u) / 256u), dim3(256), 0, e->stream, e->d_common.p, Vkeys, e->k, e->sigma,
+                                   e->rare_mask);
                         e->rare_ready = true;
                     }
-                    FSK_LAUNCH(fsk::k_dense_keybits_init, dim3((Vw + 255u) / 256u, (uint32_t)nb), dim3(256), 0, e->stream, e->d_keybits.p, Vkeys,
-                               e->k, e->sigma, e->rare_mask);
+                    FSK_LAUNCH(fsk::k_dense_keybits_init, dim3((Vw + 255u) / 256u, (uint32_t)nb), dim3(256), 0, e->stream, e->d_keybits.p,
+                               (const uint32_t*)e->d_common.p, Vkeys);
                     const uint32_t mblocks = (uint32_t)std::max<u64>(1, std::min<u64>(((u64)cap * (u64)e->cfg.g + 255) / 256, 64));
                     FSK_LAUNCH(fsk::k_dense_mark_rare, dim3(mblocks, (uint32_t)nb), dim3(256), 0, e->stream, e->view(), (const u64*)e->d_rare.p,
                                (const uint32_t*)e->d_rare_n.p, cap, e->cfg.g, e->k, e->sigma, (const uint8_t*)chunk_pos, Vkeys, e->d_keybits.p);

@@ -171,7 +171,7 @@ struct fsk_engine {
     uint32_t rare_mask = 0, rare_places = 0;
     int force_compact_rare = -1;
     DevBuf<u64> d_rare;
-    DevBuf<uint32_t> d_rare_n;
+    DevBuf<uint32_t> d_rare_n, d_common;  // (d_common: the bitmap of the keys made of common symbols alone)
     std::vector<uint16_t> h_vc_cache;
     double vc_sum = 0, vc_n = 0;
     int force_compact = -1;       // FSK_COMPACT=0/1 overrides (testing)

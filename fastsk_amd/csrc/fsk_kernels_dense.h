@@ -268,8 +268,9 @@ __global__ __launch_bounds__(256) void k_dense_rare_scan(SeqView S, uint32_t rar
     }
 }
 
-// grid = (ceil(Vw / 256), n_slots): word i of every combo's bitmap = the keys 32 i .. 32 i + 31 whose digits are all common
-__global__ __launch_bounds__(256) void k_dense_keybits_init(uint32_t* keybits, uint32_t V, int k, uint32_t sigma, uint32_t rare_mask) {
+// grid = ceil(Vw / 256): word i of `common` = the keys 32 i .. 32 i + 31 whose digits are all common symbols (the same for
+// every combo: once per set of sequences)
+__global__ __launch_bounds__(256) void k_dense_common_keys(uint32_t* common, uint32_t V, int k, uint32_t sigma, uint32_t rare_mask) {
     const uint32_t Vw = (V + 31u) >> 5, i = blockIdx.x * 256u + threadIdx.x;
     if (i >= Vw) return;
     uint32_t word = 0;
@@ -280,7 +281,12 @@ __global__ __launch_bounds__(256) void k_dense_keybits_init(uint32_t* keybits, u
         for (int c = 0; c < k; ++c) { ok = ok && !((rare_mask >> (x % sigma)) & 1u); x /= sigma; }
         if (ok) word |= 1u << b;
     }
-    keybits[(size_t)blockIdx.y * Vw + i] = word;
+    common[i] = word;
+}
+// grid = (ceil(Vw / 256), n_slots): every combo's bitmap starts as the common keys
+__global__ __launch_bounds__(256) void k_dense_keybits_init(uint32_t* keybits, const uint32_t* common, uint32_t V) {
+    const uint32_t Vw = (V + 31u) >> 5, i = blockIdx.x * 256u + threadIdx.x;
+    if (i < Vw) keybits[(size_t)blockIdx.y * Vw + i] = common[i];
 }
 
 // grid = (blocks, n_slots), block = 256: thread = (place, window offset d): the window that starts d symbols before the place
