@@ -123,6 +123,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     }
     fsk::SxIds ids{};
     const bool by_id = nb <= 16;  // (variance mode: a handful of combos per batch) positions from the resident table
+    bool consecutive = !by_id;
     if (by_id) {
         if (!e->allpos_ready) {
             FSK_HIP(e->d_allpos.reserve(e->all_pos.size()));
@@ -131,17 +132,28 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         }
         for (int s = 0; s < nb; ++s) ids.id[s] = combos[s];
     } else {
-        for (int s = 0; s < nb; ++s)
-            memcpy(pos_pin + (size_t)s * e->k, &e->all_pos[(size_t)combos[s] * e->k], e->k);
-        FSK_HIP(hipMemcpyAsync(e->d_pos.p + pos_off, pos_pin, (size_t)nb * e->k, hipMemcpyHostToDevice, stream));
-        FSK_HIP(hipMemsetAsync(S.d_sxstat.p, 0, 3 * sizeof(u64), stream));
+        // (a run of consecutive combo ids — every exact call — reads its kept positions from the resident table of all
+        // combos; the batch's statistics are zeroed by the extraction kernel: no copy or fill command in front of a batch)
+        for (int s = 1; s < nb && consecutive; ++s) consecutive = combos[s] == combos[0] + s;
+        if (consecutive) {
+            if (!e->allpos_ready) {
+                FSK_HIP(e->d_allpos.reserve(e->all_pos.size()));
+                FSK_HIP(hipMemcpy(e->d_allpos.p, e->all_pos.data(), e->all_pos.size(), hipMemcpyHostToDevice));
+                e->allpos_ready = true;
+            }
+        } else {
+            for (int s = 0; s < nb; ++s)
+                memcpy(pos_pin + (size_t)s * e->k, &e->all_pos[(size_t)combos[s] * e->k], e->k);
+            FSK_HIP(hipMemcpyAsync(e->d_pos.p + pos_off, pos_pin, (size_t)nb * e->k, hipMemcpyHostToDevice, stream));
+        }
     }
 
     RecT* rec[2] = {(RecT*)S.d_keys[0].p, (RecT*)S.d_keys[1].p};
 
     e->tic();
-    const uint8_t* const pos_tab = by_id ? (const uint8_t*)e->d_allpos.p : (const uint8_t*)e->d_pos.p + pos_off;
-    u64* const zeroed_stats = by_id ? S.d_sxstat.p : (u64*)nullptr;
+    const uint8_t* const pos_tab = by_id ? (const uint8_t*)e->d_allpos.p
+                                   : consecutive ? (const uint8_t*)e->d_allpos.p + (size_t)combos[0] * e->k : (const uint8_t*)e->d_pos.p + pos_off;
+    u64* const zeroed_stats = S.d_sxstat.p;
     const int ww = e->win_words;
     constexpr bool R32 = sizeof(RecT) == 4;
     const bool small = R32 && e->V <= ((u64)1 << 24) && e->sigma < (1u << 24);  // (the k-mer and every prefix of it fit 24 bits)
@@ -160,7 +172,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                    S.d_blockhist.p, dmask, zeroed_stats);
     } else {
         FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_extract<RecT>), dim3(tps, nb), dim3(256), 0, stream, e->view(), e->d_featseq.p,
-                   e->d_fstart.p, nfeat, tps, e->k, e->sigma, sb, pos_tab, rec[0], S.d_blockhist.p, dmask, ids, zeroed_stats);
+                   e->d_fstart.p, nfeat, tps, e->k, e->sigma, sb, pos_tab, rec[0], S.d_blockhist.p, dmask, ids, zeroed_stats, by_id ? 1 : 0);
     }
     e->toc(&e->st.ms_extract);
     e->st.launches += 1;
