@@ -61,7 +61,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 # v_dot8_u32_u4 / v_dot4_u32_u8 issue at HALF the v_fma_f32 rate on gfx950 (measured:
 # profiles/r01_ubench_valu_rates.txt): 64 lanes/clk/CU. Peak = CUs * 64 lanes * 8 MACs * 2.4 GHz.
 VALU_DOT8_PEAK_TMACS = 256 * 64 * 8 * 2.4e9 / 1e12  # = 314.6 T MAC/s
-KERNEL_FILES = ("fastsk_amd/csrc/fsk_kernels_dense.h", "fastsk_amd/csrc/fsk_tile_kernel.inc", "fastsk_amd/csrc/fsk_tile_kernel_dma.inc")
+KERNEL_FILES = ("fastsk_amd/csrc/fsk_kernels_dense.h", "fastsk_amd/csrc/fsk_tile_kernel_dma.inc")
 
 
 def synthetic(N, L, seed=20201214):
@@ -380,11 +380,15 @@ class Watchdog:
             r, w = os.pipe()
             os.set_blocking(w, False)
             os.set_blocking(r, False)
+            signal.set_wakeup_fd(w, warn_on_full_buffer=False)  # (first: if this fails, SIGTERM keeps its default action)
             signal.signal(signal.SIGTERM, lambda *a: None)
-            signal.set_wakeup_fd(w, warn_on_full_buffer=False)
             self.sig_r = r
         except (AttributeError, ValueError, OSError):
             self.sig_r = None
+            try:
+                signal.signal(signal.SIGTERM, signal.SIG_DFL)
+            except (ValueError, OSError):
+                pass
         self.thread = threading.Thread(target=self._run, name="bench-watchdog", daemon=True)
         self.thread.start()
 
@@ -497,6 +501,7 @@ def parse_args():
     ap.add_argument("--no-preflight", action="store_true", help="multi-GPU: skip the 1-step N = 16000 job whose digest is committed")
     ap.add_argument("--init-timeout", type=float, default=180.0, help="seconds init_process_group / a collective may take (torch timeout)")
     ap.add_argument("--no-watchdog", action="store_true", help="no stage bounds (debugging under a profiler)")
+    ap.add_argument("--engine-lib", default=None, help=argparse.SUPPRESS)  # (tests: a build of the engine with fault hooks, tests/hooks)
     ap.add_argument("--step-bound", type=float, default=0.0, help="seconds one step may take before the watchdog gives up (default: from the 1-GPU step time)")
     return ap.parse_args()
 
@@ -519,9 +524,13 @@ def workload_of(args):
     return tokens, offsets, N, L, g, m, workload, data
 
 
-def roofline_of(args, s0, s1, dense, world, combos_rank, share_rows, offsets, n_mine):
-    """`roofline`, `phases_ms_per_step`, `dtype` from the engine's stats before / after the timed steps."""
+def roofline_of(args, s0, s1, dense, world, combos_rank, share_rows, offsets, n_mine, prof=None):
+    """`roofline`, `phases_ms_per_step`, `dtype` from the engine's stats before / after the timed steps (HIP events recorded
+    around every kernel family of those steps: fsk_config.profile = 2, the product dataflow). `prof` = (before, after, launches
+    of one step) of ONE extra step in measurement mode (profile = 1), run after the timed region: the exact update count U and
+    the count-MACs with the flagged rows' remainder products, which the product dataflow does not compute."""
     d = lambda k: s1[k] - s0[k]
+    per_step = lambda k: ((prof[1][k] - prof[0][k]) if prof else d(k) / max(1, args.steps))
     N = s1["n_seq"]
     nfeat = s1["n_feat"]
     b_in = (int(offsets[-1]) * s1["bits_per_symbol"] + 7) // 8
@@ -532,12 +541,13 @@ def roofline_of(args, s0, s1, dense, world, combos_rank, share_rows, offsets, n_
         launches = max(1, d("n_tile_launches"))
         tile_ms = d("ms_tile") / launches
         # exact, from the count panels (whole triangle); a row-band launch owns its share of the cells
-        U = d("cell_updates") / launches * share_rows
+        launches_per_step = max(1.0, launches / max(1, args.steps))
+        U = per_step("cell_updates") / launches_per_step * share_rows
         combos_per_launch = combos_rank / launches
         alg_bytes = 16.0 * U + combos_per_launch * (b_in + 16.0 * P * nfeat)
         secs = tile_ms * 1e-3
         alg_gbs = alg_bytes / secs / 1e9 if secs > 0 else 0.0
-        macs = d("dense_macs") / launches
+        macs = per_step("dense_macs") / launches_per_step
         tmacs = macs / secs / 1e12 if secs > 0 else 0.0
         traffic, traffic_note = None, "no profiles/traffic.json for this launch shape"
         live_note = None
@@ -560,7 +570,7 @@ def roofline_of(args, s0, s1, dense, world, combos_rank, share_rows, offsets, n_
             if live_note:
                 traffic_note += "; live measurement: " + live_note
         roofline = {
-            "bound": "valu", "kernel": "k_dense_tile_dma" if os.environ.get("FSK_TILE_DMA", "1") != "0" else "k_dense_tile",
+            "bound": "valu", "kernel": "k_dense_tile_dma",
             "achieved": tmacs, "peak": VALU_DOT8_PEAK_TMACS, "unit": "T count-MAC/s (v_dot8_u32_u4: 64 lanes/clk/CU x 8 MACs, 256 CUs, 2.4 GHz)",
             "frac": tmacs / VALU_DOT8_PEAK_TMACS, "traffic": traffic, "traffic_source": traffic_note,
             "hbm_measured_frac": (traffic / secs / 1e9 / HBM_PEAK_GBS) if (traffic and secs > 0) else None,
@@ -579,7 +589,7 @@ def roofline_of(args, s0, s1, dense, world, combos_rank, share_rows, offsets, n_
         dtype = "u4 count planes (v_dot8_u32_u4), u32 register sums, u64 triangle (plain stores on the first pass over reset rows, else atomics)"
     else:
         # ---- sparse pipeline: SURVEY 8(d) algorithmic bytes over the GPU time of the pipeline
-        U = d("cell_updates") / max(1, args.steps)
+        U = d("cell_updates") / max(1, args.steps)   # (the sparse dataflow counts its `+=` in every mode)
         alg_bytes = 16.0 * U + n_mine * (b_in + 16.0 * P * nfeat)
         gpu_ms = (d("ms_extract") + d("ms_sort") + d("ms_segment") + d("ms_pairs")) / args.steps
         alg_gbs = alg_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0
@@ -657,7 +667,8 @@ def main_inproc(args):
         # the engine's own deadline (fsk_config.deadline_ms) bounds every host-side wait of the exchange: communicator
         # set-up, the engines' barriers, each band's all-reduce; the watchdog above is the backstop for a thread that
         # never returns from the runtime
-        eng = _native.Engine(g, m, devices=devices, collective=coll, bands=args.bands or 0, profile=True,
+        lib = _native.Library(args.engine_lib) if args.engine_lib else None
+        eng = _native.Engine(g, m, devices=devices, collective=coll, bands=args.bands or 0, profile=2, lib=lib,
                              deadline_ms=int(1e3 * min(args.init_timeout, step_bound)))
     except _native.FskError as exc:
         fatal(wd, 0, args.gpus, args, "fsk_create_multi failed: %s" % exc, "fsk_create_multi")
@@ -691,6 +702,13 @@ def main_inproc(args):
         eng.synchronize()
         elapsed = time.perf_counter() - t0
         s1 = eng.stats()
+        stage("one step in measurement mode (exact U)", step_bound + 60.0)
+        eng.set_tuning("profile", 1)
+        p0 = eng.stats()
+        step()
+        eng.synchronize()
+        p1 = eng.stats()
+        eng.set_tuning("profile", 2)
         stage("digest + line", step_bound)
     except _native.FskError as exc:
         fatal(wd, 0, args.gpus, args, "the in-process group failed: %s" % exc, wd.name if wd else "step",
@@ -701,12 +719,12 @@ def main_inproc(args):
     want = committed_digest(key)
     # engine 0's share: its stats carry the HIP-event times
     n0 = info["combos_per_engine"][0]
-    e0, s0e = dict(s1), dict(s0)
+    e0, s0e, q0, q1 = dict(s1), dict(s0), dict(p0), dict(p1)
     # (cell_updates / dense_macs in a group's stats are sums over the engines: bring them back to engine 0's share)
     for k in ("cell_updates", "dense_macs"):
-        e0[k] = s1[k] * n0 / max(1, ncomb)
-        s0e[k] = s0[k] * n0 / max(1, ncomb)
-    roofline, phases, dtype = roofline_of(args, s0e, e0, dense, args.gpus, n0 * args.steps, 1.0, offsets, n0)
+        for dct, src in ((e0, s1), (s0e, s0), (q0, p0), (q1, p1)):
+            dct[k] = src[k] * n0 / max(1, ncomb)
+    roofline, phases, dtype = roofline_of(args, s0e, e0, dense, args.gpus, n0 * args.steps, 1.0, offsets, n0, prof=(q0, q1))
     out = {
         "metric": "gkm kernel build: mismatch-combos/s", "value": ncomb * args.steps / elapsed, "unit": "combos/s",
         "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -859,7 +877,8 @@ def main():
                   "(rank %d digest %s)" % (world, rank, digest_hex(pd)), "preflight", {"preflight": preflight})
 
     stage("allocate the triangle + load sequences", 240.0)
-    eng = _native.Engine(g, m, device=local_rank, profile=True)
+    # profile = 2: the product dataflow, with HIP events recorded (never waited for) around every kernel family of the timed steps
+    eng = _native.Engine(g, m, device=local_rank, profile=2)
     ncomb = eng.lib.num_combos(g, m)
     workload += ", %d combos" % ncomb
     K = torch.zeros(pairs, dtype=torch.int64, device="cuda")  # the integer triangle RCCL reduces
@@ -869,6 +888,12 @@ def main():
     eng.load_sequences(tokens, offsets, N, 0)  # host packing + H2D: outside the timed region (see end_to_end)
     eng.synchronize()
     t_load = time.perf_counter() - t_load
+    # The normalised result of a step (fastsk_kernel.cpp:96-103 over every cell — part of SURVEY 8(d)'s metric): the whole
+    # triangle of doubles on the device when it fits beside the integer one, else a 4096 x 4096 block
+    nblk = min(4096, N)
+    free_now, _ = torch.cuda.mem_get_info()
+    whole = free_now > pairs * 8 + (24 << 30 if args.config == 5 and N >= 50000 else 4 << 30)
+    tri = torch.empty(pairs, dtype=torch.float64, device="cuda") if whole else None
     every = np.arange(ncomb, dtype=np.int32)
     dense = eng.stats()["path_used"] == 1
     edges = distributed.owner_edges(N, world) if dense else None
@@ -899,8 +924,13 @@ def main():
                                               n_bands=args.bands, force=world == 1)
         else:
             eng.accumulate(mine)
-            eng.synchronize()
         eng.finalize()
+        if how == "rows" and use_dist and not args.replicate:
+            return  # (the kernel matrix stays distributed: its blocks are normalised where they are served)
+        if whole:
+            eng.get_triangle_torch(tri)   # fsk_get_triangle_device: returns when the triangle is written
+        else:
+            eng.get_block_torch(0, nblk, 0, nblk)
 
     def gather_digest(how):
         """The digest of the job's triangle after a step of decomposition `how`, and whether every rank agrees:
@@ -966,6 +996,15 @@ def main():
 
     elapsed, s0, s1, (dg, agree) = timed(mode, args.warmup, args.steps)
     k_digest, identical = verdict(dg, agree)
+    # ---- one more step in measurement mode (profile = 1, outside the timed region): the exact update count U and the
+    # count-MACs including the flagged rows' remainder products — what the product dataflow does not compute
+    stage("one step in measurement mode (exact U)", step_bound + 60.0)
+    eng.set_tuning("profile", 1)
+    p0 = eng.stats()
+    step(mode)
+    torch.cuda.synchronize()
+    p1 = eng.stats()
+    eng.set_tuning("profile", 2)
     alt = None
     if world > 1 and not args.no_alt and edges is not None:
         other = "combos" if mode == "rows" else "rows"
@@ -1013,10 +1052,6 @@ def main():
     end_to_end = None
     stage("end_to_end", 4 * step_bound)
     if world == 1 and not use_dist:
-        nblk = min(4096, N)
-        free, _ = torch.cuda.mem_get_info()
-        whole = free > pairs * 8 + (8 << 30)
-        tri = torch.empty(pairs, dtype=torch.float64, device="cuda") if whole else None
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         eng.load_sequences(tokens, offsets, N, 0)
@@ -1038,7 +1073,6 @@ def main():
             low = torch.tril(torch.ones(nblk, nblk, dtype=torch.bool, device="cuda"))
             cells = (ii[:, None] * (ii[:, None] + 1) // 2 + ii[None, :])[low]
             assert bool(torch.equal(tri[cells], blk[low])), "normalised triangle and block getter disagree"
-            del tri
         else:
             assert bool((blk.diagonal() == 1.0).all())
         end_to_end = {"seconds": t_e2e, "combos_per_s": ncomb / t_e2e, "normalise_ms": 1e3 * t_norm,
@@ -1049,15 +1083,15 @@ def main():
                                       ncomb, "the WHOLE normalised triangle, %d cells of float64 written on the device "
                                       "(fsk_get_triangle_device; 16 bytes of HBM per cell)" % pairs if whole
                                       else "a normalised %d x %d train block on the device (no room for a second triangle)" % (nblk, nblk)),
-                      "value_excludes": "`value` times the combos with the packed sequences resident in HBM: it excludes "
-                                        "fsk_load_sequences (pack + H2D, load_seconds_untimed) and the normalisation "
-                                        "(normalise_ms); end_to_end.combos_per_s includes both"}
+                      "value_excludes": "`value` is timed with the packed sequences resident in HBM (the bench contract: host "
+                                        "buffers and PCIe are never part of `value`): it excludes fsk_load_sequences (pack + H2D, "
+                                        "load_seconds_untimed) and nothing else; end_to_end.combos_per_s is the same step with it"}
         torch.cuda.empty_cache()
 
     out = None
     if rank == 0:
         share_rows = ((my_rows[1] * (my_rows[1] + 1) - my_rows[0] * (my_rows[0] + 1)) // 2) / pairs
-        roofline, phases, dtype = roofline_of(args, s0, s1, dense, world, len(mine) * args.steps, share_rows, offsets, len(mine))
+        roofline, phases, dtype = roofline_of(args, s0, s1, dense, world, len(mine) * args.steps, share_rows, offsets, len(mine), prof=(p0, p1))
         out = {
             "metric": "gkm kernel build: mismatch-combos/s", "value": ncomb * args.steps / elapsed, "unit": "combos/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1066,6 +1100,11 @@ def main():
             "config": {"workload": workload, "n_seq": N, "seq_len": L, "g": g, "m": m, "combos": int(ncomb),
                        "parallelism": describe(mode, world, args.replicate),
                        "path": "dense" if dense else "sparse"},
+            "value_boundary": "a step = fsk_reset_counts + every combo (extract -> sort/group -> count -> K +=)%s + fsk_finalize + the "
+                              "normalised result written on the device (%s), packed sequences resident in HBM when it starts; "
+                              "the engine runs its product dataflow (fsk_config.profile = 2: HIP events recorded, never waited for)"
+                              % (" + the all-reduce of the partial triangles" if use_dist else "",
+                                 "the WHOLE triangle, %d float64 cells" % pairs if whole else "a %d x %d block: no room for a second triangle" % (nblk, nblk)),
             "roofline": roofline,
             "load_seconds_untimed": t_load,
             "phases_ms_per_step": phases,
@@ -1088,7 +1127,7 @@ def main():
     if use_dist:
         dist.barrier()
     eng.close()
-    del K
+    del K, tri
     torch.cuda.empty_cache()
     # ---- the same job from ONE process (FastSK(devices=[...])'s engine), measured once the ranks have let go of
     # their GPUs: rank 0 starts a fresh child (it has touched the GPU itself: a child process, never an exec)

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfastsk_amd.so")
 
 PATH_AUTO, PATH_DENSE, PATH_SPARSE = 0, 1, 2
 COLL_AUTO, COLL_RCCL, COLL_P2P = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ERRORS = {-1: "FSK_EINVAL", -2: "FSK_ESHORT", -3: "FSK_ESTATE", -4: "FSK_EDEVICE", -5: "FSK_ENOMEM",
           -6: "FSK_EUNSUPPORTED"}
@@ -73,7 +73,7 @@ SYMBOLS = ["fsk_create", "fsk_destroy", "fsk_last_error", "fsk_abi_version", "fs
            "fsk_combo_positions", "fsk_stream_wait_engine", "fsk_engine_wait_stream", "fsk_read_fasta", "fsk_sequential_sum",
            "fsk_run_chains", "fsk_get_kernel_sum_device", "fsk_set_kernel_sum_device", "fsk_create_multi", "fsk_get_multi_info",
            "fsk_counts_digest", "fsk_alloc_block_device", "fsk_free_device", "fsk_set_skip_test_block",
-           "fsk_get_triangle_device", "fsk_alloc_triangle_device"]
+           "fsk_get_triangle_device", "fsk_alloc_triangle_device", "fsk_set_tuning", "fsk_get_tuning", "fsk_tuning_keys"]
 
 
 _hip_shared = False
@@ -201,6 +201,9 @@ class Library:
             "fsk_set_skip_test_block": ([vp, i32], C.c_int),
             "fsk_get_triangle_device": ([vp, vp], C.c_int),
             "fsk_alloc_triangle_device": ([vp, C.POINTER(vp)], C.c_int),
+            "fsk_set_tuning": ([vp, C.c_char_p, i64], C.c_int),
+            "fsk_get_tuning": ([vp, C.c_char_p, C.POINTER(i64)], C.c_int),
+            "fsk_tuning_keys": ([], C.c_char_p),
         }
         for name, (argtypes, restype) in sig.items():
             fn = getattr(L, name)
@@ -220,6 +223,16 @@ class Library:
 
     def device_count(self):
         return int(self.L.fsk_device_count())
+
+    def tuning_keys(self):
+        """{key: (default, lowest, highest, what it does)} — every knob fsk_set_tuning / FSK_TUNING takes."""
+        out = {}
+        for line in self.L.fsk_tuning_keys().decode().splitlines():
+            head, rng, doc = line.split(" ", 2)
+            key, default = head.split("=")
+            lo, hi = rng.strip("[]").split("..")
+            out[key] = (int(default), int(lo), int(hi), doc)
+        return out
 
 
 _default = None
@@ -253,7 +266,7 @@ class Engine:
 
     def __init__(self, g, m, t=-1, approx=False, delta=0.025, max_iters=-1, skip_variance=False, device=0,
                  path=PATH_AUTO, profile=False, lib=None, skip_test_block=False, devices=None, collective=COLL_AUTO,
-                 bands=0, deadline_ms=0):
+                 bands=0, deadline_ms=0, tuning=None):
         self.lib = lib or library()
         if devices is not None:
             devices = [int(d) for d in devices]
@@ -261,7 +274,7 @@ class Engine:
                 raise ValueError("devices must list at least one GPU")
             device = devices[0]
         cfg = Config(g=g, m=m, t=t, approx=int(bool(approx)), delta=delta, max_iters=max_iters,
-                     skip_variance=int(bool(skip_variance)), device=device, path=path, profile=int(bool(profile)),
+                     skip_variance=int(bool(skip_variance)), device=device, path=path, profile=int(profile),
                      skip_test_block=int(bool(skip_test_block)), collective=int(collective), bands=int(bands),
                      deadline_ms=int(deadline_ms))
         h = C.c_void_p()
@@ -277,6 +290,8 @@ class Engine:
         self.g, self.m = g, m
         self.device = device
         self._keep = None
+        for key, value in (tuning or {}).items():
+            self.set_tuning(key, value)
 
     def close(self):
         if getattr(self, "h", None):
@@ -416,6 +431,15 @@ class Engine:
         info = MultiInfo()
         self._ck(self.lib.L.fsk_get_multi_info(self.h, C.byref(info)))
         return info.as_dict()
+
+    def set_tuning(self, key, value):
+        """One knob of the engine (``Library.tuning_keys()`` lists them); never changes a result."""
+        self._ck(self.lib.L.fsk_set_tuning(self.h, key.encode(), int(value)))
+
+    def get_tuning(self, key):
+        v = C.c_int64(0)
+        self._ck(self.lib.L.fsk_get_tuning(self.h, key.encode(), C.byref(v)))
+        return int(v.value)
 
     def set_skip_test_block(self, skip):
         self._ck(self.lib.L.fsk_set_skip_test_block(self.h, int(bool(skip))))

@@ -10,11 +10,12 @@
 //   - additive keyword arguments (device, devices, collective, deadline_ms, path, seed, skip_test_block), numpy and
 //     DLPack getters. devices=[0,1,...]: one engine per listed GPU behind the same object (fsk_create_multi) —
 //     the reference parallelises the same call over t host threads (fastsk_kernel.cpp:54-93).
-//   - the test x test block, which no getter of the reference exposes (fastsk.cpp:190-217), is not computed
-//     until something asks for it (get_block over test x test cells, get_counts_np, counts_digest over test rows,
-//     get_triangle_dlpack, save_kernel): that first request runs the whole compute once more with nothing left
-//     out (about twice the time of compute_kernel in total; the object keeps a copy of the tokens until then).
-//     skip_test_block=False computes everything in compute_kernel, as the reference does.
+//   - skip_test_block (default False: compute_kernel computes the whole N x N triangle, as fastsk.cpp:30-118 does).
+//     The test x test block, which no getter of the reference exposes (fastsk.cpp:190-217), can be left out:
+//     skip_test_block=True never computes it (its cells read as zero); skip_test_block="lazy" (or None) leaves it
+//     out of compute_kernel and the first request that needs it (get_block over test x test cells, get_counts_np,
+//     counts_digest over test rows, get_triangle_dlpack, save_kernel) runs the whole compute once more with
+//     nothing left out — about twice the time of compute_kernel in total; the object keeps the tokens until then.
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -74,7 +75,7 @@ class FastSK {
     int64_t n_train_ = 0, n_test_ = 0;
     bool computed_ = false;
     int device0_ = 0;
-    // skip_test_block=None: the test x test block is left out of compute_kernel and computed only if asked for
+    // skip_test_block="lazy" / None: the test x test block is left out of compute_kernel and computed only if asked for
     bool lazy_test_block_ = false, test_block_missing_ = false;
     std::vector<int32_t> kept_tokens_;   // the call's input, kept while the test x test block is missing
     std::vector<int64_t> kept_offsets_;
@@ -176,7 +177,11 @@ public:
            const std::string& path, py::object seed, py::object skip_test_block, py::object devices,
            const std::string& collective, int deadline_ms) {
         fsk_config c{};
-        lazy_test_block_ = skip_test_block.is_none();
+        if (skip_test_block.is_none()) lazy_test_block_ = true;
+        else if (py::isinstance<py::str>(skip_test_block)) {
+            if (skip_test_block.cast<std::string>() != "lazy") throw py::value_error("skip_test_block must be False, True or \"lazy\"");
+            lazy_test_block_ = true;
+        }
         c.skip_test_block = lazy_test_block_ ? 0 : (skip_test_block.cast<bool>() ? 1 : 0);
         c.g = g; c.m = m; c.t = t; c.approx = approx; c.delta = delta; c.max_iters = max_iters;
         c.skip_variance = skip_variance; c.device = device; c.path = parse_path(path);
@@ -375,7 +380,7 @@ PYBIND11_MODULE(_fastsk, m) {
                       const std::string&, int>(),
              py::arg("g"), py::arg("m"), py::arg("t") = -1, py::arg("approx") = false, py::arg("delta") = 0.025,
              py::arg("max_iters") = -1, py::arg("skip_variance") = false, py::arg("device") = 0,
-             py::arg("path") = "auto", py::arg("seed") = py::none(), py::arg("skip_test_block") = py::none(),
+             py::arg("path") = "auto", py::arg("seed") = py::none(), py::arg("skip_test_block") = false,
              py::arg("devices") = py::none(), py::arg("collective") = "auto", py::arg("deadline_ms") = 0)
         .def("compute_kernel", &FastSK::compute_kernel_np, py::arg("Xtrain").noconvert(), py::arg("Xtest").noconvert())
         .def("compute_kernel", &FastSK::compute_kernel, py::arg("Xtrain"), py::arg("Xtest"))

@@ -18,7 +18,7 @@
 //                    counts leave as 4-bit "count panels" (count = lo + 16*hi, two nibble planes)
 //                    laid out [panel][combo][key/8][64 seqs] so that the tile kernel streams
 //                    them with 16-byte coalesced loads.
-//     k_dense_tile   output-stationary 128x128 tile of K per workgroup: panels staged through
+//     k_dense_tile_dma  output-stationary 128x128 tile of K per workgroup: panels DMA'd into
 //                    LDS, 8x8 register block per lane, v_dot8_u32_u4 multiply-adds summed in
 //                    registers over ALL combos of the launch, then ONE 64-bit atomicAdd per cell.
 //

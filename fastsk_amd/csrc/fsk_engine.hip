@@ -21,6 +21,63 @@ namespace fsk_detail {
 
 void set_create_error(const std::string& msg) { g_create_error = msg; }
 
+// ---- tuning (fsk_tuning, fsk_engine_internal.h): one table of keys, defaults and ranges
+namespace {
+struct TuneKey { const char* name; int64_t fsk_tuning::*field; int64_t def, lo, hi; const char* doc; };
+const TuneKey TUNE_KEYS[] = {
+#define FSK_X(name, def, lo, hi, doc) {#name, &fsk_tuning::name, (int64_t)(def), (int64_t)(lo), (int64_t)(hi), doc},
+    FSK_TUNING_KEYS(FSK_X)
+#undef FSK_X
+};
+}  // namespace
+
+int tuning_set(fsk_tuning& t, const char* key, int64_t value, std::string& err) {
+    for (const TuneKey& k : TUNE_KEYS)
+        if (key && !strcmp(k.name, key)) {
+            if (value < k.lo || value > k.hi) {
+                err = std::string("tuning key ") + key + " takes " + std::to_string(k.lo) + " .. " + std::to_string(k.hi) + ", not " + std::to_string(value);
+                return FSK_EINVAL;
+            }
+            t.*(k.field) = value;
+            return FSK_OK;
+        }
+    err = std::string("unknown tuning key '") + (key ? key : "(null)") + "'";
+    return FSK_EINVAL;
+}
+
+// "key=value,key=value" (commas or blanks between the pairs)
+int tuning_parse(fsk_tuning& t, const char* text, std::string& err) {
+    std::string s(text ? text : "");
+    size_t i = 0;
+    while (i < s.size()) {
+        while (i < s.size() && (s[i] == ',' || s[i] == ' ' || s[i] == ';')) ++i;
+        size_t j = i;
+        while (j < s.size() && s[j] != ',' && s[j] != ' ' && s[j] != ';') ++j;
+        if (j > i) {
+            const std::string pair = s.substr(i, j - i);
+            const size_t eq = pair.find('=');
+            char* end = nullptr;
+            const long long v = eq == std::string::npos ? 0 : strtoll(pair.c_str() + eq + 1, &end, 0);
+            if (eq == std::string::npos || eq == 0 || eq + 1 == pair.size() || (end && *end)) {
+                err = "expected key=integer, got '" + pair + "'";
+                return FSK_EINVAL;
+            }
+            const int rc = tuning_set(t, pair.substr(0, eq).c_str(), (int64_t)v, err);
+            if (rc) return rc;
+        }
+        i = j;
+    }
+    return FSK_OK;
+}
+
+// the keys that differ from their defaults ("defaults" when none does)
+std::string tuning_in_force(const fsk_tuning& t) {
+    std::string out;
+    for (const TuneKey& k : TUNE_KEYS)
+        if (t.*(k.field) != k.def) out += (out.empty() ? "" : ",") + std::string(k.name) + "=" + std::to_string(t.*(k.field));
+    return out.empty() ? "defaults" : out;
+}
+
 int64_t n_choose_k(int n, int k) {  // nchoosek, shared.cpp:335-345 (exact in 64 bits)
     if (k < 0 || k > n) return 0;
     if (k * 2 > n) k = n - k;
@@ -146,7 +203,7 @@ bool dense_is_cheaper(const fsk_engine* e) {
 }
 
 int choose_path(fsk_engine* e) {
-    bool dense_ok = e->V <= DENSE_MAX_KEYS && e->k <= 16 && e->Lmax < 65536 && dense_plan(e->maxW, e->cfg.g, e->Vq).CH > 0;
+    bool dense_ok = e->V <= DENSE_MAX_KEYS && e->bits <= 8 && e->k <= 16 && e->Lmax < 65536 && dense_plan(e->maxW, e->cfg.g, e->Vq).CH > 0;
     if (e->cfg.path == FSK_PATH_DENSE) {
         if (!dense_ok)
             return e->fail(FSK_EUNSUPPORTED, "dense path needs alphabet^k <= %llu and the panel histogram to fit in LDS",
@@ -174,7 +231,7 @@ int materialise_zero(fsk_engine* e) {
     return FSK_OK;
 }
 bool lazy_zero_possible(const fsk_engine* e) {
-    return e->path == FSK_PATH_DENSE && e->tile_dma && !e->compact && !(e->cfg.skip_test_block && e->n_test > 0);
+    return e->path == FSK_PATH_DENSE && !e->compact && !(e->cfg.skip_test_block && e->n_test > 0);
 }
 
 
@@ -185,20 +242,16 @@ int do_accumulate(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t r
     for (int i = 0; i < n; ++i)
         if (combos[i] < 0 || combos[i] >= e->ncomb) return e->fail(FSK_EINVAL, "combo id %d out of range [0,%lld)", combos[i], (long long)e->ncomb);
     hipEvent_t a = nullptr, b = nullptr;
-    if (e->cfg.profile) {
-        (void)hipEventCreate(&a);
-        (void)hipEventCreate(&b);
-        (void)hipEventRecord(a, e->stream);
+    if (e->cfg.profile) {  // (the whole call on the engine's stream; profile = 2: harvested later, see fsk_engine::tic)
+        a = e->lazy_event();
+        if (a) (void)hipEventRecord(a, e->stream);
     }
     int rc = e->path == FSK_PATH_DENSE ? accumulate_dense(e, combos, n, K, row0, row1) : accumulate_sparse(e, combos, n, K, row0, row1, slot_stride, defer);
     if (e->cfg.profile) {
-        (void)hipEventRecord(b, e->stream);
-        (void)hipEventSynchronize(b);
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, a, b);
-        e->st.ms_total += ms;
-        (void)hipEventDestroy(a);
-        (void)hipEventDestroy(b);
+        b = e->lazy_event();
+        if (b) (void)hipEventRecord(b, e->stream);
+        e->lazy_interval(a, b, &e->st.ms_total);
+        if (e->profile_sync()) e->harvest_times();
     }
     if (rc == FSK_OK && row1 >= e->N) {  // a combo is done when its last row band is
         e->st.combos_done += n;
@@ -308,27 +361,17 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     e->ncomb = n_choose_k(cfg->g, cfg->m);
     if (e->ncomb > 0x7fffffff) { delete e; g_create_error = "C(g,m) >= 2^31 unsupported"; return FSK_EUNSUPPORTED; }
     enumerate_combos(cfg->g, e->k, e->all_pos);
-    { const char* f = getenv("FSK_COMPACT"); e->force_compact = f ? atoi(f) : -1; }
-    { const char* f = getenv("FSK_SPARSE_GLOBAL"); e->force_global_pairs = f ? atoi(f) : 0; }
-    { const char* f = getenv("FSK_VARIANCE_DENSE_SLOTS"); if (f) e->variance_dense_slots = atoi(f); }
-    { const char* f = getenv("FSK_VAR_SLOTS16"); if (f) e->allow_slots16 = atoi(f); }
-    { const char* f = getenv("FSK_VAR_AHEAD"); if (f && atoi(f) > 0) e->var_ahead = atoi(f); }
-    { const char* f = getenv("FSK_SEG_SCAN_CHUNKED"); if (f) e->force_seg_chunks = atoi(f); }
-    { const char* f = getenv("FSK_SPARSE_SYNC"); if (f) e->sx_sync = atoi(f); }
-    { const char* f = getenv("FSK_SPARSE_GUARD_CAP"); if (f && atoll(f) > 0) e->sx_guard_cap = (u64)atoll(f); }
-    { const char* f = getenv("FSK_LIST_MAX_WORDS"); if (f && atoll(f) > 0) e->sx_max_words = std::min<u64>(SX_MAX_LIST_WORDS, (u64)atoll(f)); }
-    { const char* f = getenv("FSK_TILE_SPLITS"); e->force_splits = f ? atoi(f) : 0; }
-    { const char* f = getenv("FSK_TILE_DMA"); e->tile_dma = f ? atoi(f) : 1; }
-    { const char* f = getenv("FSK_SPARSE_LANES"); if (f) e->sx_two_lanes = atoi(f) >= 2; }
-    { const char* f = getenv("FSK_SPARSE_BATCH_RECORDS"); if (f && atoll(f) > 0) e->sx_batch_records = (size_t)atoll(f); }
-    { const char* f = getenv("FSK_SPARSE_HINT"); if (f) e->sx_hint = atoi(f); }
-    { const char* f = getenv("FSK_SPARSE_EXACT_PARTS"); if (f && atoi(f) > 0) e->sx_exact_parts = atoi(f); }
-    { const char* f = getenv("FSK_SPARSE_EXACT_LANES"); if (f) e->sx_exact_lanes = atoi(f); }
-    { const char* f = getenv("FSK_COMPACT_RARE"); e->force_compact_rare = f ? atoi(f) : -1; }
-    { const char* f = getenv("FSK_COMPACT_DMA"); e->compact_dma = f ? atoi(f) : 1; }
-    { const char* f = getenv("FSK_EXTRACT_SLOTS"); if (f) e->extract_slots = atoi(f); }
-    { const char* f = getenv("FSK_COUNT_SLOTS"); e->force_count_slots = f ? atoi(f) : 0; }
-    { const char* f = getenv("FSK_DENSE_CHUNK"); e->force_chunk = f ? (uint32_t)atoi(f) : 0u; }
+    // the one place the library reads the environment: FSK_TUNING="key=value,key=value" (see FSK_TUNING_KEYS)
+    if (const char* env = getenv("FSK_TUNING")) {
+        std::string why;
+        if (tuning_parse(e->tune, env, why)) {
+            delete e;
+            g_create_error = "FSK_TUNING: " + why;
+            return FSK_EINVAL;
+        }
+    }
+    if (e->tune.profile >= 0) e->cfg.profile = (int)e->tune.profile;
+    if (e->trace()) fprintf(stderr, "[fsk] tuning: %s\n", tuning_in_force(e->tune).c_str());
     if (hipStreamCreate(&e->stream) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
         hipEventCreate(&e->ev1) != hipSuccess) {
         delete e;
@@ -357,6 +400,9 @@ void fsk_detail::one_destroy(fsk_engine* e) {
     e->d_pos.release(); e->d_allpos.release(); e->d_bsum.release(); e->d_seqblk.release(); e->K_store.release(); e->d_Kf64.release(); e->d_Khat.release(); e->d_prod.release();
     e->d_diag.release(); e->d_stage.release(); e->d_stage_u64.release(); e->d_Kslots.release(); e->d_cell_idx.release(); e->d_C4.release(); e->d_C4H.release(); e->d_rowmask.release(); e->d_flag.release(); e->d_tiletab.release(); e->d_rare.release(); e->d_rare_n.release(); e->d_common.release(); e->d_keybits.release(); e->d_lut.release(); e->d_vc.release();
     if (e->lane_stream) { (void)hipStreamSynchronize(e->lane_stream); (void)hipStreamDestroy(e->lane_stream); }
+    e->harvest_times();
+    if (e->lazy_open) (void)hipEventDestroy(e->lazy_open);
+    for (hipEvent_t ev : e->lazy_free) (void)hipEventDestroy(ev);
     for (auto& lane : e->sxs) lane.release();
     e->d_owner_r0.release(); e->d_U.release(); e->d_U2.release();
     if (e->h_prod) (void)hipHostFree(e->h_prod);
@@ -425,7 +471,7 @@ int fsk_detail::one_load_sequences(fsk_engine* e, const int32_t* tokens, const i
         FSK_HIP(hipStreamSynchronize(e->stream));
         e->stage_in_flight = false;
     }
-    const bool trace_load = getenv("FSK_TRACE") != nullptr;  // stderr: where the host time of the load goes
+    const bool trace_load = e->trace();  // stderr: where the host time of the load goes
     const auto tl0 = std::chrono::steady_clock::now();
     auto tl_ms = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
     double tl_lengths = 0, tl_pack = 0;
@@ -455,7 +501,7 @@ int fsk_detail::one_load_sequences(fsk_engine* e, const int32_t* tokens, const i
     std::vector<int32_t> distinct;
     std::vector<int64_t> sym_freq(256, 0);
     uint32_t sigma = 1;
-    int bits = 2;
+    int bits = 2, key_symbits = 0;
     u64 V = 1;
     std::vector<uint32_t> len32((size_t)N), fstart((size_t)N + 1);
     std::vector<uint32_t> wstart_v, words_v;           // general path only
@@ -474,13 +520,23 @@ int fsk_detail::one_load_sequences(fsk_engine* e, const int32_t* tokens, const i
     }
     // sigma, bits, V from `distinct`; where every sequence's words start
     auto plan_words = [&](uint32_t* wstart, uint64_t* nwords_out) -> int {
-        if (distinct.size() > 256) return e->fail(FSK_EUNSUPPORTED, "alphabet of %zu symbols (> 256)", distinct.size());
+        // (cntsrtna's radix is the dictionary size, whatever it is — shared.cpp:156-191 — and its keys are tuples, never a
+        // number: up to 65536 symbols travel as 16-bit fields, and a k-mer space beyond 2^62 is keyed by the symbols' bit
+        // fields side by side instead of a mixed-radix number, see key_symbits)
+        if (distinct.size() > 65536) return e->fail(FSK_EUNSUPPORTED, "alphabet of %zu symbols (> 65536)", distinct.size());
         sigma = (uint32_t)std::max<size_t>(1, distinct.size());
-        bits = sigma <= 4 ? 2 : sigma <= 16 ? 4 : 8;
+        bits = sigma <= 4 ? 2 : sigma <= 16 ? 4 : sigma <= 256 ? 8 : 16;
         V = 1;
+        key_symbits = 0;
         for (int c = 0; c < e->k; ++c) {
-            if (V > (((u64)1 << 62) / sigma)) return e->fail(FSK_EUNSUPPORTED, "alphabet^(g-m) does not fit in 62 bits");
+            if (V > (((u64)1 << 62) / sigma)) { key_symbits = 1; break; }
             V *= sigma;
+        }
+        if (key_symbits) {
+            while (((u64)1 << key_symbits) < sigma) ++key_symbits;
+            V = (u64)1 << 62;  // (at least: the dense dataflow and the 24-bit fast paths are out of the question)
+            if ((int64_t)key_symbits * e->k > 96)
+                return e->fail(FSK_EUNSUPPORTED, "a k-mer of %d symbols of %d bits does not fit the 128-bit sort records", e->k, key_symbits);
         }
         uint64_t nwords = 0;
         for (int64_t i = 0; i < N; ++i) {
@@ -592,6 +648,7 @@ int fsk_detail::one_load_sequences(fsk_engine* e, const int32_t* tokens, const i
             std::sort(distinct.begin(), distinct.end());
             distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
         }
+        if (distinct.size() > sym_freq.size()) sym_freq.assign(distinct.size(), 0);
         wstart_v.resize((size_t)N);
         uint64_t nwords = 0;
         int rc_plan = plan_words(wstart_v.data(), &nwords);
@@ -599,10 +656,10 @@ int fsk_detail::one_load_sequences(fsk_engine* e, const int32_t* tokens, const i
         words_v.assign((size_t)nwords + 4, 0u);
         const int32_t base = distinct.empty() ? 0 : distinct.front();
         const bool direct = !distinct.empty() && (int64_t)distinct.back() - base < (1 << 20);
-        std::vector<uint8_t> lut;
+        std::vector<uint16_t> lut;
         if (direct) {
             lut.assign((size_t)(distinct.back() - base) + 1, 0);
-            for (size_t r = 0; r < distinct.size(); ++r) lut[(size_t)(distinct[r] - base)] = (uint8_t)r;
+            for (size_t r = 0; r < distinct.size(); ++r) lut[(size_t)(distinct[r] - base)] = (uint16_t)r;
         }
         for (int64_t i = 0; i < N; ++i) {
             const int32_t* sq = tokens + (offsets[i] - off0);
@@ -640,8 +697,8 @@ int fsk_detail::one_load_sequences(fsk_engine* e, const int32_t* tokens, const i
         // (sequences, windows, alphabet, longest sequence: the same data loaded again, or its next fold): the first batch is then
         // enqueued under a guard like every later one instead of being capped at 2^25 records and waited for. A hint that is
         // too low costs what any overflowing guard costs — the batch leaves K alone and is redone sized exactly —, never a
-        // result. FSK_SPARSE_HINT=0: every set of sequences starts from nothing (testing).
-        const bool same = e->sx_hint && e->loaded && e->sx_shape[0] == (u64)N && e->sx_shape[1] == (u64)nfeat && e->sx_shape[2] == (u64)sigma &&
+        // result. Tuning sparse_hint = 0: every set of sequences starts from nothing (testing).
+        const bool same = e->tune.sparse_hint && e->loaded && e->sx_shape[0] == (u64)N && e->sx_shape[1] == (u64)nfeat && e->sx_shape[2] == (u64)sigma &&
                           e->sx_shape[3] == (u64)longest;
         if (!same) { e->sx_wpr = 0; e->slots16_ok = true; }
         e->sx_shape[0] = (u64)N; e->sx_shape[1] = (u64)nfeat; e->sx_shape[2] = (u64)sigma; e->sx_shape[3] = (u64)longest;
@@ -651,8 +708,10 @@ int fsk_detail::one_load_sequences(fsk_engine* e, const int32_t* tokens, const i
     {   // sparse dataflow: sort record = (k-mer << sx_sb) | sequence id; owner bands of K
         e->sx_sb = 1;
         while (((int64_t)1 << e->sx_sb) < N) ++e->sx_sb;
+        e->sx_symbits = key_symbits;
         e->sx_keybits = 1;
-        while (e->sx_keybits < 62 && ((u64)1 << e->sx_keybits) < V) ++e->sx_keybits;
+        if (key_symbits) e->sx_keybits = key_symbits * e->k;
+        else while (e->sx_keybits < 62 && ((u64)1 << e->sx_keybits) < V) ++e->sx_keybits;
         plan_owner_bands(e);
     }
     int rc = choose_path(e);
@@ -662,7 +721,7 @@ int fsk_detail::one_load_sequences(fsk_engine* e, const int32_t* tokens, const i
         int64_t rarest = INT64_MAX;
         for (uint32_t r = 0; r < sigma; ++r) rarest = std::min(rarest, sym_freq[r]);
         e->compact = sigma >= 3 && V >= 64 && V <= 4096 && rarest * 50 < total;
-        if (e->force_compact >= 0) e->compact = e->force_compact != 0 && V <= 4096;
+        if (e->tune.compact >= 0) e->compact = e->tune.compact != 0 && V <= 4096;
         // ... and the keys that occur follow from the places of the rare symbols when those are few (g windows per place
         // and combo are marked instead of every window) and every key of common symbols can be taken as present (16
         // windows per such key at least: one that is missing only costs an empty panel row)
@@ -677,7 +736,7 @@ int fsk_detail::one_load_sequences(fsk_engine* e, const int32_t* tokens, const i
         for (int c = 0; c < e->k; ++c) common_keys *= (double)common;
         e->compact_rare = e->compact && sigma <= 32 && common >= 1 && places > 0 && places < ((int64_t)1 << 24) &&
                           places * (int64_t)g * 8 < std::max<int64_t>(1, nfeat) && (double)nfeat >= 16.0 * common_keys;
-        if (e->force_compact_rare >= 0) e->compact_rare = e->compact && e->force_compact_rare != 0 && sigma <= 32 && places < ((int64_t)1 << 24);
+        if (e->tune.compact_rare >= 0) e->compact_rare = e->compact && e->tune.compact_rare != 0 && sigma <= 32 && places < ((int64_t)1 << 24);
         e->rare_places = (uint32_t)places;
     }
     FSK_HIP(e->d_words.reserve(n_words_alloc));
@@ -1205,6 +1264,7 @@ int fsk_detail::one_get_stats(fsk_engine* e, fsk_stats* out) {
     if (e->d_U.p && e->loaded) {
         DeviceScope on_device(e->cfg.device);
         u64 U[2] = {0, 0};
+        e->harvest_times();
         if (hipStreamSynchronize(e->stream) == hipSuccess && fetch_pending_u(e) == FSK_OK &&
             hipMemcpy(U, e->d_U.p, sizeof U, hipMemcpyDeviceToHost) == hipSuccess) {
             e->st.cell_updates = U[0] + e->u_extra;
@@ -1224,4 +1284,36 @@ extern "C" int fsk_set_skip_test_block(fsk_engine* e, int32_t skip) {
     e->cfg.skip_test_block = skip ? 1 : 0;
     e->tab_n = 0;  // (the tile table leaves out test x test tiles)
     return FSK_OK;
+}
+
+// ---- tuning through the ABI (include/fastsk_amd.h)
+extern "C" int fsk_set_tuning(fsk_engine* e, const char* key, int64_t value) {
+    if (!e) return FSK_EINVAL;
+    std::string why;
+    // (a group: every engine runs with the same tuning; the group's own keys are read from engine 0 by fsk_multi.hip)
+    const int rc = e->group ? fsk_detail::group_set_tuning(e, key, value, why) : fsk_detail::tuning_set(e->tune, key, value, why);
+    if (rc) return e->fail(rc, "%s", why.c_str());
+    if (e->tune.profile >= 0) {  // (a group: every engine)
+        if (e->group) fsk_detail::group_set_profile(e, (int)e->tune.profile);
+        else { e->harvest_times(); e->cfg.profile = (int)e->tune.profile; }
+    }
+    if (e->trace()) fprintf(stderr, "[fsk] tuning: %s\n", fsk_detail::tuning_in_force(e->tune).c_str());
+    return FSK_OK;
+}
+
+extern "C" int fsk_get_tuning(fsk_engine* e, const char* key, int64_t* value) {
+    if (!e || !key || !value) return FSK_EINVAL;
+    for (const TuneKey& k : TUNE_KEYS)
+        if (!strcmp(k.name, key)) { *value = e->tune.*(k.field); return FSK_OK; }
+    return e->fail(FSK_EINVAL, "unknown tuning key '%s'", key);
+}
+
+extern "C" const char* fsk_tuning_keys(void) {
+    static const std::string text = [] {
+        std::string t;
+        for (const TuneKey& k : TUNE_KEYS)
+            t += std::string(k.name) + "=" + std::to_string(k.def) + " [" + std::to_string(k.lo) + ".." + std::to_string(k.hi) + "] " + k.doc + "\n";
+        return t;
+    }();
+    return text.c_str();
 }

@@ -125,12 +125,12 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
     DensePlan plan = dense_plan(e->maxW, e->cfg.g, e->Vq, compact ? (size_t)Vkeys * 2 : 0);  // may be re-planned below
     if (plan.CH == 0) return e->fail(FSK_EUNSUPPORTED, "dense path: LDS plan does not fit");
     uint32_t CH = plan.CH;
-    if (e->force_chunk) CH = std::max(1u, std::min(CH, e->force_chunk));
+    if (e->tune.dense_chunk) CH = std::max(1u, std::min(CH, (uint32_t)e->tune.dense_chunk));
     size_t lds = (size_t)(CH + e->cfg.g - 1) * fsk::PANEL + (size_t)plan.Vcq * 512 + (compact ? (size_t)Vkeys * 2 : 0);
     // several histogram sweeps over one staging pass: cache the window keys in LDS (u16 each) when
     // they fit next to everything else, so that only the first sweep computes them
     uint32_t kc_rows = 0;
-    if (plan.Vcq < e->Vq && CH >= e->maxW && !e->force_chunk) {
+    if (plan.Vcq < e->Vq && CH >= e->maxW && !e->tune.dense_chunk) {
         // re-plan with the cache carved out first
         const size_t cache = (size_t)e->maxW * fsk::PANEL * sizeof(uint16_t);
         DensePlan p2 = dense_plan(e->maxW, e->cfg.g, e->Vq, (compact ? (size_t)Vkeys * 2 : 0) + cache);
@@ -189,9 +189,8 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
             // ---- segment counts
             // up to 16 combos share one staging of a panel's symbols, fewer when that would leave the
             // launch with less than ~512 workgroups (few sequences; with 1024 as the floor config 3 ran 11 combos a
-            // staging in 1130 workgroups: 16 a staging in 791 is 0.1-0.15 ms faster per count pass, FSK_COUNT_SLOTS sweep)
+            // staging in 1130 workgroups: 16 a staging in 791 is 0.1-0.15 ms faster per count pass)
             int slots_per_chunk = std::max(1, std::min({nb, 16, (int)((u64)nb * panels_pad / 512)}));
-            if (e->force_count_slots > 0) slots_per_chunk = std::max(1, std::min(nb, e->force_count_slots));
             const int n_chunks = (nb + slots_per_chunk - 1) / slots_per_chunk;
             e->tic();
             const dim3 cgrid(panels_pad, n_chunks);
@@ -258,7 +257,7 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
                 FSK_HIP(hipStreamSynchronize(e->stream));
                 e->prep_overflow = (flag & 1u) != 0;
             }
-            if (e->cfg.profile && !e->prep_overflow) {  // exact algorithmic update count U
+            if (e->profile_sync() && !e->prep_overflow) {  // exact algorithmic update count U
                 const bool same = nb == n && e->u_known && (int)e->u_combos.size() == n && std::equal(combos, combos + n, e->u_combos.begin());
                 if (e->u_pending) {  // value of the previous first-time launch
                     int rc = fetch_pending_u(e);
@@ -320,18 +319,18 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
                 n_splits = std::max(n_splits, std::min(nb / 2, (int)((slots + n_tiles - 1) / n_tiles)));
             n_splits = std::max(1, std::min({n_splits, nb, 4096}));
         }
-        if (e->force_splits > 0) n_splits = std::min({nb, e->force_splits, 4096});
+        if (e->tune.tile_splits > 0) n_splits = std::min({nb, (int)e->tune.tile_splits, 4096});
         const int slots_per_split = (nb + n_splits - 1) / n_splits;
         n_splits = (nb + slots_per_split - 1) / slots_per_split;
         // Store instead of add? Only the first launch over rows that are still "zero by contract",
         // starting at their lower edge, with one workgroup per tile and the engine's own triangle.
         int store = 0;
         if (e->store_next) {
-            if (!(e->tile_dma && !compact && n_splits == 1 && first_test_tile == 0xffffffffu && row0 == 0 && row1 >= e->N))
+            if (!(!compact && n_splits == 1 && first_test_tile == 0xffffffffu && row0 == 0 && row1 >= e->N))
                 return e->fail(FSK_ESTATE, "internal: a storing tile launch was asked for where none is possible");
             store = 1;
         } else if (e->lazy_lo >= 0) {
-            if (K == e->d_K && e->tile_dma && !compact && n_splits == 1 && first_test_tile == 0xffffffffu && row0 == e->lazy_lo &&
+            if (K == e->d_K && !compact && n_splits == 1 && first_test_tile == 0xffffffffu && row0 == e->lazy_lo &&
                 row1 <= e->lazy_hi) {
                 store = 1;
                 e->lazy_lo = row1 < e->lazy_hi ? row1 : -1;
@@ -341,24 +340,17 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
                 if (rcz) return rcz;
             }
         }
-        if (e->cfg.profile)  // the flagged rows' remainder products of this launch, for fsk_stats.dense_macs (read by fsk_get_stats)
+        if (e->profile_sync())  // the flagged rows' remainder products of this launch, for fsk_stats.dense_macs (read by fsk_get_stats)
             FSK_LAUNCH(fsk::k_dense_remainder_rows, dim3((uint32_t)((n_tiles + 255) / 256), (uint32_t)nb), dim3(256), 0, e->stream,
                        (const uint32_t*)e->d_rowmask.p, (const uint32_t*)e->d_tiletab.p, (uint32_t)n_tiles, (uint32_t)nb, nst, compact ? 1 : 0,
                        e->d_U.p + 1);
         e->tic();
-        if (compact && e->compact_dma)
+        if (compact)
             FSK_LAUNCH(fsk::k_dense_tile_dma_compact, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C4.p, e->d_C4H.p,
                        e->d_rowmask.p, e->d_tiletab.p, nb, Vq8, nst, (uint32_t)e->N, K, slots_per_split, 0, (const uint16_t*)e->d_vc.p);
-        else if (compact)
-            FSK_LAUNCH(fsk::k_dense_tile_compact, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C4.p,
-                       e->d_C4H.p, e->d_rowmask.p, e->d_tiletab.p, nb, Vq8, nst, (uint32_t)e->N, K, slots_per_split,
-                       (const uint16_t*)e->d_vc.p);
-        else if (e->tile_dma)
+        else
             FSK_LAUNCH(fsk::k_dense_tile_dma, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C4.p, e->d_C4H.p,
                        e->d_rowmask.p, e->d_tiletab.p, nb, Vq8, nst, (uint32_t)e->N, K, slots_per_split, store);
-        else
-            FSK_LAUNCH(fsk::k_dense_tile, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C4.p, e->d_C4H.p,
-                       e->d_rowmask.p, e->d_tiletab.p, nb, Vq8, nst, (uint32_t)e->N, K, slots_per_split);
         e->toc(&e->st.ms_tile);
         e->st.n_tile_launches += 1;
         u64 row_sum = (u64)Vq8 * (u64)nb;  // dword rows multiplied per tile (the flagged rows' remainder products are added by fsk_get_stats)

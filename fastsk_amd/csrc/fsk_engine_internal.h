@@ -81,6 +81,52 @@ struct DeviceScope {
 
 using fsk_detail::DevBuf;
 
+// ---------------------------------------------------------------------------------------------
+// Every knob of the engine that is not part of fsk_config, in ONE place. A key is set with fsk_set_tuning(handle,
+// "key", value) — tests that force a branch, A/B tools — or through the FSK_TUNING environment variable
+// ("key=value,key=value"), which fsk_create parses ONCE; nothing else in the library reads the environment, and the
+// values an engine runs with are printed under trace=1. X(name, default, lowest, highest, what it does).
+#define FSK_TUNING_KEYS(X)                                                                                                          \
+    X(trace, 0, 0, 1, "stderr: the tuning in force, where the host time of a load and of a variance-mode call goes")                 \
+    X(profile, -1, -1, 2, "fsk_config.profile from here on (-1: as the engine was created)")                                          \
+    X(compact, -1, -1, 1, "dense: key compaction off / on whatever the alphabet says (-1: a rare symbol decides)")                   \
+    X(compact_rare, -1, -1, 1, "dense: keys that occur from the places of the rare symbols (1) or a marking pass over every window (0)") \
+    X(tile_splits, 0, 0, 4096, "dense: combo splits per tile (0: by the size of the launch)")                                        \
+    X(dense_chunk, 0, 0, 1 << 24, "dense: cap of the count kernel's staging chunk, in windows (0: none)")                             \
+    X(variance_dense_slots, 1, 0, 1, "variance mode, dense: 0 = zero fill + k_welford per iteration instead of storing slot triangles") \
+    X(var_slots16, 1, 0, 1, "variance mode, sparse: 0 = u32 slot triangles from the start")                                          \
+    X(sparse_global, 0, 0, 1, "sparse: every += as a 64-bit atomicAdd (k_sx_emit<DIRECT>) whatever N is")                             \
+    X(sparse_unpacked, 0, 0, 1, "sparse: entries in the general 8 + 4 (+ 4) byte format whatever N is")                               \
+    X(sparse_pairs, 1, 0, 1, "sparse: 0 = every update word 32 bits wide (1: unit products of clean runs travel two to a word)")      \
+    X(sparse_sync, 0, 0, 1, "sparse: wait for every batch's word count and size its stream exactly")                                 \
+    X(sparse_hint, 1, 0, 1, "sparse: 0 = the words per record of the previous set of sequences are never kept as a hint")             \
+    X(sparse_exact_lanes, 0, 0, 2, "sparse: the batches of an exact accumulate never (1) / always (2) in two lanes (0: from six batches on)") \
+    X(sparse_batch_records, 0, 0, (int64_t)1 << 31, "sparse: records per batch at most (0: 2^27)")                                   \
+    X(guard_cap, 0, 0, (int64_t)1 << 40, "sparse: pretend the stream buffer holds this many words (0: its real size)")                \
+    X(list_max_words, 0, 0, (int64_t)1 << 31, "sparse: update words of one batch beyond which its pairs go to K with atomics (0: 2^31)") \
+    X(seg_scan_chunked, 0, 0, 1, "sparse: the three-launch segment scan whatever the tile count")                                    \
+    X(extract_slots, 0, 0, 4, "sparse: slots per k_sx_extract_win workgroup, 1 or 4 (0: by the size of the launch)")                  \
+    X(collective, 0, 0, 2, "fsk_create_multi: FSK_COLL_* when fsk_config.collective is FSK_COLL_AUTO")                                \
+    X(deadline_ms, 120000, -1, 86400000, "fsk_create_multi: the fail-fast bound when fsk_config.deadline_ms is 0 (negative: none)")   \
+    FSK_TUNING_TEST_KEYS(X)
+// keys that exist in test builds only (-DFSK_TEST_HOOKS: the CPU emulation and tests/hooks' library; never the product):
+// engine fault_rank of a group is late by fault_ms before the collective of band fault_band — fault_kind 1: its worker
+// thread sleeps; 2: a bounded spin kernel holds its exchange stream
+#ifdef FSK_TEST_HOOKS
+#define FSK_TUNING_TEST_KEYS(X)                                            \
+    X(fault_kind, 0, 0, 3, "test hook: 1 = host sleep, 2 = device spin before a band's collective; 3 = host sleep after the variance chains")   \
+    X(fault_rank, -1, -1, 15, "test hook: the engine that is late")        \
+    X(fault_band, -1, -1, 63, "test hook: before this band's collective")  \
+    X(fault_ms, 0, 0, 60000, "test hook: by this many milliseconds")
+#else
+#define FSK_TUNING_TEST_KEYS(X)
+#endif
+struct fsk_tuning {
+#define FSK_X(name, def, lo, hi, doc) int64_t name = (def);
+    FSK_TUNING_KEYS(FSK_X)
+#undef FSK_X
+};
+
 // What one batch of the sparse dataflow works in: sort records, tile records, entries, update streams. Two sets
 // ("lanes"): variance mode keeps two batches in flight and runs them on two streams, so that the many short
 // kernels of one batch's sort and segmentation fill the gaps of the other's emit / consume / Welford kernels.
@@ -103,6 +149,7 @@ struct SxScratch {
 
 struct fsk_engine {
     fsk_config cfg{};
+    fsk_tuning tune{};  // (fsk_set_tuning / FSK_TUNING at fsk_create; see FSK_TUNING_KEYS)
     std::string err;
     int k = 0;
     int64_t ncomb = 0;
@@ -115,8 +162,6 @@ struct fsk_engine {
     // them (dense dataflow, one workgroup per tile): rows [lazy_lo, lazy_hi) are zero by contract
     // but not in memory until a tile launch stores them or materialise_zero() fills them.
     int64_t lazy_lo = -1, lazy_hi = -1;
-    int var_ahead = 8;             // variance mode: iterations per batch issued ahead of the stop test (FSK_VAR_AHEAD=n: tuning)
-    int variance_dense_slots = 1;  // FSK_VARIANCE_DENSE_SLOTS=0: zero fill + k_welford per iteration instead (testing)
     bool store_next = false;  // variance mode, dense dataflow: the next (one-combo, whole-triangle) tile launch stores into the K it is given
     uint32_t* h_stage = nullptr;         // pinned: the packed sequences on their way to the device (fsk_load_sequences)
     size_t h_stage_cap = 0;
@@ -134,12 +179,8 @@ struct fsk_engine {
     DevBuf<uint32_t> d_words, d_wstart, d_len, d_fstart, d_featseq;
     DevBuf<uint32_t> d_win;  // sparse dataflow: the g-mer windows, win_words 32-bit words each (0: g * bits > 128, symbols are gathered)
     int win_words = 0;
-    int extract_slots = 0;  // FSK_EXTRACT_SLOTS=1|4: slots per k_sx_extract_win workgroup (0: by the size of the launch)
     std::vector<uint32_t> h_len, h_fstart;
     bool featseq_ready = false;
-    int force_splits = 0;      // FSK_TILE_SPLITS=n: combo splits per tile (tuning)
-    int force_count_slots = 0; // FSK_COUNT_SLOTS=n: combos that share one staging of a panel in k_dense_count (tuning)
-    uint32_t force_chunk = 0;  // FSK_DENSE_CHUNK=n: cap the count kernel's staging chunk (testing)
 
     // combos
     std::vector<uint8_t> all_pos;  // [ncomb][k]
@@ -166,15 +207,13 @@ struct fsk_engine {
     DevBuf<uint16_t> d_lut, d_vc; //                  rank table and key count per combo
     bool compact = false;         // decided at load: the alphabet has a rare symbol
     // key compaction from the places of the rare symbols (k_dense_rare_scan / k_dense_mark_rare) instead of a marking pass
-    // over every window: decided at load (few places, plenty of windows per common key); FSK_COMPACT_RARE=0: never (testing)
+    // over every window: decided at load (few places, plenty of windows per common key); tuning compact_rare = 0: never
     bool compact_rare = false, rare_ready = false;
     uint32_t rare_mask = 0, rare_places = 0;
-    int force_compact_rare = -1;
     DevBuf<u64> d_rare;
     DevBuf<uint32_t> d_rare_n, d_common;  // (d_common: the bitmap of the keys made of common symbols alone)
     std::vector<uint16_t> h_vc_cache;
     double vc_sum = 0, vc_n = 0;
-    int force_compact = -1;       // FSK_COMPACT=0/1 overrides (testing)
     DevBuf<uint32_t> d_tiletab;
     uint32_t tab_t0 = 0, tab_t1 = 0, tab_n = 0;   // tile-row range the table on the device covers
     uint32_t tab_ftt = 0xffffffffu;               // ... and the first all-test tile column it was built for (skip_test_block)
@@ -183,10 +222,6 @@ struct fsk_engine {
     // sparse scratch
     SxScratch sxs[2];                     // lane 0: every exact accumulate; lanes 0 and 1: variance mode's batches in flight
     hipStream_t lane_stream = nullptr;    // lane 1's stream (lane 0 runs on `stream`)
-    int sx_two_lanes = 1;                 // FSK_SPARSE_LANES=1: variance mode on one stream (testing)
-    size_t sx_batch_records = 0;          // FSK_SPARSE_BATCH_RECORDS=n: records per batch at most (testing / tuning; 0: SPARSE_MAX_RECORDS)
-    int sx_exact_parts = 1;               // FSK_SPARSE_EXACT_PARTS=n: in two lanes, what is left goes in n batches at least (tuning)
-    int sx_exact_lanes = 0;               // FSK_SPARSE_EXACT_LANES=1 / 2: the batches of an exact accumulate never / always in two lanes (0: from six batches on)
     hipEvent_t ev_lane[4] = {nullptr, nullptr, nullptr, nullptr};  // exact accumulate in two lanes: fork, join, K handed on by lane 0 / 1
     DevBuf<uint32_t> d_owner_r0;
     DevBuf<u64> d_U;
@@ -194,7 +229,10 @@ struct fsk_engine {
     uint32_t n_owners = 0, sx_rounds = 1, sx_cap = 0;
     uint32_t sx_rounds_slot = 1, sx_cap_slot = 0;  // the same for the by-slot form of k_sx_consume (variance mode)
     int sx_pb = 16, sx_sb = 1, sx_keybits = 1, sx_own_shift = 13;
+    int sx_symbits = 0;  // != 0: the k-mer space passes 2^62 and a key is the symbols' sx_symbits-bit fields side by side, not a mixed-radix number
     bool sx_lists = false, owner_ready = false;
+    bool sx_pairs_asked = true;
+    bool sx_pairs = false;  // update streams: unit products travel as 15-bit cells, two to a 32-bit container (bands of < 32767 cells)
     int64_t owner_N = -1;                 // the number of sequences the owner bands were planned for
     // profile mode, dense dataflow: U of the last single-chunk combo list is kept, so that repeating
     // the same pass (bench steps, row bands of later passes) does not re-read every count panel
@@ -202,8 +240,6 @@ struct fsk_engine {
     std::vector<int32_t> u_combos;
     bool u_known = false, u_pending = false;
     u64 u_value = 0, u_extra = 0;
-    int force_global_pairs = 0;  // FSK_SPARSE_GLOBAL=1: per-pair global atomics (testing)
-    u64 sx_max_words = (u64)1 << 31;  // update words per batch beyond which the pairs go to K with atomics (FSK_LIST_MAX_WORDS: testing)
     // Batches are enqueued without waiting for their word counts once one batch of these sequences has
     // been sized: the stream buffer keeps headroom over the largest count seen, the kernels leave a
     // batch that does not fit alone, and the host redoes such a batch (sized exactly) when it reads the
@@ -216,27 +252,24 @@ struct fsk_engine {
     u64* h_sx_head_stat = nullptr;           //                                   their {pairs, words}
     // variance mode, grouped sparse batches: u16 slot triangles (half the bytes between k_sx_consume and the Welford pass); a
     // sum above 65535 raises the batch's flag in pinned memory and the batch is redone with u32 triangles, which the
-    // sequences then keep (slots16_ok). FSK_VAR_SLOTS16=0: never.
+    // sequences then keep (slots16_ok). Tuning var_slots16 = 0: never.
     bool sx_slot16 = false;              // set by run_variance_mode around the accumulate of a deferred batch
     bool sx_slot16_used = false;         // what accumulate_sparse really did
     bool slots16_ok = true;
-    int allow_slots16 = 1;
     uint32_t* h_sx_head_flag = nullptr;  // pinned, fixed size: one overflow flag per deferred batch
     uint32_t* sx_ovf_now = nullptr;      // the flag of the batch being enqueued
     int sx_last_lane = 0;                // the lane (scratch + stream) the last accumulate_sparse ran in
-    int sx_hint = 1;                     // FSK_SPARSE_HINT=0: the words per record of the previous set of sequences are never kept as a hint
     u64 sx_shape[4] = {0, 0, 0, 0};      // sequences, windows, alphabet, longest sequence of the set at hand
     double sx_wpr = 0;                   // most update words per sort record of a batch since the sequences were loaded (0: none seen)
     u64 sx_words_of(u64 nrec) const { return (u64)(sx_wpr * (double)nrec) + 1; }  // what a batch of nrec records is expected to emit
     void sx_saw(u64 words, u64 nrec) { if (nrec) sx_wpr = std::max(sx_wpr, std::max(1e-9, (double)words / (double)nrec)); }
     struct SxDefer { bool active = false; u64 cap = 0, nrec = 0; } sx_defer[8];
-    int force_seg_chunks = 0;            // FSK_SEG_SCAN_CHUNKED=1: the three-launch segment scan whatever the tile count (testing)
-    int sx_sync = 0;                     // FSK_SPARSE_SYNC=1: size every batch exactly (testing); also while redoing a batch
-    u64 sx_guard_cap = 0;                // FSK_SPARSE_GUARD_CAP=n: pretend the stream buffer holds n words (testing the redo)
     u64 sx_redone = 0;                   // batches redone because they did not fit
-    int tile_dma = 1;            // FSK_TILE_DMA=0: register-staged tile kernel instead of the direct-to-LDS one (testing)
-    int compact_dma = 1;         // FSK_COMPACT_DMA=0: register-staged k_dense_tile_compact for key-compacted panels instead of the
-                                 // direct-to-LDS k_dense_tile_dma_compact (both side-aware in their remainders; the latter 8 % faster on config 3)
+    bool sx_redoing = false;             // set around such a redo: the batch waits for its word count and is sized exactly
+    bool sx_exactly() const { return tune.sparse_sync != 0 || sx_redoing; }
+    // update words per batch beyond which the pairs go to K with atomics
+    u64 sx_max_words() const { return tune.list_max_words > 0 ? std::min<u64>((u64)1 << 31, (u64)tune.list_max_words) : (u64)1 << 31; }
+    bool trace() const { return tune.trace != 0; }
 
     fsk_stats st{};
 
@@ -252,16 +285,56 @@ struct fsk_engine {
     fsk::SeqView view() const {
         return fsk::SeqView{d_words.p, d_wstart.p, d_len.p, (uint32_t)N, bits};
     }
-    void tic() {
-        if (cfg.profile) (void)hipEventRecord(ev0, stream);
+    // ---- HIP-event timing of the kernel families (fsk_stats.ms_*). fsk_config.profile = 1: measurement mode — every interval
+    // is waited for on the spot (and the exact update count U is computed; the sparse dataflow runs on one stream, every batch
+    // sized exactly). profile = 2: the PRODUCT dataflow, untouched — the events are only recorded (on the stream the kernels
+    // are launched on) and their times are harvested later, by fsk_get_stats or when some hundred intervals are pending.
+    struct LazyTime { hipEvent_t a, b; double* acc; };
+    std::vector<LazyTime> lazy_pending;
+    std::vector<hipEvent_t> lazy_free;
+    hipEvent_t lazy_open = nullptr;
+    bool profile_sync() const { return cfg.profile == 1; }
+    hipEvent_t lazy_event() {
+        hipEvent_t ev = nullptr;
+        if (!lazy_free.empty()) { ev = lazy_free.back(); lazy_free.pop_back(); }
+        else if (hipEventCreate(&ev) != hipSuccess) ev = nullptr;
+        return ev;
     }
-    void toc(double* acc) {
-        if (!cfg.profile) return;
-        (void)hipEventRecord(ev1, stream);
-        (void)hipEventSynchronize(ev1);
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, ev0, ev1);
-        *acc += ms;
+    void harvest_times() {
+        for (const LazyTime& t : lazy_pending) {
+            float ms = 0;
+            if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) *t.acc += ms;
+            lazy_free.push_back(t.a);
+            lazy_free.push_back(t.b);
+        }
+        lazy_pending.clear();
+    }
+    void lazy_interval(hipEvent_t a, hipEvent_t b, double* acc) {
+        if (!a || !b) { if (a) lazy_free.push_back(a); if (b) lazy_free.push_back(b); return; }
+        lazy_pending.push_back(LazyTime{a, b, acc});
+        if (lazy_pending.size() >= 512) harvest_times();
+    }
+    void tic(hipStream_t s = nullptr) {
+        if (cfg.profile == 1) (void)hipEventRecord(ev0, s ? s : stream);
+        else if (cfg.profile == 2) {
+            if (lazy_open) lazy_free.push_back(lazy_open);
+            lazy_open = lazy_event();
+            if (lazy_open) (void)hipEventRecord(lazy_open, s ? s : stream);
+        }
+    }
+    void toc(double* acc, hipStream_t s = nullptr) {
+        if (cfg.profile == 1) {
+            (void)hipEventRecord(ev1, s ? s : stream);
+            (void)hipEventSynchronize(ev1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ev0, ev1);
+            *acc += ms;
+        } else if (cfg.profile == 2 && lazy_open) {
+            hipEvent_t b = lazy_event();
+            if (b) (void)hipEventRecord(b, s ? s : stream);
+            lazy_interval(lazy_open, b, acc);
+            lazy_open = nullptr;
+        }
     }
 };
 
@@ -273,10 +346,12 @@ namespace fsk_detail {
 constexpr size_t LDS_BUDGET = 150 * 1024;       // of 160 KiB per CU
 constexpr u64 DENSE_MAX_KEYS = 16384;           // count panels: alphabet^k <= this (DNA up to k = 7)
 constexpr size_t SPARSE_MAX_RECORDS = 1u << 27; // records per sort batch (0.5 GB of 4-byte records; each batch pays ~20 launches)
-constexpr u64 SX_MAX_LIST_WORDS = (u64)1 << 31;  // update words of one sparse batch beyond which its pairs go to K with atomics
 constexpr int FSK_RETRY_UNGROUPED = 1;  // internal: a per-slot sparse batch has to be redone one combo at a time
 
 // fsk_engine.hip
+int tuning_set(fsk_tuning& t, const char* key, int64_t value, std::string& err);  // FSK_EINVAL: unknown key / out of range
+int tuning_parse(fsk_tuning& t, const char* text, std::string& err);             // "key=value,key=value"
+std::string tuning_in_force(const fsk_tuning& t);                                // the keys that differ from their defaults
 void set_create_error(const std::string& msg);  // what fsk_last_error(NULL) reports (per thread)
 int64_t n_choose_k(int n, int k);
 int materialise_zero(fsk_engine* e);
@@ -294,7 +369,7 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
 
 // fsk_engine_sparse.hip
 // which lane (scratch set + stream) the deferred batch `defer` of variance mode runs in
-inline int sx_lane_of(const fsk_engine* e, int defer) { return (defer >= 0 && e->sx_two_lanes && !e->cfg.profile) ? (defer & 1) : 0; }
+inline int sx_lane_of(const fsk_engine* e, int defer) { return (defer >= 0 && !e->profile_sync()) ? (defer & 1) : 0; }
 void plan_owner_bands(fsk_engine* e);
 bool sx_harvest(fsk_engine* e, int slot);
 int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0, int64_t row1, u64 slot_stride = 0,
@@ -329,6 +404,8 @@ int group_set_combo_order(fsk_engine* e, const int32_t* order, int32_t n);
 int group_set_seed(fsk_engine* e, uint64_t seed);
 int group_get_stats(fsk_engine* e, fsk_stats* out);
 int group_set_skip_test_block(fsk_engine* e, int32_t skip);
+int group_set_tuning(fsk_engine* e, const char* key, int64_t value, std::string& err);
+void group_set_profile(fsk_engine* e, int profile);
 void group_destroy(fsk_engine* e);
 void group_note_bound_counts(fsk_engine* e);  // fsk_bind_counts on a group handle: the bound cells are not bounded by the combos since a reset
 

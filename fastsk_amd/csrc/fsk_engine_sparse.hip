@@ -22,8 +22,10 @@ void plan_owner_bands(fsk_engine* e) {
     // of its triangular index, bands hold about 2^t cells (2^t + N at most: the last row of a band is
     // kept whole) and can be empty when a single row is longer than 2^t cells.
     const u64 N = (u64)e->N, cells = N * (N + 1) / 2;
-    if (e->owner_N == e->N && e->n_owners != 0) return;  // (the bands depend on the number of sequences alone: the same plan, and its table stays on the device)
+    const bool want_pairs = e->tune.sparse_pairs != 0;
+    if (e->owner_N == e->N && e->n_owners != 0 && e->sx_pairs_asked == want_pairs) return;  // (the bands depend on the number of sequences alone: the same plan, and its table stays on the device)
     e->owner_N = e->N;
+    e->sx_pairs_asked = want_pairs;
     // (as large as ONE round of k_sx_consume takes: with half the bands k_sx_emit bins, scans and offsets half as much per
     // tile and the per-(tile, band) word counts are half the matrix — config 4, N = 2560: 400 -> 200 bands, emit 3.75 ->
     // 3.57 ms, the column scans 0.37 -> 0.26, consume 1.04 -> 1.13)
@@ -46,6 +48,12 @@ void plan_owner_bands(fsk_engine* e) {
     int L = 1;
     while (((u64)1 << L) < largest) ++L;
     e->sx_pb = 32 - L;
+    // PAIRS: a band of fewer than 32767 cells (every workload the streams are fast on) takes its unit products — both
+    // multiplicities 1: 94 % of the words on protein data — as bare 15-bit cells, two to a 32-bit container with bit 31 set
+    // (0x7fff: no cell); every other word is {0, cell: 15 bits, product: 16 bits}. Half the bytes of those words between
+    // k_sx_emit and k_sx_consume.
+    e->sx_pairs = want_pairs && largest <= 32766;
+    if (e->sx_pairs) e->sx_pb = 16;
     e->sx_rounds = (uint32_t)std::max<u64>(1, (largest + SX_CAP - 1) / SX_CAP);
     e->sx_cap = (uint32_t)std::max<u64>(1, std::min<u64>(SX_CAP, largest));
     e->sx_rounds_slot = (uint32_t)std::max<u64>(1, (largest + SX_CAP_SLOT - 1) / SX_CAP_SLOT);
@@ -71,8 +79,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     if (nrec == 0) return FSK_OK;
     // Only the k-mer bits are sorted: the records of a slot are generated in sequence order and every
     // LSD pass is stable, so equal k-mers end up contiguous with their sequence ids ascending.
-    int keybits = 1;
-    while (keybits < 62 && ((u64)1 << keybits) < (u64)e->V) ++keybits;
+    const int keybits = e->sx_keybits;
     const int sb = e->sx_sb;
     const int passes = (keybits + 7) / 8;
     // the k-mer bits split evenly over the passes: 19 bits sort as 7 + 6 + 6, not 8 + 8 + 3 (a ballot per bit and record)
@@ -81,7 +88,8 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     const uint32_t tps = (nfeat + fsk::SX_TILE - 1) / fsk::SX_TILE;   // sort tiles per slot
     const uint32_t tpg = (nfeat + fsk::SG_TILE - 1) / fsk::SG_TILE;   // segment tiles per slot
     const uint32_t ntiles = tpg * (uint32_t)nb;
-    const bool lists = e->sx_lists && !e->force_global_pairs;
+    const bool lists = e->sx_lists && !e->tune.sparse_global;
+    const int pairs = lists && e->sx_pairs ? 1 : 0;  // (unit products as bare cells, two to a word: plan_owner_bands)
     const bool slot16 = slot_stride != 0 && e->sx_slot16_used;  // (u16 slot triangles: set by accumulate_sparse for a deferred batch)
     const uint32_t O = e->n_owners;
     for (int b = 0; b < 2; ++b) FSK_HIP(S.d_keys[b].reserve(nrec * sizeof(RecT)));
@@ -150,7 +158,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
 
     RecT* rec[2] = {(RecT*)S.d_keys[0].p, (RecT*)S.d_keys[1].p};
 
-    e->tic();
+    e->tic(stream);
     const uint8_t* const pos_tab = by_id ? (const uint8_t*)e->d_allpos.p
                                    : consecutive ? (const uint8_t*)e->d_allpos.p + (size_t)combos[0] * e->k : (const uint8_t*)e->d_pos.p + pos_off;
     u64* const zeroed_stats = S.d_sxstat.p;
@@ -159,10 +167,10 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     const bool small = R32 && e->V <= ((u64)1 << 24) && e->sigma < (1u << 24);  // (the k-mer and every prefix of it fit 24 bits)
     fsk::SxSrc src{};
     src.win = e->d_win.p; src.feat_seq = e->d_featseq.p; src.combo_pos = pos_tab;
-    src.k = e->k; src.sb = sb; src.bits = e->bits; src.by_id = by_id ? 1 : 0; src.sigma = e->sigma; src.ids = ids;
+    src.k = e->k; src.sb = sb; src.bits = e->bits; src.by_id = by_id ? 1 : 0; src.sigma = e->sigma; src.symbits = e->sx_symbits; src.ids = ids;
     if (ww) {
         // (four slots per workgroup share the window loads when that still leaves a few thousand workgroups)
-        const bool four = e->extract_slots ? e->extract_slots == 4 : (u64)tps * (u64)nb >= 8192;
+        const bool four = e->tune.extract_slots ? e->tune.extract_slots == 4 : (u64)tps * (u64)nb >= 8192;
 #define FSK_EXTRACT_WIN(SPW)                                                                                          \
     (ww == 2 ? (small ? fsk::k_sx_extract_win<RecT, 2, R32, SPW> : fsk::k_sx_extract_win<RecT, 2, false, SPW>)         \
              : (small ? fsk::k_sx_extract_win<RecT, 4, R32, SPW> : fsk::k_sx_extract_win<RecT, 4, false, SPW>))
@@ -172,12 +180,12 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                    S.d_blockhist.p, dmask, zeroed_stats);
     } else {
         FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_extract<RecT>), dim3(tps, nb), dim3(256), 0, stream, e->view(), e->d_featseq.p,
-                   e->d_fstart.p, nfeat, tps, e->k, e->sigma, sb, pos_tab, rec[0], S.d_blockhist.p, dmask, ids, zeroed_stats, by_id ? 1 : 0);
+                   e->d_fstart.p, nfeat, tps, e->k, e->sigma, sb, pos_tab, rec[0], S.d_blockhist.p, dmask, ids, zeroed_stats, by_id ? 1 : 0, e->sx_symbits);
     }
-    e->toc(&e->st.ms_extract);
+    e->toc(&e->st.ms_extract, stream);
     e->st.launches += 1;
 
-    e->tic();
+    e->tic(stream);
     int cur = 0;
     for (int p = 0, shift = sb; p < passes; shift += pass_bits(p), ++p) {
         const int nbits = pass_bits(p);
@@ -196,11 +204,11 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         cur ^= 1;
         e->st.launches += 3;
     }
-    e->toc(&e->st.ms_sort);
+    e->toc(&e->st.ms_sort, stream);
     e->st.sort_records += nrec;
     e->st.sort_passes = passes;
 
-    e->tic();
+    e->tic(stream);
     const uint32_t maxprod = (1u << e->sx_pb) - 1u;
     const uint32_t cmax = maxprod / std::max<uint32_t>(1u, e->maxW);  // multiplicities up to here: one word per pair
     FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_seg_count<RecT>), dim3(tpg, nb), dim3(256), 0, stream, rec[cur], nfeat, tpg, sb,
@@ -208,7 +216,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     {
         const int* lth = skipping ? (const int*)S.d_tile_lth.p : (const int*)nullptr;
         int* ts = skipping ? S.d_tile_ts.p : (int*)nullptr;
-        if (ntiles <= 4096u && !e->force_seg_chunks) {  // one workgroup walks the tile records
+        if (ntiles <= 4096u && !e->tune.seg_scan_chunked) {  // one workgroup walks the tile records
             FSK_LAUNCH(fsk::k_sx_seg_scan, dim3(1), dim3(1024), 0, stream, (const uint32_t*)S.d_tile_ent.p, (const int*)S.d_tile_lrh.p, ntiles,
                        S.d_ebase.p, S.d_tile_rs.p, lth, ts, (const uint32_t*)nullptr, (const int*)nullptr, (const int*)nullptr,
                        (uint32_t*)nullptr, (int*)nullptr, (int*)nullptr);
@@ -234,16 +242,16 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         }
     }
     // entries in the packed format (4 + 2 + 2 bytes) when sequence ids, multiplicities and ranks fit 16 bits
-    const bool packed = e->N < 65535 && e->maxW < 65536u;
+    const bool packed = e->N < 65535 && e->maxW < 65536u && !e->tune.sparse_unpacked;
     if (packed) {
-        auto k_seg = fsk::k_sx_seg_write<RecT, true>;
+        auto k_seg = pairs ? fsk::k_sx_seg_write<RecT, true, true> : fsk::k_sx_seg_write<RecT, true, false>;
         FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)S.d_ebase.p,
                    (const int*)S.d_tile_rs.p, reinterpret_cast<uint32_t*>(S.d_E.p), reinterpret_cast<uint16_t*>(S.d_Pk.p), e->sx_own_shift, O,
                    lists ? S.d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, S.d_tile_stat.p,
                    skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr,
                    skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr);
     } else {
-        auto k_seg = fsk::k_sx_seg_write<RecT, false>;
+        auto k_seg = pairs ? fsk::k_sx_seg_write<RecT, false, true> : fsk::k_sx_seg_write<RecT, false, false>;
         FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)S.d_ebase.p,
                    (const int*)S.d_tile_rs.p, S.d_E.p, S.d_Pk.p, e->sx_own_shift, O,
                    lists ? S.d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, S.d_tile_stat.p,
@@ -274,10 +282,10 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         words = stat_pin[1];
         e->sx_saw(words, nrec);
     }
-    e->toc(&e->st.ms_segment);
+    e->toc(&e->st.ms_segment, stream);
 
-    e->tic();
-    const bool use_lists = lists && words < e->sx_max_words;
+    e->tic(stream);
+    const bool use_lists = lists && words < e->sx_max_words();
     if (slot_stride != 0 && !use_lists) return FSK_RETRY_UNGROUPED;  // (nothing of this batch has touched K yet)
     if (use_lists) {
         if (words > 0 || slot_stride != 0) {
@@ -290,13 +298,13 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                            reinterpret_cast<const uint16_t*>(S.d_Pk.p), (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p,
                            e->sx_own_shift, O, (const uint32_t*)S.d_list_off.p, (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)row0,
                            (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg, slot_stride,
-                           skipping ? reinterpret_cast<const uint16_t*>(S.d_Tk.p) : (const uint16_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles);
+                           skipping ? reinterpret_cast<const uint16_t*>(S.d_Tk.p) : (const uint16_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles, pairs);
             } else {
                 auto k_emit = skipping ? fsk::k_sx_emit<false, true, false> : fsk::k_sx_emit<false, false, false>;
                 FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, (const uint2*)S.d_E.p, (const uint32_t*)S.d_Pk.p,
                            (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)S.d_list_off.p,
                            (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
-                           slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles);
+                           slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles, pairs);
             }
             const size_t lds = (size_t)e->sx_cap * sizeof(uint32_t), lds_slot = (size_t)e->sx_cap_slot * sizeof(uint32_t);
             FSK_HIP(fsk_hw::allow_dynamic_lds(fsk::k_sx_consume<false>, lds));
@@ -313,19 +321,19 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                     FSK_LAUNCH(k_cs16, dim3(O, e->sx_rounds_slot, nb), dim3(fsk::CS_THREADS), lds_slot, stream, (const uint32_t*)S.d_ulist.p,
                                (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)nullptr, O, target,
                                e->sx_cap_slot, e->sx_pb, K, (const uint32_t*)S.d_ucount.p, tpg, slot_stride, (const u64*)S.d_sxstat.p, cap_words,
-                               e->sx_ovf_now);
+                               e->sx_ovf_now, pairs);
                 } else {
                     FSK_LAUNCH(fsk::k_sx_consume<true>, dim3(O, e->sx_rounds_slot, nb), dim3(fsk::CS_THREADS), lds_slot, stream, (const uint32_t*)S.d_ulist.p,
                                (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)nullptr, O, target,
                                e->sx_cap_slot, e->sx_pb, K, (const uint32_t*)S.d_ucount.p, tpg, slot_stride, (const u64*)S.d_sxstat.p, cap_words,
-                               (uint32_t*)nullptr);
+                               (uint32_t*)nullptr, pairs);
                 }
             } else {
                 FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, stream, (const uint32_t*)S.d_list_off.p, O, target, S.d_part_base.p,
                            (const u64*)S.d_sxstat.p, cap_words);
                 FSK_LAUNCH(fsk::k_sx_consume<false>, dim3(max_parts, e->sx_rounds), dim3(fsk::CS_THREADS), lds, stream, (const uint32_t*)S.d_ulist.p,
                            (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)S.d_part_base.p, O, target,
-                           e->sx_cap, e->sx_pb, K, (const uint32_t*)nullptr, tpg, (u64)0, (const u64*)S.d_sxstat.p, cap_words, (uint32_t*)nullptr);
+                           e->sx_cap, e->sx_pb, K, (const uint32_t*)nullptr, tpg, (u64)0, (const u64*)S.d_sxstat.p, cap_words, (uint32_t*)nullptr, pairs);
                 e->st.launches += 1;
             }
             e->st.launches += 2;
@@ -338,13 +346,13 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                        reinterpret_cast<const uint16_t*>(S.d_Pk.p), (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift,
                        O, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod,
                        cmax, e->sx_pb, K, tpg, slot_stride, skipping ? reinterpret_cast<const uint16_t*>(S.d_Tk.p) : (const uint16_t*)nullptr,
-                       (const u64*)nullptr, ~(u64)0, ntiles);
+                       (const u64*)nullptr, ~(u64)0, ntiles, 0);
         } else {
             auto k_emit = skipping ? fsk::k_sx_emit<true, true, false> : fsk::k_sx_emit<true, false, false>;
             FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, (const uint2*)S.d_E.p, (const uint32_t*)S.d_Pk.p,
                        (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)nullptr,
                        (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
-                       slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)nullptr, ~(u64)0, ntiles);
+                       slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)nullptr, ~(u64)0, ntiles, 0);
         }
         e->st.launches += 1;
     }
@@ -356,7 +364,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                    use_lists ? (const u64*)S.d_sxstat.p : (const u64*)nullptr, cap_words, slot16 ? 1 : 0, slot16 ? e->sx_ovf_now : (uint32_t*)nullptr);
     e->st.launches += 1;
     if (k_done) FSK_HIP(hipEventRecord(k_done, stream));
-    e->toc(&e->st.ms_pairs);
+    e->toc(&e->st.ms_pairs, stream);
     FSK_HIP(hipGetLastError());
     return FSK_OK;
 }
@@ -421,15 +429,15 @@ int sx_pinned(fsk_engine* e, size_t tail_pos_bytes, size_t tail_stat_words) {
 // how many words a batch may hold when it is enqueued before its count is known (0: size it exactly)
 u64 sx_guard_for(fsk_engine* e, int lane, u64 nrec) {
     DevBuf<uint32_t>& ulist = e->sxs[lane].d_ulist;
-    if (e->sx_sync || e->cfg.profile) return 0;
-    if (!e->sx_lists || e->force_global_pairs) return ~(u64)0;       // no streams: nothing to size
+    if (e->sx_exactly() || e->profile_sync()) return 0;
+    if (!e->sx_lists || e->tune.sparse_global) return ~(u64)0;       // no streams: nothing to size
     if (e->sx_wpr == 0) return 0;                                       // (the first batch of these sequences)
-    if (e->sx_guard_cap)  // (testing: pretend the stream buffer holds this many words)
-        return ulist.reserve((size_t)e->sx_guard_cap) == hipSuccess ? e->sx_guard_cap : 0;
+    if (e->tune.guard_cap)  // (testing: pretend the stream buffer holds this many words)
+        return ulist.reserve((size_t)e->tune.guard_cap) == hipSuccess ? (u64)e->tune.guard_cap : 0;
     const u64 expect = e->sx_words_of(nrec), want = expect + expect / 2;  // (words per record differ by a few percent between batches)
-    if (want >= e->sx_max_words) return 0;
+    if (want >= e->sx_max_words()) return 0;
     if ((u64)ulist.cap < want && ulist.reserve((size_t)want) != hipSuccess) return 0;
-    return std::min<u64>((u64)ulist.cap, e->sx_max_words - 1);
+    return std::min<u64>((u64)ulist.cap, e->sx_max_words() - 1);
 }
 
 // the counts of deferred batch `slot` (its kernels have finished): false when it has to be redone
@@ -457,7 +465,7 @@ bool sx_harvest(fsk_engine* e, int slot) {
 // slot_stride != 0 (variance mode): combo q of the list goes to its own u32 triangle (uint32_t*)K + q * slot_stride,
 // written whole; returns FSK_RETRY_UNGROUPED when that form cannot be used for this batch.
 // defer >= 0 (variance mode): the call returns with the batch enqueued; the caller passes `defer` to
-// sx_harvest() once the batch has finished and redoes the batch (with e->sx_sync set) if that says so.
+// sx_harvest() once the batch has finished and redoes the batch (with e->sx_redoing set) if that says so.
 int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0, int64_t row1, u64 slot_stride,
                       int defer) {
     { int rcz = materialise_zero(e); if (rcz) return rcz; }
@@ -470,13 +478,13 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     const size_t nfeat = (size_t)std::max<int64_t>(1, e->nfeat);
     const u64 by_cells = std::max<u64>(1, 0xffffffffull / std::max<u64>(1, (u64)e->maxW * e->maxW));
     auto batch_combos = [&](int left) {
-        size_t recs = e->sx_batch_records ? e->sx_batch_records : SPARSE_MAX_RECORDS;
+        size_t recs = e->tune.sparse_batch_records ? (size_t)e->tune.sparse_batch_records : SPARSE_MAX_RECORDS;
         if (e->sx_wpr == 0) recs = std::min<size_t>(recs, (size_t)1 << 25);
-        else recs = std::min<size_t>(recs, (size_t)std::max(1.0, (double)(e->sx_max_words / 2) / e->sx_wpr));
+        else recs = std::min<size_t>(recs, (size_t)std::max(1.0, (double)(e->sx_max_words() / 2) / e->sx_wpr));
         const u64 B = std::max<u64>(1, std::min<u64>({(u64)(recs / nfeat), (u64)left, by_cells, (u64)65535}));  // (65535: grid.y)
         return (int)B;
     };
-    const int recbits = e->sx_keybits + e->sx_sb;  // (<= 62 + 31: a 128-bit record always holds it)
+    const int recbits = e->sx_keybits + e->sx_sb;  // (<= 96 + 31: a 128-bit record always holds it)
     if (defer >= 0 && (defer >= SX_DEFER || batch_combos(n) != n || n > SX_DEFER_COMBOS)) defer = -1;
     // variance mode's batches in flight alternate between two lanes of scratch and two streams
     const int lane = sx_lane_of(e, defer);
@@ -494,7 +502,7 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     };
     e->sx_slot16_used = false;
     if (defer >= 0) {
-        e->sx_slot16_used = e->sx_slot16 && slot_stride != 0 && e->sx_lists && !e->force_global_pairs;
+        e->sx_slot16_used = e->sx_slot16 && slot_stride != 0 && e->sx_lists && !e->tune.sparse_global;
         e->sx_ovf_now = e->h_sx_head_flag + defer;
         e->h_sx_head_flag[defer] = 0u;
         const u64 guard = sx_guard_for(e, lane, (u64)n * nfeat);
@@ -517,11 +525,11 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     // fsk_compute starts with one — says nothing about the batches that follow)
     int nb_steady = nb0;
     if (e->sx_wpr == 0) {
-        const size_t recs = e->sx_batch_records ? e->sx_batch_records : SPARSE_MAX_RECORDS;
+        const size_t recs = e->tune.sparse_batch_records ? (size_t)e->tune.sparse_batch_records : SPARSE_MAX_RECORDS;
         nb_steady = (int)std::max<u64>(1, std::min<u64>({(u64)(recs / nfeat), (u64)n, by_cells, (u64)65535}));
     }
     const bool many = (n + nb_steady - 1) / nb_steady >= 6;
-    const bool two = (e->sx_exact_lanes >= 2 || (e->sx_exact_lanes == 0 && many)) && !e->cfg.profile && !e->sx_sync && slot_stride == 0 && nb0 < n;
+    const bool two = (e->tune.sparse_exact_lanes >= 2 || (e->tune.sparse_exact_lanes == 0 && many)) && !e->profile_sync() && !e->sx_exactly() && slot_stride == 0 && nb0 < n;
     if (two) {
         if (!e->lane_stream) FSK_HIP(hipStreamCreateWithFlags(&e->lane_stream, hipStreamNonBlocking));
         for (auto& ev : e->ev_lane)
@@ -539,7 +547,6 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
             // while a batch still has a few dozen combos)
             const int left = n - s;
             int parts = (left + nb - 1) / nb;
-            parts = std::max(parts, std::min(e->sx_exact_parts, std::max(1, left / 32)));
             nb = std::min(nb, (left + parts - 1) / parts);
         }
         int ln = two ? next_lane : 0;
@@ -581,10 +588,10 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
         if (words <= b.cap) { e->u_extra += pairs; continue; }
         // the batch did not fit and has left K alone: once more, sized exactly
         e->sx_redone += 1;
-        const int was = e->sx_sync;
-        e->sx_sync = 1;
+        const bool was = e->sx_redoing;
+        e->sx_redoing = true;
         rc = one(b.s, b.nb, e->h_sx_pos + (size_t)b.s * e->k, e->h_sx_stat + 2 * i, 0, 0);
-        e->sx_sync = was;
+        e->sx_redoing = was;
         if (rc) return rc;
     }
     return FSK_OK;

@@ -62,10 +62,10 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     // of the oldest one in flight, a latency a third batch would cover —: config 1 6.4 -> 6.8 -> 7.4 ms; the GPU is
     // busy as it is, and what the extra batches add are iterations beyond the stop.)
     constexpr int MAX_AHEAD = 16, MAX_DEPTH = 2, LANES = 2;
-    const int AHEAD = std::max(1, std::min(MAX_AHEAD, e->var_ahead));  // iterations per batch (FSK_VAR_AHEAD; 8: see above)
+    const int AHEAD = 8;  // iterations per batch (see above)
     const int DEPTH = MAX_DEPTH, INFLIGHT = MAX_DEPTH;
     const int RING = DEPTH * AHEAD + 1;
-    const bool trace = getenv("FSK_TRACE") != nullptr;  // stderr: where the wall time of this mode goes
+    const bool trace = e->trace();  // stderr: where the wall time of this mode goes
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
     double t_wait = 0;
@@ -95,7 +95,7 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     // Sparse batches in flight alternate between two lanes (scratch + stream, sx_lane_of): the short kernels of one
     // batch's sort and segmentation run in the gaps of the other's emit / consume / Welford. What orders them: a
     // batch's Welford pass waits for the previous batch's (K_hat is handed from one to the next) through ev_wf.
-    if (e->sx_two_lanes && !e->cfg.profile && !e->lane_stream) FSK_HIP(hipStreamCreateWithFlags(&e->lane_stream, hipStreamNonBlocking));
+    if (!e->profile_sync() && !e->lane_stream) FSK_HIP(hipStreamCreateWithFlags(&e->lane_stream, hipStreamNonBlocking));
     auto sync_all = [e]() {
         (void)hipStreamSynchronize(e->stream);
         if (e->lane_stream) (void)hipStreamSynchronize(e->lane_stream);
@@ -135,7 +135,7 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
         int most = AHEAD;
         if (e->path == FSK_PATH_SPARSE) {
             if (e->sx_wpr == 0) most = std::min(most, (int)fsk::WF_SLOTS);
-            else most = std::max(1, std::min(most, (int)((double)(e->sx_max_words / 2) / (e->sx_wpr * (double)std::max<int64_t>(1, e->nfeat)))));
+            else most = std::max(1, std::min(most, (int)((double)(e->sx_max_words() / 2) / (e->sx_wpr * (double)std::max<int64_t>(1, e->nfeat)))));
         }
         int n = most;
         if (pred_stop != INT32_MAX) {
@@ -158,13 +158,13 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     // land in AHEAD separate triangles; dense dataflow: one iteration at a time into the engine's triangle
     // (u32 triangles written whole by k_sx_consume; without update streams — huge N — pairs go to K with
     // atomics and the iterations run one at a time like the dense ones)
-    bool grouped = e->path == FSK_PATH_SPARSE && e->sx_lists && !e->force_global_pairs;
+    bool grouped = e->path == FSK_PATH_SPARSE && e->sx_lists && !e->tune.sparse_global;
     // Dense dataflow with a tile kernel that can STORE (one workgroup per tile, the direct-to-LDS kernel, no
     // key compaction, no test-block filter): every iteration's tile launch stores its counts into a u64
     // triangle of its own — no zero fill — and the batch's Welford updates run as one pass like the sparse
     // batches' (while the slot triangles stay a modest share of the memory).
-    const bool dense_slots = e->path == FSK_PATH_DENSE && e->tile_dma && !e->compact && !(e->cfg.skip_test_block && e->n_test > 0) &&
-                             (u64)pairs * AHEAD * DEPTH * sizeof(u64) <= ((u64)8 << 30) && e->variance_dense_slots;
+    const bool dense_slots = e->path == FSK_PATH_DENSE && !e->compact && !(e->cfg.skip_test_block && e->n_test > 0) &&
+                             (u64)pairs * AHEAD * DEPTH * sizeof(u64) <= ((u64)8 << 30) && e->tune.variance_dense_slots;
     // (one set of slot triangles per batch in flight: a stop inside a batch runs its Welford prefix again)
     if (grouped) FSK_HIP(e->d_Kslots.reserve((ps * AHEAD * DEPTH + 1) / 2));
     if (dense_slots) FSK_HIP(e->d_Kslots.reserve(ps * AHEAD * DEPTH));
@@ -207,7 +207,7 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
         if (grouped) {
             int32_t combos[MAX_AHEAD];
             for (int b = 0; b < B.n; ++b) combos[b] = e->order[B.first_item + b * T];
-            e->sx_slot16 = e->allow_slots16 && e->slots16_ok;  // (u16 slot triangles until a sum of these sequences has not fit one)
+            e->sx_slot16 = e->tune.var_slots16 && e->slots16_ok;  // (u16 slot triangles until a sum of these sequences has not fit one)
             int rc = do_accumulate(e, combos, B.n, reinterpret_cast<u64*>(slots_of(B.part)), 0, -1, (u64)ps, B.part);
             e->sx_slot16 = false;
             B.s16 = e->sx_slot16_used;
@@ -297,11 +297,11 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
                 sync_all();
                 for (const Batch& B : q) { e->st.combos_done -= B.n; e->sx_defer[B.part].active = false; }
                 q.clear();
-                const int was = e->sx_sync;
-                e->sx_sync = 1;
+                const bool was = e->sx_redoing;
+                e->sx_redoing = true;
                 Batch R = A;
                 int rc = issue(R);
-                e->sx_sync = was;
+                e->sx_redoing = was;
                 if (rc) return rc;
                 q.push_back(R);
                 continue;

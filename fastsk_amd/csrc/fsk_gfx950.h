@@ -92,6 +92,19 @@ __device__ __forceinline__ unsigned long long wave_incl_sum_u64(unsigned long lo
     return x;
 }
 
+// the same for 32-bit values (sums below 2^32): six VALU instructions
+__device__ __forceinline__ uint32_t wave_incl_sum_u32(uint32_t x) {
+#define FSK_DPP_ADD32(ctrl, rows) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rows, 0xf, true);
+    FSK_DPP_ADD32(0x111, 0xf)  // row_shr:1
+    FSK_DPP_ADD32(0x112, 0xf)  // row_shr:2
+    FSK_DPP_ADD32(0x114, 0xf)  // row_shr:4
+    FSK_DPP_ADD32(0x118, 0xf)  // row_shr:8
+    FSK_DPP_ADD32(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+    FSK_DPP_ADD32(0x143, 0xc)  // row_bcast:31 into rows 2 and 3
+#undef FSK_DPP_ADD32
+    return x;
+}
+
 // a copy of a VGPR the compiler cannot see through (see the flush of the tile kernels: a 64-bit operand built from
 // the accumulator itself makes hipcc keep every accumulator in the low half of a register pair)
 __device__ __forceinline__ uint32_t vgpr_copy(uint32_t x) {

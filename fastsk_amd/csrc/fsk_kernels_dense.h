@@ -1,6 +1,6 @@
 // fsk_kernels_dense.h — DENSE dataflow: per-sequence LDS counting sort into 4-bit count panels (k_dense_count),
 // key compaction (k_dense_keylut), the exact update count U (k_dense_distinct) and the output-stationary
-// 128x128 tile kernels (fsk_tile_kernel.inc, fsk_tile_kernel_dma.inc). Included by fsk_engine_dense.hip only.
+// 128x128 tile kernels (fsk_tile_kernel_dma.inc). Included by fsk_engine_dense.hip only.
 #pragma once
 #include "fsk_common.h"
 
@@ -380,16 +380,6 @@ __global__ __launch_bounds__(256) void k_dense_remainder_rows(const uint32_t* ro
     if ((threadIdx.x & 63u) == 0 && rows) atomicAdd(out, rows);
 }
 
-#define FSK_TILE_KERNEL k_dense_tile
-#define FSK_TILE_COMPACT 0
-#include "fsk_tile_kernel.inc"
-#undef FSK_TILE_KERNEL
-#undef FSK_TILE_COMPACT
-#define FSK_TILE_KERNEL k_dense_tile_compact
-#define FSK_TILE_COMPACT 1
-#include "fsk_tile_kernel.inc"
-#undef FSK_TILE_KERNEL
-#undef FSK_TILE_COMPACT
 #define FSK_DMA_KERNEL k_dense_tile_dma
 #define FSK_DMA_COMPACT 0
 #include "fsk_tile_kernel_dma.inc"

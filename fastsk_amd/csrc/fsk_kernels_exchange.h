@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void k_p2p_allreduce_wide(PeerBufs bufs, int R
 }
 
 
-// Test-only (FSK_FAULT="device:..."): keeps one wave busy for about `ms` milliseconds of the constant-rate wall clock
+#ifdef FSK_TEST_HOOKS
+// Test builds only (tuning fault_kind = 2): keeps one wave busy for about `ms` milliseconds of the constant-rate wall clock
 // — an engine whose exchange is late — and then ends by itself: bounded by the clock AND by a trip count, so that
 // no value of the clock can leave the GPU hanging.
 __global__ __launch_bounds__(64) void k_spin_ms(u64 ms) {
@@ -64,5 +65,6 @@ __global__ __launch_bounds__(64) void k_spin_ms(u64 ms) {
         fsk_hw::nap();
     }
 }
+#endif
 
 }  // namespace fsk

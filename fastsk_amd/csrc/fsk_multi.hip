@@ -16,7 +16,9 @@
 #include "fsk_engine_internal.h"
 #include "fsk_kernels_exchange.h"
 
-#ifndef FSK_EMU
+#ifdef FSK_EMU
+#include "rccl_emu.h"  // tests/emu: the nccl types and the test-only stand-in the emulated build binds in place of librccl
+#else
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #endif
@@ -35,6 +37,13 @@ struct HostBarrier {
     int n = 1, arrived = 0;
     unsigned gen = 0;
     bool broken = false;
+    // every waiter, now and later, returns false at once (the group is being poisoned: nobody may sit out a deadline —
+    // or, without one, wait for ever — for an engine that has already given up)
+    void release() {
+        std::lock_guard<std::mutex> lk(m);
+        broken = true;
+        cv.notify_all();
+    }
     bool wait(int timeout_ms = 0) {
         std::unique_lock<std::mutex> lk(m);
         if (broken) return false;
@@ -194,6 +203,7 @@ struct P2PCollective : Collective {
             }
         }
     }
+    void abort() override { bar.release(); }
     int all_reduce(int r, void* b, size_t count, XType type, hipStream_t stream, std::string& err) override {
         buf[(size_t)r] = b;
         hipError_t he = hipEventRecord(ready[(size_t)r], stream);
@@ -227,7 +237,6 @@ struct P2PCollective : Collective {
 };
 
 // ---- FSK_COLL_RCCL ---------------------------------------------------------------------------------------
-#ifndef FSK_EMU
 struct RcclApi {
     void* handle = nullptr;
     std::string path;
@@ -240,6 +249,24 @@ struct RcclApi {
     ncclResult_t (*GetVersion)(int*) = nullptr;
 };
 
+#ifdef FSK_EMU
+// the CPU test build has no librccl and no devices: the table is bound to tests/emu/rccl_stub.cpp, which is linked
+// into libfastsk_emu.so and nowhere else — everything from here down (the init thread and its deadline, the rank
+// bookkeeping, payload types, abort) is the product code
+RcclApi* rccl_api(std::string&) {
+    static RcclApi api;
+    api.handle = &api;
+    api.path = "tests/emu/rccl_stub.cpp (test build)";
+    api.CommInitAll = &ncclCommInitAll;
+    api.CommDestroy = &ncclCommDestroy;
+    api.CommAbort = &ncclCommAbort;
+    api.AllReduce = &ncclAllReduce;
+    api.CommCount = &ncclCommCount;
+    api.GetErrorString = &ncclGetErrorString;
+    api.GetVersion = &ncclGetVersion;
+    return &api;
+}
+#else
 // librccl of the ROCm the process already runs on: the image that is mapped (torch's, when torch is
 // imported), else the one beside libamdhip64, else the loader's default search.
 RcclApi* rccl_api(std::string& err) {
@@ -295,6 +322,7 @@ RcclApi* rccl_api(std::string& err) {
     if (!api.handle) { err = why; return nullptr; }
     return &api;
 }
+#endif  // !FSK_EMU
 
 struct RcclCollective : Collective {
     RcclApi* api = nullptr;
@@ -308,10 +336,12 @@ struct RcclCollective : Collective {
         std::mutex m;
         std::condition_variable cv;
         bool done = false;
+        bool abandoned = false;  // the caller gave up waiting: the thread releases whatever it still obtains
         ncclResult_t result = ncclSuccess;
         std::vector<ncclComm_t> comm;
         std::vector<int> dev;
     };
+    bool init_timed_out = false;  // (fatal for the handle whatever the collective asked for: the init may still be running on the devices)
     int init(const std::vector<int>& devices, int init_deadline_ms, std::string& err) {
         kind = FSK_COLL_RCCL;
         api = rccl_api(err);
@@ -323,19 +353,31 @@ struct RcclCollective : Collective {
         RcclApi* a = api;
         std::thread th([job, a] {
             const ncclResult_t r = a->CommInitAll(job->comm.data(), (int)job->dev.size(), job->dev.data());
-            std::lock_guard<std::mutex> lk(job->m);
-            job->result = r;
-            job->done = true;
-            job->cv.notify_all();
+            bool abandoned;
+            {
+                std::lock_guard<std::mutex> lk(job->m);
+                job->result = r;
+                job->done = true;
+                abandoned = job->abandoned;
+                job->cv.notify_all();
+            }
+            if (abandoned && r == ncclSuccess)  // nobody will ever use these communicators: give them back
+                for (size_t q = 0; q < job->comm.size(); ++q)
+                    if (job->comm[q]) {
+                        DeviceScope on(job->dev[q]);
+                        (void)(a->CommAbort ? a->CommAbort(job->comm[q]) : a->CommDestroy(job->comm[q]));
+                    }
         });
         {
             std::unique_lock<std::mutex> lk(job->m);
             if (init_deadline_ms > 0) {
                 if (!job->cv.wait_for(lk, std::chrono::milliseconds(init_deadline_ms), [&] { return job->done; })) {
+                    job->abandoned = true;
+                    init_timed_out = true;
                     lk.unlock();
                     th.detach();
                     err = "ncclCommInitAll over " + std::to_string(devices.size()) + " devices did not return within " +
-                          std::to_string(init_deadline_ms) + " ms (FSK_DEADLINE_MS / fsk_config.deadline_ms)";
+                          std::to_string(init_deadline_ms) + " ms (fsk_config.deadline_ms / tuning deadline_ms)";
                     return FSK_EDEVICE;
                 }
             } else {
@@ -384,7 +426,6 @@ struct RcclCollective : Collective {
         return FSK_OK;
     }
 };
-#endif  // !FSK_EMU
 
 constexpr int MAX_BANDS = 64;  // row bands of one accumulate's all-reduce
 int64_t cell_of(int64_t row) { return row * (row + 1) / 2; }
@@ -407,7 +448,8 @@ struct fsk_group {
     std::vector<int> device;
     std::unique_ptr<Collective> coll;
     std::vector<hipStream_t> xstream;            // the exchange stream of every engine
-    std::vector<hipEvent_t> ev_band, ev_xdone;   // compute -> exchange, exchange -> compute
+    std::vector<hipEvent_t> ev_xdone;            // exchange -> compute
+    std::vector<std::vector<hipEvent_t>> ev_cb;  // [engine][band]: the band's kernels have run on the compute stream (compute -> exchange)
     std::vector<std::vector<hipEvent_t>> ev_xb;  // [engine][band]: the band's collective has run on the exchange stream
     std::vector<DevBuf<int32_t>> stage;          // a band of the triangle narrowed to int32
     WorkerPool pool;
@@ -417,7 +459,7 @@ struct fsk_group {
     int64_t combos_since_reset = 0;   // bounds the cells of engine 0's triangle (narrowing)
     bool bound_unknown = false;       // engine 0's triangle was bound to caller memory of unknown contents: no narrowing until a whole reset
     fsk_multi_info info{};
-    // ---- fail fast (fsk_config.deadline_ms / FSK_DEADLINE_MS): every host-side wait of the exchange — the engines'
+    // ---- fail fast (fsk_config.deadline_ms / tuning deadline_ms): every host-side wait of the exchange — the engines'
     // barriers, and the wait for a band's collective to have run on the device — gives up after deadline_ms, names
     // the stage it was in, aborts the communicator (so that stuck exchange kernels let go of the streams) and
     // leaves the group POISONED: every later call returns FSK_EDEVICE with the first failure's message.
@@ -426,10 +468,6 @@ struct fsk_group {
     std::atomic<int> poisoned{0};
     std::mutex poison_m;
     std::string poison_msg;
-    // test-only fault injection (FSK_FAULT="kind:rank:band:ms"): engine `rank` is late by `ms` milliseconds before
-    // the collective of band `band` — kind "host": its worker thread sleeps; kind "device": a kernel on its exchange
-    // stream spins for that long (bounded: the GPU is never left hanging)
-    int fault_kind = 0, fault_rank = -1, fault_band = -1, fault_ms = 0;
 
     int R() const { return (int)member.size(); }
     void poison(const std::string& msg) {
@@ -439,6 +477,9 @@ struct fsk_group {
             poison_msg = msg;
             poisoned.store(1);
         }
+        // whoever waits for the engine that failed — at the group's barrier, inside the collective — is released at once,
+        // with or without a deadline
+        bar.release();
         if (coll) coll->abort();
     }
     int poisoned_rc(fsk_engine* e) {
@@ -447,11 +488,12 @@ struct fsk_group {
     }
     // every worker reports its code; all leave together with the first failure (nobody is left waiting
     // inside a collective for a rank that gave up)
-    bool agree(int rc) {
+    // (timeout_ms: how long an engine waits for the others; 0: as long as it takes)
+    bool agree(int rc, int timeout_ms) {
         if (rc) failed.store(rc);
-        if (!bar.wait(deadline_ms)) return false;
+        if (!bar.wait(timeout_ms)) return false;
         const bool ok = failed.load() == 0;
-        if (!bar.wait(deadline_ms)) return false;
+        if (!bar.wait(timeout_ms)) return false;
         return ok;
     }
     // run fn on every engine's thread; the first failing engine's message becomes the handle's
@@ -459,6 +501,14 @@ struct fsk_group {
         if (poisoned.load()) return poisoned_rc(member[0]);
         failed.store(0);
         pool.run(fn);
+        if (poisoned.load()) {  // the FIRST failure is the one to report: the other engines only saw its consequences
+            int code = FSK_EDEVICE;
+            for (int r = 0; r < R(); ++r)
+                if (pool.rc[(size_t)r]) { code = pool.rc[(size_t)r]; break; }
+            std::lock_guard<std::mutex> lk(poison_m);
+            member[0]->err = poison_msg;
+            return code;
+        }
         for (int r = 0; r < R(); ++r)
             if (pool.rc[(size_t)r]) {
                 if (r != 0) member[0]->err = "device " + std::to_string(device[(size_t)r]) + ": " + member[(size_t)r]->err;
@@ -495,17 +545,23 @@ int member_accumulate(fsk_group* g, int r, const std::vector<int32_t>& mine, con
     for (size_t b = 0; b + 1 < edges.size(); ++b) {
         const int64_t lo = edges[b], hi = edges[b + 1];
         if (!rc) rc = one_accumulate_rows(e, mine.data(), (int32_t)mine.size(), lo, hi);
-        if (!g->agree(rc)) {
+        if (!g->agree(rc, g->deadline_ms)) {
+            if (g->poisoned.load()) return rc ? rc : g->poisoned_rc(e);
             if (g->bar.broken) return waited(b, "before the band's all-reduce");
             return rc ? rc : e->fail(FSK_EDEVICE, "another engine of the group failed");
         }
         const u64 c0 = (u64)cell_of(lo), cells = (u64)cell_of(hi) - c0;
-        note(hipEventRecord(g->ev_band[(size_t)r], e->stream), "hipEventRecord");
-        note(hipStreamWaitEvent(xs, g->ev_band[(size_t)r], 0), "hipStreamWaitEvent");
-        if (g->fault_rank == r && g->fault_band == (int)b && g->fault_ms > 0) {  // test-only: this engine is late
-            if (g->fault_kind == 1) std::this_thread::sleep_for(std::chrono::milliseconds(g->fault_ms));
-            else FSK_LAUNCH(fsk::k_spin_ms, dim3(1), dim3(64), 0, xs, (u64)g->fault_ms);
+        note(hipEventRecord(g->ev_cb[(size_t)r][b], e->stream), "hipEventRecord");
+        note(hipStreamWaitEvent(xs, g->ev_cb[(size_t)r][b], 0), "hipStreamWaitEvent");
+#ifdef FSK_TEST_HOOKS
+        {   // test builds only: this engine is late
+            const fsk_tuning& t = g->member[0]->tune;
+            if (t.fault_rank == r && t.fault_band == (int64_t)b && t.fault_ms > 0) {
+                if (t.fault_kind == 1) std::this_thread::sleep_for(std::chrono::milliseconds(t.fault_ms));
+                else if (t.fault_kind == 2) FSK_LAUNCH(fsk::k_spin_ms, dim3(1), dim3(64), 0, xs, (u64)t.fault_ms);
+            }
         }
+#endif
         std::string cerr;
         int crc;
         if (narrow) {
@@ -522,7 +578,7 @@ int member_accumulate(fsk_group* g, int r, const std::vector<int32_t>& mine, con
             g->poison(e->err);  // the other engines may already have enqueued their half: release them
         }
         note(hipGetLastError(), "exchange kernels");
-        if (b < g->ev_xb[(size_t)r].size()) note(hipEventRecord(g->ev_xb[(size_t)r][b], xs), "hipEventRecord");
+        note(hipEventRecord(g->ev_xb[(size_t)r][b], xs), "hipEventRecord");
         if (g->poisoned.load()) return rc ? rc : g->poisoned_rc(e);
     }
     // the engine's next work (finalize, getters, another accumulate) starts after the reduced cells are in place
@@ -538,8 +594,22 @@ int member_await_exchange(fsk_group* g, int r) {
     fsk_engine* e = g->member[(size_t)r];
     if (g->deadline_ms <= 0 || g->bands_in_flight <= 0) return FSK_OK;
     FSK_ON_DEVICE(e);
-    const auto t0 = std::chrono::steady_clock::now();
     for (int b = 0; b < g->bands_in_flight && b < (int)g->ev_xb[(size_t)r].size(); ++b) {
+        // The deadline bounds a band's EXCHANGE, so its clock starts when the band's own kernels have run (the accumulate is
+        // asynchronous: a long one — many combos, the sparse dataflow at large g — is not a peer that does not answer).
+        for (;;) {
+            const hipError_t q = hipEventQuery(g->ev_cb[(size_t)r][(size_t)b]);
+            if (q == hipSuccess) break;
+            (void)hipGetLastError();
+            if (q != hipErrorNotReady) {
+                const int code = e->fail(FSK_EDEVICE, "the kernels of band %d failed on device %d: %s", b, e->cfg.device, hipGetErrorString(q));
+                g->poison(e->err);
+                return code;
+            }
+            if (g->poisoned.load()) return g->poisoned_rc(e);
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
             const hipError_t q = hipEventQuery(g->ev_xb[(size_t)r][(size_t)b]);
             if (q == hipSuccess) break;
@@ -599,7 +669,8 @@ int group_sum_combos(fsk_engine* lead, const int32_t* combos, int32_t n) {
             if (g->stage[(size_t)r].reserve((size_t)largest) != hipSuccess)
                 rc1 = e->fail(FSK_ENOMEM, "cannot allocate %llu bytes of exchange staging", (unsigned long long)(largest * 4));
         }
-        if (!g->agree(rc1)) {
+        if (!g->agree(rc1, g->deadline_ms)) {
+            if (g->poisoned.load()) return rc1 ? rc1 : g->poisoned_rc(e);
             if (g->bar.broken) {
                 const int code = e->fail(FSK_EDEVICE, "engine %d waited more than %d ms for the other engines before the accumulate", r, g->deadline_ms);
                 g->poison(e->err);
@@ -687,6 +758,22 @@ int group_set_skip_test_block(fsk_engine* lead, int32_t skip) {
     return FSK_OK;
 }
 
+int group_set_tuning(fsk_engine* lead, const char* key, int64_t value, std::string& err) {
+    for (fsk_engine* e : lead->group->member) {
+        const int rc = tuning_set(e->tune, key, value, err);
+        if (rc) return rc;
+    }
+    return FSK_OK;
+}
+
+void group_set_profile(fsk_engine* lead, int profile) {
+    for (fsk_engine* e : lead->group->member) {
+        DeviceScope on(e->cfg.device);
+        e->harvest_times();
+        e->cfg.profile = profile;
+    }
+}
+
 int group_get_stats(fsk_engine* lead, fsk_stats* out) {
     fsk_group* g = lead->group;
     int rc = one_get_stats(lead, out);
@@ -734,10 +821,15 @@ int group_compute(fsk_engine* lead, const int32_t* tokens, const int64_t* offset
         FSK_ON_DEVICE(e);
         e->finalized = false;
         int rc1 = run_variance_mode(e, T, r, R);
-        // (no deadline on this barrier: the chains of one engine may legitimately run much longer than another's)
-        const int keep = g->deadline_ms;
-        (void)keep;
-        if (!g->agree(rc1)) return rc1 ? rc1 : e->fail(FSK_EDEVICE, "another engine of the group failed");
+#ifdef FSK_TEST_HOOKS
+        {   // test builds only (fault_kind 3): this engine's chains take fault_ms longer than the others'
+            const fsk_tuning& t = g->member[0]->tune;
+            if (t.fault_kind == 3 && t.fault_rank == r && t.fault_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(t.fault_ms));
+        }
+#endif
+        // (no deadline on this barrier: the chains of one engine may legitimately run much longer than another's; a failure
+        // elsewhere still releases it, see fsk_group::poison)
+        if (!g->agree(rc1, 0)) return rc1 ? rc1 : g->poisoned.load() ? g->poisoned_rc(e) : e->fail(FSK_EDEVICE, "another engine of the group failed");
         std::string cerr;
         rc1 = g->coll->all_reduce(r, e->d_Kf64.p, (size_t)e->pairs, XType::F64, e->stream, cerr);
         if (rc1) {
@@ -769,8 +861,8 @@ void group_destroy(fsk_engine* lead) {
     for (int r = 0; r < g->R(); ++r) {
         DeviceScope on(g->device[(size_t)r]);
         g->stage[(size_t)r].release();
-        if (g->ev_band[(size_t)r]) (void)hipEventDestroy(g->ev_band[(size_t)r]);
         if (g->ev_xdone[(size_t)r]) (void)hipEventDestroy(g->ev_xdone[(size_t)r]);
+        for (hipEvent_t ev : g->ev_cb[(size_t)r]) if (ev) (void)hipEventDestroy(ev);
         for (hipEvent_t ev : g->ev_xb[(size_t)r]) if (ev) (void)hipEventDestroy(ev);
         if (g->xstream[(size_t)r]) (void)hipStreamDestroy(g->xstream[(size_t)r]);
     }
@@ -788,10 +880,6 @@ int fsk_create_multi(const fsk_config* cfg, const int32_t* devices, int32_t ndev
     *out = nullptr;
     if (ndev < 1 || ndev > 16) { set_create_error("need 1..16 devices"); return FSK_EINVAL; }
     int collective = cfg->collective;
-    if (const char* f = getenv("FSK_MULTI_COLLECTIVE")) {
-        if (!strcmp(f, "p2p")) collective = FSK_COLL_P2P;
-        else if (!strcmp(f, "rccl")) collective = FSK_COLL_RCCL;
-    }
     if (collective != FSK_COLL_AUTO && collective != FSK_COLL_RCCL && collective != FSK_COLL_P2P) {
         set_create_error("collective must be FSK_COLL_AUTO, FSK_COLL_RCCL or FSK_COLL_P2P");
         return FSK_EINVAL;
@@ -799,17 +887,14 @@ int fsk_create_multi(const fsk_config* cfg, const int32_t* devices, int32_t ndev
     bool distinct = true;
     for (int a = 0; a < ndev; ++a)
         for (int b = a + 1; b < ndev; ++b) distinct = distinct && devices[a] != devices[b];
-    if (!distinct && collective == FSK_COLL_RCCL) {
-        set_create_error("RCCL needs distinct devices (a device listed twice runs over FSK_COLL_P2P)");
-        return FSK_EINVAL;
-    }
     std::unique_ptr<fsk_group> g(new fsk_group);
     auto undo = [&](int rc, const std::string& msg) {
         g->coll.reset();
         for (size_t r = 0; r < g->member.size(); ++r) {
             DeviceScope on(g->device[r]);
-            if (r < g->ev_band.size() && g->ev_band[r]) (void)hipEventDestroy(g->ev_band[r]);
             if (r < g->ev_xdone.size() && g->ev_xdone[r]) (void)hipEventDestroy(g->ev_xdone[r]);
+            if (r < g->ev_cb.size())
+                for (hipEvent_t ev : g->ev_cb[r]) if (ev) (void)hipEventDestroy(ev);
             if (r < g->ev_xb.size())
                 for (hipEvent_t ev : g->ev_xb[r]) if (ev) (void)hipEventDestroy(ev);
             if (r < g->xstream.size() && g->xstream[r]) (void)hipStreamDestroy(g->xstream[r]);
@@ -828,47 +913,42 @@ int fsk_create_multi(const fsk_config* cfg, const int32_t* devices, int32_t ndev
         g->device.push_back(devices[r]);
     }
     g->xstream.assign((size_t)ndev, nullptr);
-    g->ev_band.assign((size_t)ndev, nullptr);
     g->ev_xdone.assign((size_t)ndev, nullptr);
+    g->ev_cb.assign((size_t)ndev, std::vector<hipEvent_t>(MAX_BANDS, nullptr));
     g->ev_xb.assign((size_t)ndev, std::vector<hipEvent_t>(MAX_BANDS, nullptr));
     g->stage.resize((size_t)ndev);
     for (int r = 0; r < ndev; ++r) {
         DeviceScope on(devices[r]);
         if (on.err != hipSuccess || hipStreamCreateWithFlags(&g->xstream[(size_t)r], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&g->ev_band[(size_t)r], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&g->ev_xdone[(size_t)r], hipEventDisableTiming) != hipSuccess)
             return undo(FSK_EDEVICE, "cannot create the exchange stream / events on device " + std::to_string(devices[r]));
-        for (hipEvent_t& ev : g->ev_xb[(size_t)r])
-            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
-                return undo(FSK_EDEVICE, "cannot create the band events on device " + std::to_string(devices[r]));
+        for (auto* evs : {&g->ev_cb[(size_t)r], &g->ev_xb[(size_t)r]})
+            for (hipEvent_t& ev : *evs)
+                if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+                    return undo(FSK_EDEVICE, "cannot create the band events on device " + std::to_string(devices[r]));
     }
-    // fail fast: fsk_config.deadline_ms, else FSK_DEADLINE_MS, else two minutes (negative: no deadline)
-    g->deadline_ms = cfg->deadline_ms;
-    if (g->deadline_ms == 0) {
-        const char* f = getenv("FSK_DEADLINE_MS");
-        g->deadline_ms = f ? atoi(f) : 120000;
-    }
+    // what fsk_config leaves open comes from engine 0's tuning (FSK_TUNING at its fsk_create): the collective, and the
+    // fail-fast bound — fsk_config.deadline_ms, else the tuning's (two minutes by default); negative: no deadline
+    const fsk_tuning& tune = g->member[0]->tune;
+    if (collective == FSK_COLL_AUTO) collective = (int)tune.collective;
+    if (!distinct && collective == FSK_COLL_RCCL)
+        return undo(FSK_EINVAL, "RCCL needs distinct devices (a device listed twice runs over FSK_COLL_P2P)");
+    g->deadline_ms = cfg->deadline_ms != 0 ? cfg->deadline_ms : (int)tune.deadline_ms;
     if (g->deadline_ms < 0) g->deadline_ms = 0;
-    if (const char* f = getenv("FSK_FAULT")) {  // test-only: "host:rank:band:ms" or "device:rank:band:ms"
-        char kind[16] = {0};
-        int fr = -1, fb = -1, fm = 0;
-        if (sscanf(f, "%15[a-z]:%d:%d:%d", kind, &fr, &fb, &fm) == 4 && fm > 0 && fm <= 60000) {
-            g->fault_kind = !strcmp(kind, "host") ? 1 : !strcmp(kind, "device") ? 2 : 0;
-            if (g->fault_kind) { g->fault_rank = fr; g->fault_band = fb; g->fault_ms = fm; }
-        }
-    }
     const std::vector<int> devs(devices, devices + ndev);
     std::string why;
-#ifndef FSK_EMU
-    if (collective != FSK_COLL_P2P && distinct) {
+#ifdef FSK_EMU
+    const bool try_rccl = collective == FSK_COLL_RCCL;  // (the test build's stand-in is taken only when asked for by name)
+#else
+    const bool try_rccl = collective != FSK_COLL_P2P && distinct;
+#endif
+    if (try_rccl) {
         std::unique_ptr<RcclCollective> rc(new RcclCollective);
         const int code = rc->init(devs, g->deadline_ms, why);
         if (code == FSK_OK) g->coll = std::move(rc);
-        else if (collective == FSK_COLL_RCCL) return undo(code, why);
+        // (an init that timed out may still be running on these devices: no second collective beside it)
+        else if (collective == FSK_COLL_RCCL || rc->init_timed_out) return undo(code, why);
     }
-#else
-    if (collective == FSK_COLL_RCCL) return undo(FSK_EUNSUPPORTED, "no RCCL in this build");
-#endif
     if (!g->coll) {
         std::unique_ptr<P2PCollective> p(new P2PCollective);
         const int code = p->init(devs, why);

@@ -28,8 +28,10 @@
 extern "C" {
 #endif
 
-#define FSK_ABI_VERSION 3  /* 2: fsk_create_multi + fsk_config.collective/bands, fsk_counts_digest, device-block allocation;
-                              3: fsk_get_triangle_device / fsk_alloc_triangle_device, fsk_config.deadline_ms */
+#define FSK_ABI_VERSION 4  /* 2: fsk_create_multi + fsk_config.collective/bands, fsk_counts_digest, device-block allocation;
+                              3: fsk_get_triangle_device / fsk_alloc_triangle_device, fsk_config.deadline_ms;
+                              4: fsk_set_tuning / fsk_get_tuning / fsk_tuning_keys (one FSK_TUNING variable instead of
+                                 two dozen FSK_* switches) */
 
 enum {
     FSK_OK = 0,
@@ -38,7 +40,7 @@ enum {
     FSK_ESTATE = -3,   /* call out of order (e.g. getter before compute)                          */
     FSK_EDEVICE = -4,  /* HIP runtime error / no device                                           */
     FSK_ENOMEM = -5,   /* device or host allocation failed                                        */
-    FSK_EUNSUPPORTED = -6 /* alphabet > 256 symbols or (g-m)*log2(alphabet) > 62 bits            */
+    FSK_EUNSUPPORTED = -6 /* alphabet > 65536 symbols, (g-m) * ceil(log2(alphabet)) > 96 bits, g > 255 ...   */
 };
 
 /* accumulate dataflow */
@@ -78,7 +80,10 @@ typedef struct fsk_config {
     int32_t skip_variance; /* approx: integer sums, no Welford chain                            */
     int32_t device;        /* HIP device ordinal                                                */
     int32_t path;          /* FSK_PATH_*                                                        */
-    int32_t profile;       /* 1: time every kernel family with HIP events (fsk_get_stats)       */
+    int32_t profile;       /* 1: measurement mode — every kernel family timed with HIP events that are waited for on
+                              the spot, the exact update count U computed (fsk_get_stats); the sparse dataflow on
+                              one stream, every batch sized exactly. 2: the product dataflow untouched — the events
+                              are only recorded (on the stream the kernels run on), fsk_get_stats harvests them */
     int32_t skip_test_block; /* 1: cells with both sequences in the test set (other than the diagonal)
                                 may be left at zero — no getter of the reference exposes them
                                 (fastsk.cpp:190-217). Dense dataflow: whole tiles of such cells
@@ -91,8 +96,8 @@ typedef struct fsk_config {
                               ncclCommInitAll, the engines' barriers, a band's all-reduce having run on the device.
                               A wait that exceeds it returns FSK_EDEVICE naming the stage and the band, the
                               communicator is aborted (ncclCommAbort) and the group is dead: every later call
-                              returns FSK_EDEVICE with that first message. 0 = FSK_DEADLINE_MS from the
-                              environment, else 120000; negative = no deadline                                */
+                              returns FSK_EDEVICE with that first message. 0 = the tuning key deadline_ms
+                              (120000 unless set); negative = no deadline                                     */
     int32_t reserved[1];
 } fsk_config;
 
@@ -160,6 +165,16 @@ typedef struct fsk_multi_info {
     double reserved[4];
 } fsk_multi_info;
 int fsk_get_multi_info(fsk_engine* e, fsk_multi_info* out);
+/* Tuning: every knob of the engine that is not a constructor argument of the reference — forcing one of two
+ * equivalent code paths (tests), sizes of batches and launches (A/B measurements) — is a named integer key.
+ * fsk_tuning_keys() lists them, one "key=default [lowest..highest] what it does" per line. A key is set per handle
+ * with fsk_set_tuning (a group: on all its engines; takes effect from the next fsk_load_sequences / fsk_compute on),
+ * or for every engine a process creates through ONE environment variable, FSK_TUNING="key=value,key=value", parsed
+ * once by fsk_create — the only variable the library reads; an unknown key or a value out of range fails the call
+ * (FSK_EINVAL). No key changes a result. trace=1 prints the keys in force (stderr). */
+int fsk_set_tuning(fsk_engine* e, const char* key, int64_t value);
+int fsk_get_tuning(fsk_engine* e, const char* key, int64_t* value);
+const char* fsk_tuning_keys(void);
 /* message of the last failure on `e` (or of the last failed fsk_create when e == NULL) */
 const char* fsk_last_error(const fsk_engine* e);
 int fsk_abi_version(void);

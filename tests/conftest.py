@@ -15,7 +15,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def golden_names(prefixes=("f1", "f2", "f3", "f4", "f5", "f6")):
+def set_tuning_env(monkeypatch, **keys):
+    """FSK_TUNING for the engines created from here on (fsk_create parses it once; the pybind11 class and the ctypes view
+    both go through it): merges `keys` into what is already set; a value of None removes a key."""
+    cur = dict(kv.split("=") for kv in os.environ.get("FSK_TUNING", "").split(",") if kv)
+    for k, v in keys.items():
+        if v is None:
+            cur.pop(k, None)
+        else:
+            cur[k] = str(v)
+    if cur:
+        monkeypatch.setenv("FSK_TUNING", ",".join("%s=%s" % kv for kv in cur.items()))
+    else:
+        monkeypatch.delenv("FSK_TUNING", raising=False)
+
+
+def golden_names(prefixes=("f1", "f2", "f3", "f4", "f5", "f6", "f8")):
     out = []
     for p in sorted(glob.glob(os.path.join(GOLD, "*.npz"))):
         n = os.path.basename(p)[:-4]

@@ -12,14 +12,16 @@ OUT = os.path.join(HERE, "libfastsk_emu.so")
 
 
 def _current():
-    deps = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")] + [os.path.join(ROOT, "include", "fastsk_amd.h")]
+    deps = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".h", ".cpp"))] + [os.path.join(ROOT, "include", "fastsk_amd.h")]
     deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc", ".cpp")) and f != "bindings.cpp"]
     return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps)
 
 
 def units():
-    """The translation units of libfastsk_amd.so (everything but the pybind11 module)."""
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip")) + [os.path.join(CSRC, "fsk_fasta.cpp")]
+    """The translation units of libfastsk_amd.so (everything but the pybind11 module) — and, in this library ONLY, the stand-in
+    for librccl that the emulated build's RCCL collective is bound to (rccl_stub.cpp)."""
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip")) + [os.path.join(CSRC, "fsk_fasta.cpp"),
+                                                                                               os.path.join(HERE, "rccl_stub.cpp")]
 
 
 def build(force=False):
@@ -39,7 +41,7 @@ def build(force=False):
         def compile_unit(src):
             obj = "%s.%s.o" % (tmp, os.path.splitext(os.path.basename(src))[0])
             objs.append(obj)
-            cmd = ["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-pthread", "-DFSK_EMU", "-ffp-contract=off", "-Wall",
+            cmd = ["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-pthread", "-DFSK_EMU", "-DFSK_TEST_HOOKS", "-ffp-contract=off", "-Wall",
                    "-Wno-unused-function", "-Wno-unknown-pragmas", "-I", HERE, "-x", "c++", "-c", src, "-o", obj]
             return subprocess.run(cmd, capture_output=True, text=True)
         try:

@@ -247,6 +247,7 @@ template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + 
 static inline unsigned atomicAdd(unsigned* p, int v) { unsigned o = *p; *p = o + (unsigned)v; return o; }
 template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <typename T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <typename T> static inline T atomicXor(T* p, T v) { T o = *p; *p = o ^ v; return o; }
 
 static inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool) {
@@ -337,6 +338,13 @@ static inline unsigned long long wave_sum_u64(unsigned long long x) {
 static inline unsigned long long wave_incl_sum_u64(unsigned long long x) {
     for (int d = 1; d < 64; d <<= 1) {
         const unsigned long long y = __shfl_up(x, d);
+        if ((int)emu::lane_id() >= d) x += y;
+    }
+    return x;
+}
+static inline unsigned wave_incl_sum_u32(unsigned x) {
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned y = __shfl_up(x, d);
         if ((int)emu::lane_id() >= d) x += y;
     }
     return x;

@@ -163,6 +163,21 @@ def slice_cases():
     make_case("f6_ep47848_slice_exact", Xtr[:40], Xte[:24], 10, 6, t=4)
 
 
+def wide_cases():
+    """F8: inputs beyond the packed fast paths — more than 256 distinct tokens (cntsrtna's radix is the dictionary size,
+    shared.cpp:156-191) and a k-mer space beyond 2^62 (protein, g=20 m=4: 24^16)."""
+    rng = np.random.default_rng(8)
+    X = [rng.integers(1, 301, size=int(n)).tolist() for n in rng.integers(30, 61, size=80)]
+    for x in X[:40]:                      # shared motifs, so that the kernel is not all zeros off the diagonal
+        a = int(rng.integers(0, len(x) - 12))
+        x[a:a + 12] = X[0][5:17]
+    make_case("f8_sigma300_g5m2", X[:50], X[50:], 5, 2, t=2)
+    Xtr, _, Xte, _ = read_pair("1.1")
+    Xtr = [x for x in Xtr if len(x) >= 20][:40]
+    Xte = [x for x in Xte if len(x) >= 20][:20]
+    make_case("f8_prot11_g20m4_skipvar12", Xtr, Xte, 20, 4, t=1, approx=True, max_iters=12, skip_variance=True)
+
+
 def token_fixtures():
     """Token arrays of the four FASTA configs, as produced by the reference's Python reader."""
     for name in ["EP300", "EP300_47848", "1.1", "2.19", "small"]:
@@ -230,11 +245,16 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--only-full", action="store_true")
+    ap.add_argument("--only-wide", action="store_true")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
+    if args.only_wide:
+        wide_cases()
+        sys.exit(0)
     if not args.only_full:
         token_fixtures()
         small_cases()
         slice_cases()
+        wide_cases()
     if args.full or args.only_full:
         full_cases()

@@ -30,7 +30,39 @@ def test_every_declared_symbol_is_exported(product_lib):
     assert sorted(_native.SYMBOLS) == names, "ctypes view and header disagree"
     for n in names:
         assert hasattr(product_lib.L, n), n
-    assert product_lib.L.fsk_abi_version() == _native.ABI_VERSION == 3
+    assert product_lib.L.fsk_abi_version() == _native.ABI_VERSION == 4
+
+
+def test_tuning_keys_and_no_ambient_switches(product_lib):
+    """One tuning table (fsk_tuning_keys), ONE environment variable (FSK_TUNING, parsed by fsk_create): the engine's
+    sources read nothing else from the environment; the test-only keys do not exist in the product library."""
+    keys = product_lib.tuning_keys()
+    assert {"trace", "compact", "sparse_global", "sparse_unpacked", "guard_cap", "deadline_ms", "collective"} <= set(keys)
+    assert keys["deadline_ms"][0] == 120000 and keys["sparse_global"][:3] == (0, 0, 1)
+    assert not any(k.startswith("fault_") for k in keys), "test hooks in the product library"
+    csrc = os.path.join(ROOT, "fastsk_amd", "csrc")
+    reads = []
+    for f in sorted(os.listdir(csrc)):
+        for n, line in enumerate(open(os.path.join(csrc, f), errors="replace"), 1):
+            if re.search(r"\bgetenv\s*\(", line):
+                reads.append((f, n, line.strip()))
+    assert len(reads) == 1 and "FSK_TUNING" in reads[0][2], reads
+
+
+def test_product_library_holds_no_test_infrastructure(product_lib):
+    """The stand-in for librccl of the CPU test build (tests/emu/rccl_stub.cpp) and the fault hooks (-DFSK_TEST_HOOKS) are
+    in tests/ only: the product library neither defines nor needs their symbols, and the package never names tests/."""
+    import subprocess
+    syms = subprocess.run(["nm", "-D", product_lib.path], capture_output=True, text=True, check=True).stdout
+    for name in ("emu_rccl_set_fault", "emu_rccl_stats", "ncclAllReduce", "ncclCommInitAll", "ncclCommAbort"):
+        assert not re.search(r"\b%s\b" % name, syms), name      # (RCCL itself is bound with dlopen: not even an undefined reference)
+    blob = open(product_lib.path, "rb").read()
+    assert b"fault_kind" not in blob and b"rccl_stub" not in blob
+    pkg = os.path.join(ROOT, "fastsk_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            text = open(os.path.join(pkg, f)).read()
+            assert "tests/emu" not in text and "libfastsk_emu" not in text and "rccl_stub" not in text and "hooks" not in text, f
 
 
 def test_host_helpers_without_gpu(product_lib):

@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import golden_names, load_golden, tri_to_square, ROOT
+from conftest import golden_names, load_golden, tri_to_square, set_tuning_env, ROOT
 
 sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
 
@@ -124,8 +124,9 @@ def test_emu_variance_mode_stops_anywhere(emu_lib, port, path, monkeypatch):
     the dense dataflow, where every iteration's tile launch stores into a triangle of its own; path -1 =
     the dense dataflow with that switched off: zero fill and one Welford kernel per iteration.)"""
     from fastsk_amd import _native
+    slots_off = path == -1
     if path == -1:
-        monkeypatch.setenv("FSK_VARIANCE_DENSE_SLOTS", "0")
+        set_tuning_env(monkeypatch, variance_dense_slots="0")
         path = 1
     elif path == 0:
         path = 1
@@ -135,7 +136,7 @@ def test_emu_variance_mode_stops_anywhere(emu_lib, port, path, monkeypatch):
     g, m = 7, 3
     order = rng.permutation(port.num_combos(g, m)).astype(np.int32)
     lengths = set()
-    full = path == 1 and os.environ.get("FSK_VARIANCE_DENSE_SLOTS") != "0"
+    full = path == 1 and not slots_off
     for T in (1, 2, 3) if full else (1, 2):
         for max_iters in (-1, 1, 2, 4, 5, 6, 9) if full else (-1, 3, 6):
             for delta in (0.025, 0.2, 0.5, 1.0, 3.0) if full else (0.2, 0.5, 1.0, 3.0):
@@ -167,13 +168,13 @@ def test_emu_variance_mode_count_above_255(emu_lib, port, form, monkeypatch):
     general dataflow, which adds — into a triangle that must have been zeroed first."""
     from fastsk_amd import _native
     if form == "dense_fill":
-        monkeypatch.setenv("FSK_VARIANCE_DENSE_SLOTS", "0")
+        set_tuning_env(monkeypatch, variance_dense_slots="0")
     tok, off = _native.flatten(poly_a_sequences())
     g, m, T = 5, 2, 2
     order = np.random.default_rng(3).permutation(port.num_combos(g, m)).astype(np.int32)
     want, sd, _ = port.compute(tok, off, 16, 8, g, m, t=T, approx=True, delta=0.025, max_iters=-1, order=order)
     if form == "sparse_u32":
-        monkeypatch.setenv("FSK_VAR_SLOTS16", "0")
+        set_tuning_env(monkeypatch, var_slots16="0")
     e = _native.Engine(g, m, t=T, approx=True, path=2 if form.startswith("sparse") else 1, lib=emu_lib)
     e.set_combo_order(order)
     e.compute(tok, off, 16, 8)
@@ -204,7 +205,7 @@ def test_emu_reset_then_storing_launch(emu_lib, port, monkeypatch):
     wb, _, _ = port.raw_counts(tokens, offsets, 8, 4, cb, threads=4)
     cell = lambda r: r * (r + 1) // 2
     for splits in ("1", "0"):   # "1": one workgroup per tile -> the storing launch; "0": automatic splits -> zero fill + atomics
-        monkeypatch.setenv("FSK_TILE_SPLITS", splits)
+        set_tuning_env(monkeypatch, tile_splits=splits)
         e = _native.Engine(8, 4, path=1, lib=emu_lib)
         e.load_sequences(tokens, offsets, N, 0)
         e.accumulate(ca)                        # K now holds data that every reset below must erase
@@ -495,7 +496,7 @@ def test_emu_row_bands(emu_lib, port, path):
 def test_emu_dense_count_chunked_staging(emu_lib, port, monkeypatch, chunk):
     """Sequences too long for one LDS staging pass are counted chunk by chunk (forced small here)."""
     from fastsk_amd import _native
-    monkeypatch.setenv("FSK_DENSE_CHUNK", chunk)
+    set_tuning_env(monkeypatch, dense_chunk=chunk)
     rng = np.random.default_rng(12)
     X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(9, 200, size=70)]
     tok, off = _native.flatten(X)
@@ -529,10 +530,10 @@ def test_emu_dense_large_key_space_sweeps(emu_lib, port, sigma, g, m):
 
 
 def test_emu_extract_four_slots_per_workgroup(emu_lib, port, monkeypatch):
-    """Large sparse launches take a tile of windows through four slots per workgroup (FSK_EXTRACT_SLOTS forces it
+    """Large sparse launches take a tile of windows through four slots per workgroup (tuning extract_slots forces it
     here); a batch whose slot count is not a multiple of four leaves the last workgroup row short."""
     from fastsk_amd import _native
-    monkeypatch.setenv("FSK_EXTRACT_SLOTS", "4")
+    set_tuning_env(monkeypatch, extract_slots="4")
     for name in ("f5_prot11_exact", "f3_ragged_sigma7_g6m3"):
         d = load_golden(name)
         nc = port.num_combos(d["g"], d["m"])
@@ -552,7 +553,7 @@ def test_emu_sparse_pair_accumulation_variants(emu_lib, port, monkeypatch, globa
     """Sparse dataflow: owner-slice LDS accumulation (default when a row band of K fits in LDS)
     and direct per-pair global atomics (large N) issue the same updates."""
     from fastsk_amd import _native
-    monkeypatch.setenv("FSK_SPARSE_GLOBAL", global_pairs)
+    set_tuning_env(monkeypatch, sparse_global=global_pairs)
     d = load_golden("f5_prot11_exact")
     combos = np.arange(0, 210, 30, dtype=np.int32)
     want, _, U = port.raw_counts(d["tokens"], d["offsets"], d["g"], d["m"], combos)
@@ -589,7 +590,7 @@ def test_emu_segment_scan_in_chunks(emu_lib, port, monkeypatch):
     one workgroup, or — batches of many tiles — as chunk totals, a scan over the chunks and the chunks
     with their carries; forced here on a small batch, with and without skip_test_block."""
     from fastsk_amd import _native
-    monkeypatch.setenv("FSK_SEG_SCAN_CHUNKED", "1")
+    set_tuning_env(monkeypatch, seg_scan_chunked="1")
     d = load_golden("f5_prot11_exact")
     combos = np.arange(0, 210, 40, dtype=np.int32)
     want, _, U = port.raw_counts(d["tokens"], d["offsets"], d["g"], d["m"], combos)
@@ -611,10 +612,10 @@ def test_emu_segment_scan_in_chunks(emu_lib, port, monkeypatch):
 def test_emu_sparse_batches_enqueued_ahead_of_their_size(emu_lib, port, monkeypatch, cap):
     """Sparse dataflow: after the first batch of a set of sequences, batches are enqueued without
     waiting for their update-word count; one that does not fit the stream buffer leaves K alone and
-    is redone sized exactly (FSK_SPARSE_GUARD_CAP makes every such batch overflow)."""
+    is redone sized exactly (tuning guard_cap makes every such batch overflow)."""
     from fastsk_amd import _native
     if cap:
-        monkeypatch.setenv("FSK_SPARSE_GUARD_CAP", cap)
+        set_tuning_env(monkeypatch, guard_cap=cap)
     d = load_golden("f5_prot11_exact")
     combos = np.arange(0, 210, 15, dtype=np.int32)
     want, _, U = port.raw_counts(d["tokens"], d["offsets"], d["g"], d["m"], combos)
@@ -630,16 +631,15 @@ def test_emu_sparse_batches_enqueued_ahead_of_their_size(emu_lib, port, monkeypa
     e.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"FSK_SPARSE_EXACT_LANES": "2"}, {"FSK_SPARSE_EXACT_LANES": "1"}, {"FSK_SPARSE_GUARD_CAP": "100"}])
+@pytest.mark.parametrize("env", [{}, {"sparse_exact_lanes": "2"}, {"sparse_exact_lanes": "1"}, {"guard_cap": "100"}])
 def test_emu_sparse_exact_accumulate_in_two_lanes(emu_lib, port, monkeypatch, env):
     """Sparse dataflow: the batches of ONE exact accumulate alternate between two lanes (scratch + stream), their consume
     passes ordered by events; the same counts and U as on one stream, also when every guarded batch is redone."""
     from fastsk_amd import _native
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    set_tuning_env(monkeypatch, **env)
     d = load_golden("f5_prot11_exact")
     nfeat = int(sum(max(0, int(b) - int(a) - d["g"] + 1) for a, b in zip(d["offsets"][:-1], d["offsets"][1:])))
-    monkeypatch.setenv("FSK_SPARSE_BATCH_RECORDS", str(3 * nfeat))  # (three combos a batch)
+    set_tuning_env(monkeypatch, sparse_batch_records=str(3 * nfeat))  # (three combos a batch)
     combos = np.arange(0, 210, 9, dtype=np.int32)
     want, _, U = port.raw_counts(d["tokens"], d["offsets"], d["g"], d["m"], combos)
     e = _native.Engine(d["g"], d["m"], path=2, lib=emu_lib)
@@ -652,7 +652,7 @@ def test_emu_sparse_exact_accumulate_in_two_lanes(emu_lib, port, monkeypatch, en
     st = e.stats()
     assert st["cell_updates"] == U and st["combos_done"] == combos.size
     assert st["launches"] - first > 9 * 15
-    if "FSK_SPARSE_GUARD_CAP" in env:
+    if "guard_cap" in env:
         assert st["batches_redone"] >= 7
     e.close()
 
@@ -664,7 +664,7 @@ def test_emu_sparse_words_per_record_hint_across_loads(emu_lib, port, monkeypatc
     that is far too low (low-complexity sequences after random ones) only costs a redone batch."""
     from fastsk_amd import _native
     if hint is not None:
-        monkeypatch.setenv("FSK_SPARSE_HINT", hint)
+        set_tuning_env(monkeypatch, sparse_hint=hint)
     rng = np.random.default_rng(5)
     N, L, g, m = 90, 50, 7, 3
     A = rng.integers(1, 5, size=(N, L), dtype=np.int32)
@@ -700,7 +700,7 @@ def test_emu_sparse_batches_sized_by_words_per_record(emu_lib, port, monkeypatch
     launches = {}
     for limit in (None, max_words):
         if limit:
-            monkeypatch.setenv("FSK_LIST_MAX_WORDS", limit)
+            set_tuning_env(monkeypatch, list_max_words=limit)
         e = _native.Engine(d["g"], d["m"], path=2, lib=emu_lib)
         e.load_sequences(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
         for part in np.array_split(combos, 3):
@@ -714,23 +714,22 @@ def test_emu_sparse_batches_sized_by_words_per_record(emu_lib, port, monkeypatch
     assert launches[max_words] > launches[None]
 
 
-@pytest.mark.parametrize("env", [{"FSK_SPARSE_GLOBAL": "1"}, {"FSK_LIST_MAX_WORDS": "2000"}, {}, {"FSK_SPARSE_SYNC": "1"},
-                                 {"FSK_SPARSE_GUARD_CAP": "100"}])
+@pytest.mark.parametrize("env", [{"sparse_global": "1"}, {"list_max_words": "2000"}, {}, {"sparse_sync": "1"},
+                                 {"guard_cap": "100"}])
 def test_emu_variance_mode_sparse_fallbacks(emu_lib, monkeypatch, env):
     """Variance mode on the sparse dataflow: the iterations of a batch share one sparse pass (a u32
     triangle per slot), unless no update streams exist (atomics) or a batch has too many update words
     for one stream (then: one iteration at a time) — all forms give the reference's stdevs; so do
-    batches sized exactly (FSK_SPARSE_SYNC) and batches that overflow their guard and are redone."""
+    batches sized exactly (tuning sparse_sync) and batches that overflow their guard and are redone."""
     from fastsk_amd import _native
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    set_tuning_env(monkeypatch, **env)
     d = load_golden("f5_prot11_variance_T1_it9")
     e = _native.Engine(d["g"], d["m"], t=d["t"], approx=True, delta=d["delta"], max_iters=d["max_iters"], path=2, lib=emu_lib)
     e.set_combo_order(d["order"])
     e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
     assert np.array_equal(e.get_stdevs(), d["stdevs"])
     assert np.array_equal(e.get_triangle(), d["tri"])
-    if "FSK_SPARSE_GUARD_CAP" in env:
+    if "guard_cap" in env:
         assert e.stats()["batches_redone"] > 0
     e.close()
 
@@ -740,12 +739,12 @@ def test_emu_variance_mode_sparse_fallbacks(emu_lib, monkeypatch, env):
 def test_emu_key_compaction_rare_symbol(emu_lib, port, monkeypatch, g, m, force, rare):
     """DNA with a few 'n': the 5^k key space is mostly empty; the dense dataflow counts only the
     keys that occur (per-combo rank table) and must still match the oracle bit for bit — with the keys found by
-    a marking pass over every window (FSK_COMPACT_RARE=0) and from the places of the rare symbol alone (=1)."""
+    a marking pass over every window (tuning compact_rare=0) and from the places of the rare symbol alone (=1)."""
     from fastsk_amd import _native
     if force is not None:
-        monkeypatch.setenv("FSK_COMPACT", force)
+        set_tuning_env(monkeypatch, compact=force)
     if rare is not None:
-        monkeypatch.setenv("FSK_COMPACT_RARE", rare)
+        set_tuning_env(monkeypatch, compact_rare=rare)
     rng = np.random.default_rng(g * 7 + m)
     X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(g, 80, size=150)]
     for i in (3, 70, 149):
@@ -806,3 +805,127 @@ def test_emu_many_flagged_rows_in_one_stage(emu_lib, port):
     e.accumulate(combos)
     e.finalize()
     assert np.array_equal(e.get_counts(), want)
+
+
+# ---- the unpacked entry format of the sparse dataflow (N >= 65,535 sequences or a sequence of >= 65,536 windows): the kernel
+# instantiations k_sx_seg_write<RecT, false> and k_sx_emit<DIRECT | streams, SKIP, false> (countAndUpdateTri, shared.cpp:268-333)
+@pytest.mark.parametrize("global_pairs", ["0", "1"])
+@pytest.mark.parametrize("name", ["f5_prot11_exact", "f3_ragged_sigma7_g6m3", "f3_lowcomplexity_g5m2", "f5_prot11_variance_T1_it9"])
+def test_emu_sparse_unpacked_entries_forced(emu_lib, monkeypatch, name, global_pairs):
+    """tuning sparse_unpacked=1: the general entry format on the golden vectors, through the update streams and as atomics,
+    exact and variance mode."""
+    set_tuning_env(monkeypatch, sparse_unpacked="1", sparse_global=global_pairs)
+    d = load_golden(name)
+    e = run_case(emu_lib, d, 2)
+    assert e.get_tuning("sparse_unpacked") == 1 and e.stats()["path_used"] == 2
+    assert np.array_equal(e.get_triangle(), d["tri"])
+    if "counts" in d:
+        assert np.array_equal(e.get_counts(), d["counts"])
+    if d["approx"] and not d["skip_variance"]:
+        assert np.array_equal(e.get_stdevs(), d["stdevs"])
+    e.close()
+
+
+@pytest.mark.parametrize("global_pairs", ["0", "1"])
+def test_emu_sparse_unpacked_entries_skip_test_block(emu_lib, port, monkeypatch, global_pairs):
+    from fastsk_amd import _native
+    set_tuning_env(monkeypatch, sparse_unpacked="1", sparse_global=global_pairs)
+    rng = np.random.default_rng(4)
+    N, ntr = 300, 100
+    X = rng.integers(1, 5, size=(N, 24), dtype=np.int32)
+    tokens, offsets = X.reshape(-1), np.arange(N + 1, dtype=np.int64) * 24
+    combos = np.arange(0, 35, 2, dtype=np.int32)
+    raw, _, U = port.raw_counts(tokens, offsets, 7, 4, combos, threads=4)
+    a, b = np.tril_indices(N)
+    keep = (b < ntr) | (a == b)
+    e = _native.Engine(7, 4, path=2, lib=emu_lib, skip_test_block=True)
+    e.load_sequences(tokens, offsets, ntr, N - ntr)
+    e.accumulate(combos)
+    e.finalize()
+    got = e.get_counts()
+    assert np.array_equal(got[keep], raw[keep]) and not got[~keep].any() and raw[~keep].any()
+    assert e.stats()["cell_updates"] < U
+    e.close()
+
+
+@pytest.mark.parametrize("global_pairs,skip", [("0", False), ("1", False), ("0", True)])
+def test_emu_sparse_one_sequence_of_65536_windows(emu_lib, port, monkeypatch, global_pairs, skip):
+    """A sequence of more than 65,535 windows among ordinary ones: multiplicities and ranks no longer fit 16 bits, so the
+    engine itself takes the unpacked entries — with the update streams (a few multi-word products included) and as atomics."""
+    from fastsk_amd import _native
+    set_tuning_env(monkeypatch, sparse_global=global_pairs)
+    rng = np.random.default_rng(66)
+    g, m = 8, 4
+    X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(30, 80, size=40)]
+    X.insert(17, rng.integers(1, 5, size=65600 + g - 1).astype(np.int32))
+    N, ntr = len(X), 25
+    tokens, offsets = _native.flatten(X)
+    combos = np.array([11, 52], dtype=np.int32)
+    raw, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=4)
+    e = _native.Engine(g, m, path=2, lib=emu_lib, skip_test_block=skip)
+    e.load_sequences(tokens, offsets, ntr if skip else N, N - ntr if skip else 0)
+    e.accumulate(combos)
+    e.finalize()
+    st = e.stats()
+    assert st["path_used"] == 2 and st["max_windows"] == 65600 and e.get_tuning("sparse_unpacked") == 0
+    got = e.get_counts()
+    if skip:
+        a, b = np.tril_indices(N)
+        keep = (b < ntr) | (a == b)
+        assert np.array_equal(got[keep], raw[keep]) and not got[~keep].any() and raw[~keep].any()
+    else:
+        assert np.array_equal(got, raw) and st["cell_updates"] == U
+    e.close()
+
+
+@pytest.mark.parametrize("name", ["f8_sigma300_g5m2", "f8_prot11_g20m4_skipvar12"])
+@pytest.mark.parametrize("tune", [{}, {"sparse_global": "1"}, {"sparse_unpacked": "1"}])
+def test_emu_wide_alphabets_and_wide_keys(emu_lib, monkeypatch, name, tune):
+    """Inputs upstream computes that the packed fast paths do not cover (cntsrtna takes any dictionary size and any k,
+    shared.cpp:156-191): 300 distinct tokens (16-bit symbols in HBM) and protein at g=20 m=4 (24^16 > 2^62: the k-mer key
+    is the symbols' bit fields side by side, in 128-bit sort records) — the reference's own outputs."""
+    set_tuning_env(monkeypatch, **tune)
+    d = load_golden(name)
+    e = run_case(emu_lib, d, 0)
+    st = e.stats()
+    assert st["path_used"] == 2 and st["alphabet"] == (300 if "sigma300" in name else st["alphabet"])
+    assert st["bits_per_symbol"] == (16 if "sigma300" in name else 8)
+    assert np.array_equal(e.get_counts(), d["counts"]) and np.array_equal(e.get_triangle(), d["tri"])
+    assert np.array_equal(e.get_train(), d["train"]) and np.array_equal(e.get_test(), d["test"])
+    e.close()
+
+
+@pytest.mark.parametrize("skip", [False, True])
+def test_emu_sparse_paired_unit_words(emu_lib, port, monkeypatch, skip):
+    """Update streams with PAIRS (bands of fewer than 32767 cells): the words of UNIT entries — multiplicity 1 and every partner
+    of multiplicity 1 — travel as bare cells, two to a 32-bit container, padded per owner band and per pass of k_sx_emit. Runs of
+    ~20 entries over 400 keys: ten words an entry, so a tile's short entries take several passes, about half of them unit;
+    with the pairs off (tuning sparse_pairs=0), in one call and in three, whole and in row bands, with skip_test_block."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(12)
+    N, ntr, g, m = 300, 180, 4, 2
+    X = [rng.integers(1, 21, size=int(L)).astype(np.int32) for L in rng.integers(24, 36, size=N)]
+    X[7][:] = 3   # one low-complexity sequence: multiplicities above 1 inside otherwise clean runs
+    tokens, offsets = _native.flatten(X)
+    combos = np.arange(6, dtype=np.int32)
+    raw, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=4)
+    a, b = np.tril_indices(N)
+    keep = (b < ntr) | (a == b) if skip else np.ones(len(a), dtype=bool)
+    for pairs in ("1", "0"):
+        set_tuning_env(monkeypatch, sparse_pairs=pairs)
+        for how in ("whole", "three calls", "row bands"):
+            e = _native.Engine(g, m, path=2, lib=emu_lib, skip_test_block=skip)
+            e.load_sequences(tokens, offsets, ntr if skip else N, N - ntr if skip else 0)
+            if how == "whole":
+                e.accumulate(combos)
+            elif how == "three calls":
+                for part in np.array_split(combos, 3):
+                    e.accumulate(part)
+            else:
+                for lo, hi in ((0, 128), (128, 256), (256, N)):
+                    e.accumulate_rows(combos, lo, hi)
+            e.finalize()
+            got = e.get_counts()
+            assert np.array_equal(got[keep], raw[keep]), (pairs, how)
+            assert skip or e.stats()["cell_updates"] == U
+            e.close()

@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import load_golden, ROOT
+from conftest import load_golden, synthetic_dna, ROOT
 
 sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
 
@@ -159,8 +159,8 @@ def test_group_errors(emu_lib):
     from fastsk_amd import _native
     with pytest.raises(_native.FskError, match="device ordinal"):
         _native.Engine(5, 2, lib=emu_lib, devices=[0, 99])
-    with pytest.raises(_native.FskError, match="RCCL"):
-        _native.Engine(5, 2, lib=emu_lib, devices=[0, 1], collective=_native.COLL_RCCL)
+    with pytest.raises(_native.FskError, match="distinct devices"):
+        _native.Engine(5, 2, lib=emu_lib, devices=[0, 0], collective=_native.COLL_RCCL)
     e = _native.Engine(6, 2, lib=emu_lib, devices=[0, 1])
     with pytest.raises(_native.FskError) as err:   # the reference printf+exit(1)s here (fastsk.cpp:53-58)
         e.compute(np.array([1, 2, 3, 1, 2, 3, 1, 2], dtype=np.int32), np.array([0, 3, 8]), 1, 1)
@@ -173,15 +173,15 @@ def test_group_errors(emu_lib):
 
 # ---- fail fast: a stuck engine must not hang the group (fsk_config.deadline_ms) ---------------------------------
 def test_group_deadline_names_the_band_and_poisons_the_group(emu_lib, monkeypatch):
-    """Engine 1's worker is late by 2.5 s before the collective of band 0 (FSK_FAULT, test-only): with a 300 ms
+    """Engine 1's worker is late by 2.5 s before the collective of band 0 (the fault_* tuning keys of test builds): with a 300 ms
     deadline the other engines give up at that band's exchange, the call returns FSK_EDEVICE naming the band well
     before a run without a deadline would have returned, every later call repeats the first failure (the group is
     dead, never half alive), and destroying the handle does not hang."""
     import time
     from fastsk_amd import _native
     d = load_golden("f4_ep300_exact")
-    monkeypatch.setenv("FSK_FAULT", "host:1:0:2500")
-    e = _native.Engine(d["g"], d["m"], lib=emu_lib, devices=[0, 1, 2], bands=3, deadline_ms=300)
+    e = _native.Engine(d["g"], d["m"], lib=emu_lib, devices=[0, 1, 2], bands=3, deadline_ms=300,
+                       tuning={"fault_kind": 1, "fault_rank": 1, "fault_band": 0, "fault_ms": 2500})
     e.load_sequences(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
     t0 = time.perf_counter()
     with pytest.raises(_native.FskError) as ei:
@@ -206,14 +206,12 @@ def test_group_without_fault_is_untouched_by_the_deadline(emu_lib, monkeypatch):
     """The same job with the deadline armed and no fault: identical result (the deadline only bounds waits)."""
     from fastsk_amd import _native
     d = load_golden("f4_ep300_exact")
-    monkeypatch.delenv("FSK_FAULT", raising=False)
     e = engine_for(emu_lib, d, [0, 1, 2], bands=3, deadline_ms=20000)
     e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
     assert np.array_equal(e.get_counts(), d["counts"])
     e.close()
     # a late engine INSIDE the deadline only delays the result
-    monkeypatch.setenv("FSK_FAULT", "host:2:0:300")
-    e = engine_for(emu_lib, d, [0, 1, 2], bands=2, deadline_ms=20000)
+    e = engine_for(emu_lib, d, [0, 1, 2], bands=2, deadline_ms=20000, tuning={"fault_kind": 1, "fault_rank": 2, "fault_band": 0, "fault_ms": 300})
     e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
     assert np.array_equal(e.get_counts(), d["counts"])
     e.close()
@@ -241,3 +239,265 @@ def test_group_bound_counts_are_not_narrowed(emu_lib):
     assert e.multi_info()["narrow"]
     assert np.array_equal(big, d["counts"])
     e.close()
+
+
+# ---- the RCCL collective with R >= 2 (fsk_multi.hip: RcclCollective) against the test build's stand-in for librccl ------
+# (tests/emu/rccl_stub.cpp: R worker threads meet in a real rendezvous, sums in rank order, counts / types / devices checked,
+# injectable failures). What it replaces is the reduce over the reference's worker threads, fastsk_kernel.cpp:286-315.
+STAT = {"init_calls": 0, "comms": 1, "destroyed": 2, "aborted": 3, "allreduce_calls": 4, "int32": 5, "uint64": 6, "float64": 7,
+        "bytes": 8, "wrong_device": 9, "mismatched": 10, "completed": 11, "ranks": 12}
+
+
+def rccl_stats(emu_lib):
+    import ctypes as C
+    out = (C.c_int64 * 16)()
+    emu_lib.L.emu_rccl_stats(out)
+    return {k: int(out[i]) for k, i in STAT.items()}
+
+
+@pytest.fixture
+def rccl(emu_lib):
+    emu_lib.L.emu_rccl_reset()
+    yield emu_lib
+    emu_lib.L.emu_rccl_reset()
+
+
+@pytest.mark.parametrize("name,devices", [("f4_ep300_exact", [0, 1]), ("f4_ep300_exact", [3, 1, 0, 2]), ("f4_ep300_exact", list(range(8))),
+                                          ("f3_ragged_sigma7_g6m3", [5, 2, 7, 1]), ("f5_prot11_exact", [0, 1, 2, 3, 4, 5, 6, 7]),
+                                          ("f1_small_g3m1", [0, 1, 2, 3, 4, 5, 6, 7])])
+def test_rccl_group_exact_equals_golden(rccl, name, devices):
+    """fsk_create_multi(collective = RCCL) with 2, 4 and 8 ranks: ncclCommInitAll over the listed devices, one int32
+    ncclAllReduce per band and rank issued from the rank's own worker thread on its own device, the golden counts."""
+    from fastsk_amd import _native
+    d = load_golden(name)
+    R = len(devices)
+    e = engine_for(rccl, d, devices, collective=_native.COLL_RCCL)
+    e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+    assert np.array_equal(e.get_counts(), d["counts"])
+    assert np.array_equal(e.get_triangle(), d["tri"])
+    info = e.multi_info()
+    assert info["collective"] == "rccl" and info["comm_ranks"] == R and info["ndev"] == R and info["narrow"]
+    assert sum(info["combos_per_engine"]) == len(d["combos"])
+    st = rccl_stats(rccl)
+    assert st["init_calls"] == 1 and st["comms"] == R and st["ranks"] == R
+    assert st["allreduce_calls"] == st["int32"] == R * info["bands"] and st["completed"] == info["bands"]
+    assert st["bytes"] == R * info["reduce_bytes"]
+    assert st["wrong_device"] == 0 and st["mismatched"] == 0 and st["aborted"] == 0
+    e.close()
+    assert rccl_stats(rccl)["destroyed"] == R
+
+
+@pytest.mark.parametrize("R", [2, 4, 8])
+def test_rccl_banded_exchange_both_widths_by_digest(rccl, port, R):
+    """Several row bands, int32 and uint64 payloads, additive accumulates, resets, engines without combos — by the
+    order-free digest against one engine and cell by cell against the oracle."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(31)
+    N = 700
+    X = rng.integers(1, 5, size=(N, 26), dtype=np.int32)
+    X[::17, 2:24] = 2   # counts above 15: the hi plane
+    tok, off = _native.flatten(X)
+    g, m = 6, 3
+    ca, cb = np.arange(0, 20, 2, dtype=np.int32), np.array([1, 7, 19], dtype=np.int32)
+    wa, _, _ = port.raw_counts(tok, off, g, m, ca, threads=4)
+    wb, _, _ = port.raw_counts(tok, off, g, m, cb, threads=4)
+    single = _native.Engine(g, m, lib=rccl, path=1)
+    single.load_sequences(tok, off, N, 0)
+    single.accumulate(ca)
+    single.finalize()
+    want = single.counts_digest()
+    single.close()
+    e = _native.Engine(g, m, lib=rccl, devices=list(range(R)), collective=_native.COLL_RCCL, bands=5, path=1)
+    e.load_sequences(tok, off, N, 0)
+    e.accumulate(ca)
+    e.finalize()
+    info = e.multi_info()
+    assert info["bands"] == 5 and info["narrow"] and info["collective"] == "rccl"
+    assert e.counts_digest() == want and np.array_equal(e.get_counts(), wa)
+    st = rccl_stats(rccl)
+    assert st["int32"] == 5 * R and st["uint64"] == 0 and st["mismatched"] == 0 and st["wrong_device"] == 0
+    e.accumulate(cb)                       # additive; three combos over R engines: some have none
+    e.finalize()
+    assert np.array_equal(e.get_counts(), wa + wb)
+    # caller memory of unknown contents: the exchange stays 64 bits wide until a whole reset
+    pairs = N * (N + 1) // 2
+    big = np.full(pairs, (1 << 33) + 5, dtype=np.uint64)
+    e.bind_counts(big.ctypes.data, pairs, keepalive=big)
+    e.accumulate(ca)
+    e.finalize()
+    assert not e.multi_info()["narrow"] and rccl_stats(rccl)["uint64"] == 5 * R
+    assert np.array_equal(big, wa + np.uint64((1 << 33) + 5))
+    e.reset_counts()
+    e.accumulate(cb)
+    e.finalize()
+    assert e.multi_info()["narrow"] and np.array_equal(big, wb)
+    assert rccl_stats(rccl)["mismatched"] == 0
+    e.close()
+
+
+@pytest.mark.parametrize("devices,path", [([0, 1], 0), ([4, 5, 6], 2)])
+def test_rccl_wide_cells_and_sparse_dataflow(rccl, port, devices, path):
+    """C(g,m) * max_windows^2 >= 2^31: the band travels as ncclUint64, in place."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(21)
+    X = [rng.integers(1, 5, size=n).astype(np.int32) for n in (20000, 50, 64, 41, 77, 58)]
+    tok, off = _native.flatten(X)
+    g, m = 6, 2
+    want, _, _ = port.compute(tok, off, 4, 2, g, m, t=1)
+    e = _native.Engine(g, m, lib=rccl, devices=devices, path=path, collective=_native.COLL_RCCL)
+    e.compute(tok, off, 4, 2)
+    assert not e.multi_info()["narrow"] and np.array_equal(e.get_triangle(), want)
+    st = rccl_stats(rccl)
+    assert st["uint64"] == len(devices) and st["int32"] == 0 and st["bytes"] == len(devices) * 8 * 21
+    e.close()
+
+
+@pytest.mark.parametrize("name", ["f4_ep300_skipvar_T3", "f6_prot219_skipvar16"])
+def test_rccl_skip_variance(rccl, name):
+    from fastsk_amd import _native
+    d = load_golden(name)
+    e = engine_for(rccl, d, [0, 1, 2, 3], collective=_native.COLL_RCCL)
+    e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+    assert np.array_equal(e.get_triangle(), d["tri"]) and np.array_equal(e.get_test(), d["test"])
+    e.close()
+
+
+@pytest.mark.parametrize("R,T", [(2, 1), (2, 2), (4, 2), (8, 5)])
+def test_rccl_variance_chains(rccl, port, R, T):
+    """Variance mode: chain t on engine t mod R, ONE ncclFloat64 all-reduce of the chains' sums; stdevs are chain 0's."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(5)
+    X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(12, 40, size=30)]
+    tok, off = _native.flatten(X)
+    g, m = 7, 3
+    order = rng.permutation(port.num_combos(g, m)).astype(np.int32)
+    want, sd, _ = port.compute(tok, off, 22, 8, g, m, t=T, approx=True, delta=0.5, max_iters=6, order=order)
+    e = _native.Engine(g, m, t=T, approx=True, delta=0.5, max_iters=6, lib=rccl, devices=list(range(R)), collective=_native.COLL_RCCL)
+    e.set_combo_order(order)
+    e.compute(tok, off, 22, 8)
+    assert np.array_equal(e.get_stdevs(), sd)
+    got = e.get_triangle()
+    assert np.array_equal(got, want) if T <= 2 else np.allclose(got, want, rtol=1e-14, atol=0)
+    st = rccl_stats(rccl)
+    assert st["float64"] == R and st["int32"] == st["uint64"] == 0 and st["completed"] == 1 and st["wrong_device"] == 0
+    e.close()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("deadline_ms", [400, -1])
+def test_rccl_failed_collective_poisons_the_group(rccl, deadline_ms):
+    """Rank 2's ncclAllReduce of band 1 fails (the others are already inside theirs): the call returns FSK_EDEVICE with RCCL's
+    message and the band, the communicator is aborted (which releases the ranks that wait for rank 2 — with a deadline or
+    without one: nobody sits it out), every later call repeats the first failure, destroying the handle does not hang."""
+    import time
+    from fastsk_amd import _native
+    tok, off = synthetic_dna(400, 26, seed=8)   # (400 sequences: three tile rows, so three bands)
+    combos = np.arange(0, 20, dtype=np.int32)
+    e = _native.Engine(6, 3, lib=rccl, devices=[0, 1, 2, 3], bands=3, deadline_ms=deadline_ms, collective=_native.COLL_RCCL)
+    e.load_sequences(tok, off, 400, 0)
+    rccl.L.emu_rccl_set_fault(2, 2, 1, 0)    # rank 2, its second all-reduce (band 1)
+    t0 = time.perf_counter()
+    with pytest.raises(_native.FskError) as ei:
+        e.accumulate(combos)
+        e.finalize()
+    assert time.perf_counter() - t0 < 30
+    assert ei.value.code == -4 and "ncclAllReduce failed" in str(ei.value) and "band 1" in str(ei.value), str(ei.value)
+    st = rccl_stats(rccl)
+    assert st["aborted"] == 4 and st["completed"] == 1   # (band 0 went through)
+    with pytest.raises(_native.FskError) as ei2:
+        e.accumulate(combos)
+    assert "dead after an earlier failure" in str(ei2.value) and "ncclAllReduce failed" in str(ei2.value)
+    with pytest.raises(_native.FskError):
+        e.synchronize()
+    e.close()
+    assert rccl_stats(rccl)["destroyed"] == 0     # (aborted communicators are not destroyed a second time)
+    # and a fresh group on the same devices works
+    d = load_golden("f4_ep300_exact")
+    e = engine_for(rccl, d, [0, 1, 2, 3], collective=_native.COLL_RCCL)
+    e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+    assert np.array_equal(e.get_counts(), d["counts"])
+    e.close()
+
+
+@pytest.mark.timeout(120)
+def test_rccl_peer_that_never_answers(rccl):
+    """Rank 1 never takes part in band 0's collective: the others' collectives give up (the library's own watchdog, 500 ms
+    here), the group is poisoned and aborted — which is also what lets go of rank 1 —, FSK_EDEVICE, no hang."""
+    from fastsk_amd import _native
+    d = load_golden("f4_ep300_exact")
+    e = _native.Engine(d["g"], d["m"], lib=rccl, devices=[0, 1, 2], bands=2, deadline_ms=5000, collective=_native.COLL_RCCL)
+    e.load_sequences(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+    rccl.L.emu_rccl_set_fault(3, 1, 0, 500)
+    with pytest.raises(_native.FskError) as ei:
+        e.accumulate(np.arange(0, 30, dtype=np.int32))
+        e.finalize()
+    assert ei.value.code == -4 and "band 0" in str(ei.value), str(ei.value)
+    assert rccl_stats(rccl)["aborted"] == 3 and rccl_stats(rccl)["completed"] == 0
+    e.close()
+
+
+@pytest.mark.timeout(120)
+def test_rccl_init_failure_and_init_deadline(rccl):
+    """ncclCommInitAll fails -> fsk_create_multi fails with its message (nothing leaks); ncclCommInitAll that takes longer
+    than the deadline -> FSK_EDEVICE naming the deadline, and the abandoned helper thread gives back the communicators it
+    obtains afterwards."""
+    import time
+    from fastsk_amd import _native
+    rccl.L.emu_rccl_set_fault(1, 0, 0, 0)
+    with pytest.raises(_native.FskError, match="ncclCommInitAll failed"):
+        _native.Engine(6, 2, lib=rccl, devices=[0, 1], collective=_native.COLL_RCCL)
+    rccl.L.emu_rccl_set_fault(4, 0, 1200, 0)   # the init takes 1.2 s
+    t0 = time.perf_counter()
+    with pytest.raises(_native.FskError, match="did not return within 300 ms"):
+        _native.Engine(6, 2, lib=rccl, devices=[0, 1, 2], collective=_native.COLL_RCCL, deadline_ms=300)
+    assert time.perf_counter() - t0 < 1.0
+    time.sleep(1.6)
+    st = rccl_stats(rccl)
+    assert st["comms"] == 3 and st["aborted"] == 3 and st["destroyed"] == 0, st
+    e = _native.Engine(6, 2, lib=rccl, devices=[0, 1, 2], collective=_native.COLL_RCCL, deadline_ms=300)   # and the next one is fine
+    e.close()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("collective", ["rccl", "p2p"])
+def test_group_variance_chains_may_outlast_the_deadline(rccl, port, collective):
+    """Variance mode: the chains of one engine legitimately take much longer than another's (here engine 1 is 1.5 s late,
+    the deadline is 300 ms): the barrier in front of the fp64 all-reduce has NO deadline — the result is the usual one,
+    not FSK_EDEVICE 'another engine of the group failed' on a healthy machine."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(5)
+    X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(12, 40, size=30)]
+    tok, off = _native.flatten(X)
+    g, m, T = 7, 3, 2
+    order = rng.permutation(port.num_combos(g, m)).astype(np.int32)
+    want, sd, _ = port.compute(tok, off, 22, 8, g, m, t=T, approx=True, delta=0.5, max_iters=6, order=order)
+    coll = _native.COLL_RCCL if collective == "rccl" else _native.COLL_P2P
+    e = _native.Engine(g, m, t=T, approx=True, delta=0.5, max_iters=6, lib=rccl, devices=[0, 1], collective=coll, deadline_ms=300,
+                       tuning={"fault_kind": 3, "fault_rank": 1, "fault_ms": 1500})
+    e.set_combo_order(order)
+    e.compute(tok, off, 22, 8)
+    assert np.array_equal(e.get_stdevs(), sd) and np.array_equal(e.get_triangle(), want)
+    e.close()
+
+
+def test_tuning_through_the_abi_and_the_environment(emu_lib, monkeypatch):
+    """fsk_set_tuning / fsk_get_tuning / FSK_TUNING: unknown keys and values out of range fail loudly, a group hands a key to
+    all its engines, the test-only keys exist in this (test) build."""
+    from fastsk_amd import _native
+    keys = emu_lib.tuning_keys()
+    assert "fault_kind" in keys and keys["fault_kind"][:3] == (0, 0, 3)
+    e = _native.Engine(6, 2, lib=emu_lib, devices=[0, 1], tuning={"sparse_global": 1})
+    assert e.get_tuning("sparse_global") == 1 and e.get_tuning("guard_cap") == 0
+    with pytest.raises(_native.FskError, match="unknown tuning key"):
+        e.set_tuning("no_such_key", 1)
+    with pytest.raises(_native.FskError, match="takes 0 .. 1"):
+        e.set_tuning("sparse_global", 7)
+    e.close()
+    monkeypatch.setenv("FSK_TUNING", "guard_cap=64, sparse_sync=1")
+    e = _native.Engine(6, 2, lib=emu_lib)
+    assert e.get_tuning("guard_cap") == 64 and e.get_tuning("sparse_sync") == 1
+    e.close()
+    for bad in ("guard_cap", "nonsense=1", "guard_cap=abc", "sparse_sync=9"):
+        monkeypatch.setenv("FSK_TUNING", bad)
+        with pytest.raises(_native.FskError, match="FSK_TUNING"):
+            _native.Engine(6, 2, lib=emu_lib)

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import golden_names, load_golden, load_tokens, tri_to_square, synthetic_dna, GOLD, EDGE_CASES
+from conftest import golden_names, load_golden, load_tokens, tri_to_square, synthetic_dna, set_tuning_env, GOLD, EDGE_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -29,6 +29,12 @@ def native():
     lib = _native.library()  # raises if the HIP library is missing: no fallback
     assert lib.device_count() >= 1
     return _native
+
+
+def hooks_library(native):
+    """tests/hooks/libfastsk_amd_hooks.so: the engine compiled with -DFSK_TEST_HOOKS (fault injection); the product has none."""
+    import __graft_entry__ as ge
+    return native.Library(ge.build_engine(hooks=True))
 
 
 def engine_for(native, d, path=0, **kw):
@@ -211,7 +217,7 @@ def test_sparse_products_beyond_one_update_word(native, port, monkeypatch, globa
     """Sparse dataflow with multiplicities so large that a product does not fit the product field of a
     32-bit update word (a 1500-long homopolymer and a long dinucleotide repeat among 300 ordinary
     sequences: multiplicity x max windows ~ 2.2e6 > 2^18): such entries spend several words per pair."""
-    monkeypatch.setenv("FSK_SPARSE_GLOBAL", global_pairs)
+    set_tuning_env(monkeypatch, sparse_global=global_pairs)
     rng = np.random.default_rng(8)
     X = [rng.integers(1, 6, size=int(L)).astype(np.int32) for L in rng.integers(12, 90, size=300)]
     X[17] = np.full(1500, 3, dtype=np.int32)
@@ -451,8 +457,8 @@ def test_config5_full_size_100k_through_the_class(native, port):
     del tri, blk, f
     torch.cuda.empty_cache()
 
-    # ---- compute_kernel, SURVEY 8(d)'s 90k / 10k split; the test x test block is lazy (skip_test_block=None)
-    f = FastSK(g=g, m=m)
+    # ---- compute_kernel, SURVEY 8(d)'s 90k / 10k split; the test x test block lazy (skip_test_block="lazy")
+    f = FastSK(g=g, m=m, skip_test_block="lazy")
     f.compute_kernel(X[:90000], X[90000:])
     st = f.stats()
     assert st["combos_done"] == 495 and not st["test_block_computed"]
@@ -523,6 +529,139 @@ def test_sparse_dataflow_large_n(native, port, N, lo, hi, ncombo, n_sub):
     assert np.array_equal(blk, blk.T) and np.all(np.diag(blk) == 1.0)
     e.close()
     sub.close()
+
+
+# ---- the unpacked entry format (8 + 4 (+ 4) bytes) of the sparse dataflow: N >= 65,535 sequences, or a sequence of >= 65,536
+# windows — k_sx_seg_write<RecT, false> and k_sx_emit<DIRECT | lists, SKIP, false>, the path of countAndUpdateTri
+# (shared.cpp:268-333) for inputs whose ids or multiplicities do not fit 16 bits
+def _subset_against_oracle(native, port, e, X, idx, g, m, combos, n_train=None):
+    """The oracle on just the sequences `idx`: its cells must equal the scattered cells (idx[a], idx[b]) of the big triangle —
+    all of them, or with skip_test_block every cell whose column is a train sequence or that lies on the diagonal."""
+    stoks, soff = native.flatten([X[i] for i in idx])
+    want, _, U = port.raw_counts(stoks, soff, g, m, combos, threads=min(32, os.cpu_count() or 8))
+    a, b = np.tril_indices(len(idx))
+    got = e.get_counts_cells(idx[a], idx[b])
+    if n_train is None:
+        assert np.array_equal(got, want)
+    else:
+        keep = (idx[b] < n_train) | (a == b)
+        assert np.array_equal(got[keep], want[keep]) and not got[~keep].any() and want[~keep].any()
+    return stoks, soff, U
+
+
+@pytest.mark.parametrize("skip", [False, True])
+def test_sparse_unpacked_entries_beyond_65535_sequences(native, port, skip):
+    """N = 70,000 protein-like ragged sequences (20 letters, 30-50 long), g=8 m=4, five combos, sparse dataflow: sequence ids
+    no longer fit the packed entry format. Random 1500-sequence subset (rows on both sides of 65,535) against the oracle,
+    the update count U on that subset, with and without skip_test_block."""
+    N, g, m = 70000, 8, 4
+    X = protein_like(N, 30, 51, seed=70)
+    tokens, offsets = native.flatten(X)
+    combos = np.array([0, 17, 33, 51, 69], dtype=np.int32)
+    n_train = 40000
+    e = native.Engine(g, m, path=2, skip_test_block=skip)
+    e.load_sequences(tokens, offsets, n_train if skip else N, N - n_train if skip else 0)
+    e.accumulate(combos)
+    e.finalize()
+    st = e.stats()
+    assert st["path_used"] == 2 and st["combos_done"] == len(combos) and st["n_seq"] == N
+    rng = np.random.Generator(np.random.PCG64(5))
+    idx = np.sort(np.concatenate([rng.choice(65535, size=900, replace=False), 65535 + rng.choice(N - 65535, size=600, replace=False)]))
+    stoks, soff, U = _subset_against_oracle(native, port, e, X, idx, g, m, combos, n_train if skip else None)
+    if not skip:   # U from the definition, on the subset, through the same (forced) entry format
+        sub = native.Engine(g, m, path=2, tuning={"sparse_unpacked": 1})
+        sub.load_sequences(stoks, soff, len(idx), 0)
+        sub.accumulate(combos)
+        sub.finalize()
+        assert sub.stats()["cell_updates"] == U
+        sub.close()
+    blk = e.get_block(N - 64, N, N - 64, N)
+    assert np.all(np.diag(blk) == 1.0) and (skip or np.array_equal(blk, blk.T))
+    e.close()
+
+
+@pytest.mark.parametrize("global_pairs", ["0", "1"])
+@pytest.mark.parametrize("skip", [False, True])
+def test_sparse_unpacked_entries_one_very_long_sequence(native, port, monkeypatch, global_pairs, skip):
+    """One sequence of 66,000 windows among 300 ordinary ones (N < 65,535): multiplicities and ranks need the unpacked entries
+    while the update STREAMS are in use (k_sx_emit<false, SKIP, false>); and as 64-bit atomics (tuning sparse_global=1)."""
+    set_tuning_env(monkeypatch, sparse_global=global_pairs)
+    rng = np.random.default_rng(66)
+    g, m = 9, 4
+    X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(40, 120, size=300)]
+    X.insert(137, rng.integers(1, 5, size=66000 + g - 1).astype(np.int32))
+    N, n_train = len(X), 200
+    tokens, offsets = native.flatten(X)
+    combos = np.array([3, 40, 77, 125], dtype=np.int32)
+    raw, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=8)
+    e = native.Engine(g, m, path=2, skip_test_block=skip)
+    e.load_sequences(tokens, offsets, n_train if skip else N, N - n_train if skip else 0)
+    e.accumulate(combos)
+    e.finalize()
+    st = e.stats()
+    assert st["path_used"] == 2 and st["max_windows"] == 66000
+    got = e.get_counts()
+    if not skip:
+        assert np.array_equal(got, raw) and st["cell_updates"] == U
+    else:
+        a, b = np.tril_indices(N)
+        keep = (b < n_train) | (a == b)
+        assert np.array_equal(got[keep], raw[keep]) and not got[~keep].any() and raw[~keep].any()
+        assert st["cell_updates"] < U
+    e.close()
+
+
+@pytest.mark.parametrize("name", ["f5_prot11_exact", "f6_prot219_skipvar16", "f3_ragged_sigma7_g6m3"])
+@pytest.mark.parametrize("global_pairs", ["0", "1"])
+def test_sparse_unpacked_entries_forced_on_the_goldens(native, monkeypatch, name, global_pairs):
+    """The same kernel instantiations on the golden vectors (tuning sparse_unpacked=1): streams and atomics, exact counts, and
+    variance mode's by-slot batches on top of unpacked entries."""
+    set_tuning_env(monkeypatch, sparse_unpacked="1", sparse_global=global_pairs)
+    d = load_golden(name)
+    e = engine_for(native, d, path=2)
+    e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+    assert np.array_equal(e.get_counts(), d["counts"]) and np.array_equal(e.get_triangle(), d["tri"])
+    e.close()
+    if global_pairs == "0" and name == "f5_prot11_exact":
+        v = load_golden("f5_prot11_variance_T1_it9")
+        e = engine_for(native, v, path=2)
+        e.compute(v["tokens"], v["offsets"], v["n_train"], v["n_test"])
+        assert np.array_equal(e.get_stdevs(), v["stdevs"]) and np.array_equal(e.get_triangle(), v["tri"])
+        e.close()
+
+
+@pytest.mark.parametrize("skip", [False, True])
+def test_sparse_paired_unit_words(native, port, monkeypatch, skip):
+    """Update streams with PAIRS (a band of fewer than 32767 cells): the words of UNIT entries — multiplicity 1, every partner
+    of multiplicity 1 — leave k_sx_emit as bare 15-bit cells, two to a 32-bit container, when the tile's short entries are
+    binned in one pass; protein-like data (one-pass tiles, most words unit) and long runs over 400 keys (several passes: no
+    pairs), pairs on and off (tuning sparse_pairs), in one call, in three, in row bands: the oracle's counts and U."""
+    for X, g, m, combos in ((protein_like(1500, 40, 160, seed=31), 10, 6, np.arange(0, 210, 9, dtype=np.int32)),
+                            ([np.random.default_rng(12 + i).integers(1, 21, size=30).astype(np.int32) for i in range(1400)], 4, 2, np.arange(6, dtype=np.int32))):
+        N, ntr = len(X), 900
+        X[7][:] = 3   # a low-complexity sequence: multiplicities above 1 inside otherwise clean runs
+        tokens, offsets = native.flatten(X)
+        raw, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=min(32, os.cpu_count() or 8))
+        a, b = np.tril_indices(N)
+        keep = (b < ntr) | (a == b) if skip else np.ones(len(a), dtype=bool)
+        for pairs in ("1", "0"):
+            set_tuning_env(monkeypatch, sparse_pairs=pairs)
+            for how in ("whole", "three calls", "row bands"):
+                e = native.Engine(g, m, path=2, skip_test_block=skip)
+                e.load_sequences(tokens, offsets, ntr if skip else N, N - ntr if skip else 0)
+                if how == "whole":
+                    e.accumulate(combos)
+                elif how == "three calls":
+                    for part in np.array_split(combos, 3):
+                        e.accumulate(part)
+                else:
+                    for lo, hi in ((0, 384), (384, 1024), (1024, N)):
+                        e.accumulate_rows(combos, lo, hi)
+                e.finalize()
+                got = e.get_counts()
+                assert np.array_equal(got[keep], raw[keep]), (pairs, how, g)
+                assert skip or e.stats()["cell_updates"] == U
+                e.close()
 
 
 def test_pybind_surface_on_gpu(native):
@@ -672,15 +811,16 @@ def test_bench_fails_fast_with_a_json_line_when_a_rank_hangs(native):
 
 def test_bench_inproc_reports_a_stuck_exchange(native):
     """The same for the in-process engine (fsk_create_multi): engine 1's exchange stream is held for 6 s in front of
-    band 0's all-reduce (FSK_FAULT, bounded spin kernel), the engine's deadline is the step bound (2 s): fsk_finalize
+    band 0's all-reduce (tests/hooks' build of the engine: fault_* tuning keys, a bounded spin kernel), the engine's deadline is the step bound (2 s): fsk_finalize
     returns FSK_EDEVICE naming the band, bench.py prints the JSON error line and exits 2."""
     import json
     import subprocess
     import sys
     from conftest import ROOT
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--inproc", "--steps", "1", "--warmup", "0",
-                        "--n-seq", "8000", "--no-cpu-baseline", "--no-also", "--step-bound", "2"],
-                       env=_bench_env(FSK_BENCH_SHARE_GPU="1", FSK_FAULT="device:1:0:6000"), capture_output=True, text=True, timeout=300)
+                        "--n-seq", "8000", "--no-cpu-baseline", "--no-also", "--step-bound", "2", "--engine-lib", hooks_library(native).path],
+                       env=_bench_env(FSK_BENCH_SHARE_GPU="1", FSK_TUNING="fault_kind=2,fault_rank=1,fault_band=0,fault_ms=6000"),
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode == 2, r.stdout[-1500:] + r.stderr[-1500:]
     e = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert "band 0" in e["error"] and "2000 ms" in e["error"] and e["n_gpus"] == 2 and e["value"] is None
@@ -809,7 +949,7 @@ def test_reset_then_storing_launch(native, port, monkeypatch):
     wb, _, _ = port.raw_counts(tokens, offsets, 8, 4, cb, threads=4)
     cell = lambda r: r * (r + 1) // 2
     for splits in ("1", "0"):   # "1": one workgroup per tile -> the storing launch; "0": automatic splits -> zero fill + atomics
-        monkeypatch.setenv("FSK_TILE_SPLITS", splits)
+        set_tuning_env(monkeypatch, tile_splits=splits)
         e = native.Engine(8, 4, path=1)
         e.load_sequences(tokens, offsets, N, 0)
         e.accumulate(ca)                        # K now holds data that every reset below must erase
@@ -841,27 +981,6 @@ def test_reset_then_storing_launch(native, port, monkeypatch):
         e.finalize()
         want[cell(0):cell(128)] += wb[cell(0):cell(128)]
         assert np.array_equal(e.get_counts(), want)
-        e.close()
-
-
-def test_register_staged_tile_kernel_still_agrees(native, port, monkeypatch):
-    """FSK_TILE_DMA=0 selects k_dense_tile (register-staged panels) instead of the default
-    k_dense_tile_dma (direct-to-LDS loads): same counts, including rows with counts above 15 and a
-    key space that is not a multiple of a stage."""
-    rng = np.random.default_rng(77)
-    N = 700
-    X = rng.integers(1, 4, size=(N, 150), dtype=np.int32)   # 3 symbols, k = 5: 243 keys -> 31 dword rows
-    X[::9, 20:90] = 1                                        # long runs: counts above 15
-    tokens, offsets = native.flatten(X)
-    combos = np.arange(0, 126, 5, dtype=np.int32)
-    want, _, _ = port.raw_counts(tokens, offsets, 9, 4, combos, threads=8)
-    for dma in ("0", "1"):
-        monkeypatch.setenv("FSK_TILE_DMA", dma)
-        e = native.Engine(9, 4, path=1)
-        e.load_sequences(tokens, offsets, N, 0)
-        e.accumulate(combos)
-        e.finalize()
-        assert np.array_equal(e.get_counts(), want), "FSK_TILE_DMA=" + dma
         e.close()
 
 
@@ -899,7 +1018,7 @@ def test_variance_mode_stops_anywhere(native, port, path, monkeypatch):
     their own and the Welford state is written once per batch (a stop inside a batch runs its prefix again);
     path -1: the dense dataflow with its per-iteration triangles switched off."""
     if path == -1:
-        monkeypatch.setenv("FSK_VARIANCE_DENSE_SLOTS", "0")
+        set_tuning_env(monkeypatch, variance_dense_slots="0")
         path = 1
     rng = np.random.default_rng(5)
     X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(12, 40, size=30)]
@@ -927,7 +1046,7 @@ def test_variance_mode_count_above_255(native, port, form, monkeypatch):
     diverted to the general dataflow, which adds into the iteration's own triangle — zeroed first
     (the storing tile launch that normally writes every cell of it is not coming)."""
     if form == "dense_fill":
-        monkeypatch.setenv("FSK_VARIANCE_DENSE_SLOTS", "0")
+        set_tuning_env(monkeypatch, variance_dense_slots="0")
     rng = np.random.default_rng(11)
     X = [rng.integers(1, 5, size=int(l)).astype(np.int32) for l in rng.integers(280, 320, size=24)]
     for i in (2, 9, 17):
@@ -937,7 +1056,7 @@ def test_variance_mode_count_above_255(native, port, form, monkeypatch):
     order = np.random.default_rng(3).permutation(port.num_combos(g, m)).astype(np.int32)
     want, sd, _ = port.compute(tok, off, 16, 8, g, m, t=T, approx=True, delta=0.025, max_iters=-1, order=order)
     if form == "sparse_u32":
-        monkeypatch.setenv("FSK_VAR_SLOTS16", "0")
+        set_tuning_env(monkeypatch, var_slots16="0")
     e = native.Engine(g, m, t=T, approx=True, path=2 if form.startswith("sparse") else 1)
     e.set_combo_order(order)
     e.compute(tok, off, 16, 8)
@@ -969,13 +1088,12 @@ def test_sequential_sum_on_the_device(native):
     e.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"FSK_SPARSE_SYNC": "1"}, {"FSK_SPARSE_GUARD_CAP": "5000"}])
+@pytest.mark.parametrize("env", [{}, {"sparse_sync": "1"}, {"guard_cap": "5000"}])
 def test_sparse_batches_enqueued_ahead_of_their_size(native, port, monkeypatch, env):
     """Sparse dataflow, several accumulate calls: batches after the first are enqueued before their
     update-word count is known; the same counts and U as batches sized one by one, also when every
     such batch overflows the (shrunk) guard and is redone."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    set_tuning_env(monkeypatch, **env)
     tokens, offsets = synthetic_dna(900, 120, seed=21)
     g, m = 12, 6
     combos = np.arange(0, port.num_combos(g, m), 5, dtype=np.int32)
@@ -989,21 +1107,20 @@ def test_sparse_batches_enqueued_ahead_of_their_size(native, port, monkeypatch, 
     assert np.array_equal(e.get_counts(), want)
     st = e.stats()
     assert st["cell_updates"] == U
-    assert st["batches_redone"] == (len(parts) - 1 if "FSK_SPARSE_GUARD_CAP" in env else 0)
+    assert st["batches_redone"] == (len(parts) - 1 if "guard_cap" in env else 0)
     e.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"FSK_SPARSE_EXACT_LANES": "2"}, {"FSK_SPARSE_EXACT_LANES": "1"}, {"FSK_SPARSE_GUARD_CAP": "5000"}, {"FSK_SPARSE_GLOBAL": "1"}])
+@pytest.mark.parametrize("env", [{}, {"sparse_exact_lanes": "2"}, {"sparse_exact_lanes": "1"}, {"guard_cap": "5000"}, {"sparse_global": "1"}])
 def test_sparse_exact_accumulate_in_two_lanes(native, port, monkeypatch, env):
     """Sparse dataflow: the batches of ONE exact accumulate alternate between two lanes (a scratch set and a stream each);
     their consume passes — plain read-modify-writes of K — are ordered by events. Same counts and U as on one stream,
     with every guarded batch redone, and with atomics instead of streams; repeated, so that a race would show."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    set_tuning_env(monkeypatch, **env)
     tokens, offsets = synthetic_dna(900, 120, seed=33)
     g, m = 12, 6
     nfeat = 900 * (120 - g + 1)
-    monkeypatch.setenv("FSK_SPARSE_BATCH_RECORDS", str(6 * nfeat))  # (six combos a batch)
+    set_tuning_env(monkeypatch, sparse_batch_records=str(6 * nfeat))  # (six combos a batch)
     combos = np.arange(0, port.num_combos(g, m), 7, dtype=np.int32)
     want, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=8)
     e = native.Engine(g, m, path=2)
@@ -1015,20 +1132,19 @@ def test_sparse_exact_accumulate_in_two_lanes(native, port, monkeypatch, env):
         assert np.array_equal(e.get_counts(), want), rep
     st = e.stats()
     assert st["cell_updates"] == 3 * U
-    if "FSK_SPARSE_GUARD_CAP" in env:
+    if "guard_cap" in env:
         assert st["batches_redone"] > 0
     e.close()
 
 
-@pytest.mark.parametrize("env", [{"FSK_SPARSE_GLOBAL": "1"}, {"FSK_LIST_MAX_WORDS": "200000"}, {}, {"FSK_SPARSE_SYNC": "1"},
-                                 {"FSK_SPARSE_GUARD_CAP": "5000"}])
+@pytest.mark.parametrize("env", [{"sparse_global": "1"}, {"list_max_words": "200000"}, {}, {"sparse_sync": "1"},
+                                 {"guard_cap": "5000"}])
 def test_variance_mode_sparse_forms(native, monkeypatch, env):
     """Variance mode through the sparse dataflow in its forms (grouped batches with a u32 triangle
     per slot; atomics; ungrouped after a batch too large for one stream; batches sized one by one;
     batches that overflow their guard and are redone): the reference's stdevs and
     triangle, bit for bit, on the protein slice and on BASELINE config 1 at full size."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    set_tuning_env(monkeypatch, **env)
     for name in ("f5_prot11_variance_T1", "f7_cfg1_prot11_approx_t1"):
         d = load_golden(name)
         if "tokens" in d:
@@ -1079,7 +1195,7 @@ def test_skip_test_block_sparse(native, port, monkeypatch, global_pairs):
     """skip_test_block=1 on the sparse dataflow: a test row pairs only with the train entries of its k-mer
     runs and with itself, so exactly the test x test cells off the diagonal stay zero and everything a
     getter of the reference exposes is unchanged — update streams and atomics, whole and in row bands."""
-    monkeypatch.setenv("FSK_SPARSE_GLOBAL", global_pairs)
+    set_tuning_env(monkeypatch, sparse_global=global_pairs)
     X = protein_like(1400, 40, 160, seed=21)
     N, ntr, g, m = len(X), 500, 10, 6
     tokens, offsets = native.flatten(X)
@@ -1161,7 +1277,7 @@ def test_sparse_segment_scan_in_chunks(native, port, monkeypatch, forced):
     """A sparse batch of more than 4096 entry tiles scans its tile records in three launches (chunk
     totals, the chunks, the tiles with their carries); forced=1 takes that form for the small batches of
     the row bands too. Counts against the oracle, with and without skip_test_block."""
-    monkeypatch.setenv("FSK_SEG_SCAN_CHUNKED", forced)
+    set_tuning_env(monkeypatch, seg_scan_chunked=forced)
     X = protein_like(2600, 60, 260, seed=33)
     N, ntr, g, m = len(X), 1700, 8, 4
     tokens, offsets = native.flatten(X)
@@ -1352,7 +1468,7 @@ def test_two_ranks_sharing_the_gpu_variance_chains(native, port, tmp_path, T):
 def test_sparse_pair_accumulation_variants(native, port, monkeypatch, global_pairs):
     """Protein-like input through the sparse dataflow with owner-slice LDS accumulation and with
     direct per-pair atomics, whole and in row bands; U equals the oracle's count of `+=`."""
-    monkeypatch.setenv("FSK_SPARSE_GLOBAL", global_pairs)
+    set_tuning_env(monkeypatch, sparse_global=global_pairs)
     rng = np.random.default_rng(31)
     N = 900
     X = [rng.integers(1, 21, size=int(L)).astype(np.int32) for L in rng.integers(20, 400, size=N)]
@@ -1380,7 +1496,7 @@ def test_sparse_words_per_record_hint_across_loads(native, port, monkeypatch, hi
     """Sparse dataflow: a second set of sequences of the same shape starts from the first set's words per record as a hint
     (its first batch goes out under a guard, at full size); a hint that is far too low costs a redone batch, never a count."""
     if hint is not None:
-        monkeypatch.setenv("FSK_SPARSE_HINT", hint)
+        set_tuning_env(monkeypatch, sparse_hint=hint)
     rng = np.random.default_rng(5)
     N, L, g, m = 700, 90, 9, 4
     A = rng.integers(1, 5, size=(N, L), dtype=np.int32)
@@ -1418,31 +1534,24 @@ def test_key_compaction_two_rare_symbols(native, port):
     want, _, _ = port.raw_counts(tokens, offsets, g, m, combos, threads=8)
     got = {}
     for rare in ("1", "0"):
-        os.environ["FSK_COMPACT_RARE"] = rare
-        try:
-            e = native.Engine(g, m, path=1)
-            e.load_sequences(tokens, offsets, 600, 300)
-            e.accumulate(combos)
-            e.finalize()
-            got[rare] = (e.get_counts(), e.stats()["compact_keys_avg"])
-            e.close()
-        finally:
-            os.environ.pop("FSK_COMPACT_RARE", None)
+        e = native.Engine(g, m, path=1, tuning={"compact_rare": rare})
+        e.load_sequences(tokens, offsets, 600, 300)
+        e.accumulate(combos)
+        e.finalize()
+        got[rare] = (e.get_counts(), e.stats()["compact_keys_avg"])
+        e.close()
     assert np.array_equal(got["1"][0], want) and np.array_equal(got["0"][0], want)
     assert 256 <= got["0"][1] <= got["1"][1] < 6 ** 4   # (the places' form takes every common key as present: a superset)
 
 
-@pytest.mark.parametrize("force", [None, "0", "1", "regs", "mark"])
+@pytest.mark.parametrize("force", [None, "0", "1", "mark"])
 def test_key_compaction_rare_symbol(native, port, monkeypatch, force):
-    """DNA with a few 'n' (config-3-like): key compaction on (auto / forced; through the direct-to-LDS compact
-    tile kernel, the default, and the register-staged one) and off give the oracle's counts; with compaction
-    the tile kernel multiplies far fewer keys than 5^4."""
-    if force == "regs":
-        monkeypatch.setenv("FSK_COMPACT_DMA", "0")
-    elif force == "mark":  # (the keys that occur from a marking pass over every window, not from the places of the rare symbol)
-        monkeypatch.setenv("FSK_COMPACT_RARE", "0")
+    """DNA with a few 'n' (config-3-like): key compaction on (auto / forced) and off give the oracle's counts; with
+    compaction the tile kernel multiplies far fewer keys than 5^4."""
+    if force == "mark":  # (the keys that occur from a marking pass over every window, not from the places of the rare symbol)
+        set_tuning_env(monkeypatch, compact_rare="0")
     elif force is not None:
-        monkeypatch.setenv("FSK_COMPACT", force)
+        set_tuning_env(monkeypatch, compact=force)
     rng = np.random.default_rng(77)
     N, L = 1100, 160
     X = rng.integers(1, 5, size=(N, L), dtype=np.int32)
@@ -1589,14 +1698,15 @@ def test_group_variance_chains(native, port, T):
 
 def test_group_deadline_on_a_late_exchange_kernel(native, monkeypatch):
     """Fail fast on the device side: engine 1's exchange stream is held by a (bounded, 3 s) spinning kernel in front
-    of band 0's all-reduce (FSK_FAULT, test-only), the deadline is 400 ms: finalize returns FSK_EDEVICE naming the
+    of band 0's all-reduce (the fault_* tuning keys of tests/hooks' build of the engine), the deadline is 400 ms: finalize returns FSK_EDEVICE naming the
     band within about the deadline instead of sitting in hipStreamSynchronize, the group is dead afterwards, and
     closing it (which waits for the spin to end by itself) does not hang. Then the same job without the fault."""
     import time
     d = load_golden("f4_ep300_exact")
     combos = np.asarray(d["combos"], dtype=np.int32)
-    monkeypatch.setenv("FSK_FAULT", "device:1:0:3000")
-    e = native.Engine(d["g"], d["m"], devices=[0, 0], collective=native.COLL_P2P, deadline_ms=400)
+    hooks = hooks_library(native)
+    e = native.Engine(d["g"], d["m"], devices=[0, 0], collective=native.COLL_P2P, deadline_ms=400, lib=hooks,
+                      tuning={"fault_kind": 2, "fault_rank": 1, "fault_band": 0, "fault_ms": 3000})
     e.load_sequences(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
     e.accumulate(combos)           # asynchronous: nothing waits here
     t0 = time.perf_counter()
@@ -1609,8 +1719,7 @@ def test_group_deadline_on_a_late_exchange_kernel(native, monkeypatch):
         e.accumulate(combos)
     assert "dead after an earlier failure" in str(ei2.value)
     e.close()
-    monkeypatch.delenv("FSK_FAULT")
-    e = native.Engine(d["g"], d["m"], devices=[0, 0], collective=native.COLL_P2P, deadline_ms=400)
+    e = native.Engine(d["g"], d["m"], devices=[0, 0], collective=native.COLL_P2P, deadline_ms=400, lib=hooks)
     e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
     assert np.array_equal(e.get_counts(), d["counts"])
     e.close()
@@ -1644,11 +1753,12 @@ def test_pybind_devices_dlpack_and_lazy_test_block(native, port):
     X = [tokens[offsets[i]:offsets[i + 1]].tolist() for i in range(len(offsets) - 1)]
     N, ntr = len(X), d["n_train"]
     sq = tri_to_square(d["tri"], N)
-    for kw in ({}, {"devices": [0]}, {"devices": [0, 0], "collective": "p2p"}, {"skip_test_block": False}):
+    for kw in ({"skip_test_block": "lazy"}, {"devices": [0], "skip_test_block": None}, {"devices": [0, 0], "collective": "p2p", "skip_test_block": "lazy"}, {}):
+        lazy = "skip_test_block" in kw      # (the default is the reference's: everything computed by compute_kernel)
         f = FastSK(g=d["g"], m=d["m"], **kw)
         f.compute_kernel(X[:ntr], X[ntr:])
         st = f.stats()
-        assert st["test_block_computed"] == (kw.get("skip_test_block") is False)
+        assert st["test_block_computed"] == (not lazy)
         assert st["devices"] == kw.get("devices", [0])
         if "devices" in kw:
             assert st["collective"] == ("p2p" if len(kw["devices"]) > 1 else "rccl") and st["comm_ranks"] == len(kw["devices"])
@@ -1663,7 +1773,7 @@ def test_pybind_devices_dlpack_and_lazy_test_block(native, port):
         f = FastSK(g=d["g"], m=d["m"], **kw)
         f.compute_kernel(X[:ntr], X[ntr:])
         assert np.array_equal(f.get_block(0, N, 0, ntr), sq[:, :ntr])          # no test x test cell: nothing recomputed
-        assert f.stats()["test_block_computed"] == (kw.get("skip_test_block") is False)
+        assert f.stats()["test_block_computed"] == (not lazy)
         assert np.array_equal(f.get_block(ntr, N, ntr, N), sq[ntr:, ntr:])      # now they are needed
         assert f.stats()["test_block_computed"]
         assert np.array_equal(f.get_counts_np(), d["counts"])

@@ -44,23 +44,21 @@ def main(iters=150, seed=0):
                 continue
             if name == "dense_compact" and sigma ** k > 4096:
                 continue
-            os.environ["FSK_COMPACT"] = env if path == 1 else "0"
-            os.environ["FSK_SPARSE_GLOBAL"] = env if path == 2 else "0"
-            os.environ.pop("FSK_SPARSE_GUARD_CAP", None)
+            tuning = {"compact": int(env) if path == 1 else 0, "sparse_global": int(env) if path == 2 else 0}
             if name == "sparse" and rng.random() < 0.3:
-                os.environ["FSK_SPARSE_GUARD_CAP"] = str(int(rng.choice([1, 64, 5000])))
-            # (round 4) key compaction from the places of the rare symbols, forced on and off; a rare symbol planted in half
-            # of the cases; the batches of an exact accumulate in two lanes, with batches of a few combos
-            for v in ("FSK_COMPACT_RARE", "FSK_SPARSE_EXACT_LANES", "FSK_SPARSE_BATCH_RECORDS"):
-                os.environ.pop(v, None)
+                tuning["guard_cap"] = int(rng.choice([1, 64, 5000]))
+            # key compaction from the places of the rare symbols, forced on and off; a rare symbol planted in half of the cases;
+            # the batches of an exact accumulate in two lanes, with batches of a few combos; the unpacked entry format
             if name == "dense_compact":
-                os.environ["FSK_COMPACT_RARE"] = str(int(rng.integers(0, 2)))
+                tuning["compact_rare"] = int(rng.integers(0, 2))
             if path == 2 and rng.random() < 0.5:
-                os.environ["FSK_SPARSE_EXACT_LANES"] = "2"
-                os.environ["FSK_SPARSE_BATCH_RECORDS"] = str(max(1, int(rng.integers(1, 5)) * int(sum(max(0, int(L) - g + 1) for L in lens))))
+                tuning["sparse_exact_lanes"] = 2
+                tuning["sparse_batch_records"] = max(1, int(rng.integers(1, 5)) * int(sum(max(0, int(L) - g + 1) for L in lens)))
+            if path == 2 and rng.random() < 0.3:
+                tuning["sparse_unpacked"] = 1
             if os.environ.get("FSK_STRESS_VERBOSE"):
-                print("   %s guard=%s" % (name, os.environ.get("FSK_SPARSE_GUARD_CAP")), flush=True)
-            e = _native.Engine(g, m, path=path)
+                print("   %s %s" % (name, tuning), flush=True)
+            e = _native.Engine(g, m, path=path, tuning=tuning)
             e.load_sequences(tokens, offsets, ntr, N - ntr)
             if rng.random() < 0.5 or N < 256:
                 # (several calls: the sparse dataflow enqueues all batches but the first ahead of their size;
@@ -76,8 +74,7 @@ def main(iters=150, seed=0):
             res[name] = (e.get_counts(), e.get_triangle())
             e.close()
         if N - ntr > 0:  # skip_test_block on the sparse dataflow: exactly the test x test cells off the diagonal stay zero
-            os.environ["FSK_SPARSE_GLOBAL"] = "0" if it % 2 else "1"
-            e = _native.Engine(g, m, path=2, skip_test_block=True)
+            e = _native.Engine(g, m, path=2, skip_test_block=True, tuning={"sparse_global": it % 2, "sparse_unpacked": (it // 2) % 2})
             e.load_sequences(tokens, offsets, ntr, N - ntr)
             e.accumulate(combos)
             e.finalize()

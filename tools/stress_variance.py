@@ -38,15 +38,13 @@ def main(iters=200, seed=0):
         for path in (1, 2):
             if path == 1 and sigma ** k > 4096:
                 continue
-            for var in ("FSK_SPARSE_SYNC", "FSK_SPARSE_GUARD_CAP", "FSK_LIST_MAX_WORDS"):
-                os.environ.pop(var, None)
-            mode = "default"
+            mode, tuning = "default", {}
             if path == 2:
                 mode = str(rng.choice(["default", "sync", "overflow", "ungrouped"]))
-                if mode == "sync": os.environ["FSK_SPARSE_SYNC"] = "1"
-                if mode == "overflow": os.environ["FSK_SPARSE_GUARD_CAP"] = str(int(rng.choice([1, 50, 2000])))
-                if mode == "ungrouped": os.environ["FSK_LIST_MAX_WORDS"] = str(int(rng.choice([10, 1000])))
-            e = _native.Engine(g, m, t=T, approx=True, delta=delta, max_iters=max_iters, path=path)
+                if mode == "sync": tuning["sparse_sync"] = 1
+                if mode == "overflow": tuning["guard_cap"] = int(rng.choice([1, 50, 2000]))
+                if mode == "ungrouped": tuning["list_max_words"] = int(rng.choice([10, 1000]))
+            e = _native.Engine(g, m, t=T, approx=True, delta=delta, max_iters=max_iters, path=path, tuning=tuning)
             e.set_combo_order(order)
             e.compute(tokens, offsets, ntr, N - ntr)
             what = (it, path, mode, sigma, g, m, N, T, max_iters, delta)

@@ -11,7 +11,7 @@ for name in ("f7_cfg2_ep300_exact", "f7_cfg3_ep47848_100combos"):
     tokens, offsets, ntr, nte, _, _ = load_tokens(d["data"])
     combos = np.sort(d["combos"]).astype(np.int32)
     for sp in (0, 1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
-        os.environ["FSK_TILE_SPLITS"] = str(sp)
+        os.environ["FSK_TUNING"] = "tile_splits=%d" % sp
         e = _native.Engine(d["g"], d["m"], profile=True)
         e.load_sequences(tokens, offsets, ntr, nte)
         e.accumulate(combos); e.synchronize(); e.reset_counts()

@@ -4,7 +4,8 @@ NAME=${1:-f7_cfg4_prot219_exact}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/trace4
 rm -rf "$O"; mkdir -p "$O"
-cat > /tmp/run4.py <<PY
+RUN=$(mktemp /tmp/fsk_trace_XXXXXX.py)
+cat > "$RUN" <<PY
 import os, sys, time
 sys.path.insert(0, "$R"); sys.path.insert(0, "$R/tests")
 from conftest import load_golden, load_tokens
@@ -18,7 +19,7 @@ for _ in range(3):
     time.sleep(0.01)
 PY
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d "$O/t" -- python3 /tmp/run4.py > "$O/out.txt" 2> "$O/err.txt"
+rocprofv3 --kernel-trace --output-format csv -d "$O/t" -- python3 "$RUN" > "$O/out.txt" 2> "$O/err.txt"
 cd "$R" && python3 - <<'PY'
 import csv, glob, os
 f = max(glob.glob("gpurun_out/trace4/t/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Config 1 (variance mode, sparse dataflow) a few times with FSK_TRACE on: where its wall time goes."""
+"""Config 1 (variance mode, sparse dataflow) a few times with the tuning key trace=1: where its wall time goes."""
 import os, sys, time
 import numpy as np
-os.environ["FSK_TRACE"] = "1"
+os.environ["FSK_TUNING"] = "trace=1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_golden, load_tokens
