@@ -929,3 +929,29 @@ def test_emu_sparse_paired_unit_words(emu_lib, port, monkeypatch, skip):
             assert np.array_equal(got[keep], raw[keep]), (pairs, how)
             assert skip or e.stats()["cell_updates"] == U
             e.close()
+
+
+@pytest.mark.parametrize("skip", [False, True])
+def test_emu_sparse_long_runs_grouped_entries(emu_lib, port, skip):
+    """Runs of hundreds of entries (400 sequences over 16 keys): entries of more than 48 partners are taken in groups of 16 list
+    neighbours that share the reads of their partners (k_sx_emit, class 3) — runs that begin before the tile, own cells of
+    multiplicities above 1, groups that span two runs; with skip_test_block they go a wave each (class 2)."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(77)
+    N, ntr, g, m = 400, 250, 5, 3
+    X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(14, 30, size=N)]
+    tokens, offsets = _native.flatten(X)
+    combos = np.array([0, 4, 9], dtype=np.int32)
+    raw, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=4)
+    e = _native.Engine(g, m, path=2, lib=emu_lib, skip_test_block=skip)
+    e.load_sequences(tokens, offsets, ntr if skip else N, N - ntr if skip else 0)
+    e.accumulate(combos)
+    e.finalize()
+    got = e.get_counts()
+    if skip:
+        a, b = np.tril_indices(N)
+        keep = (b < ntr) | (a == b)
+        assert np.array_equal(got[keep], raw[keep]) and not got[~keep].any()
+    else:
+        assert np.array_equal(got, raw) and e.stats()["cell_updates"] == U
+    e.close()
