@@ -59,7 +59,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 # v_dot8_u32_u4 / v_dot4_u32_u8 issue at HALF the v_fma_f32 rate on gfx950 (measured:
-# profiles/r01_ubench_valu_rates.txt): 64 lanes/clk/CU. Peak = CUs * 64 lanes * 8 MACs * 2.4 GHz.
+# profiles/ubench_valu_rates.txt): 64 lanes/clk/CU. Peak = CUs * 64 lanes * 8 MACs * 2.4 GHz.
 VALU_DOT8_PEAK_TMACS = 256 * 64 * 8 * 2.4e9 / 1e12  # = 314.6 T MAC/s
 KERNEL_FILES = ("fastsk_amd/csrc/fsk_kernels_dense.h", "fastsk_amd/csrc/fsk_tile_kernel_dma.inc")
 
