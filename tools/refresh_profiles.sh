@@ -5,7 +5,7 @@
 # and the micro-benchmarks. Raw output lands in gpurun_out/prof/ and gpurun_out/pmc/;
 # tools/collect_profiles.py turns it into the files under profiles/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
 rm -rf "$O"; mkdir -p "$O"
