@@ -810,7 +810,7 @@ def test_emu_many_flagged_rows_in_one_stage(emu_lib, port):
 # ---- the unpacked entry format of the sparse dataflow (N >= 65,535 sequences or a sequence of >= 65,536 windows): the kernel
 # instantiations k_sx_seg_write<RecT, false> and k_sx_emit<DIRECT | streams, SKIP, false> (countAndUpdateTri, shared.cpp:268-333)
 @pytest.mark.parametrize("global_pairs", ["0", "1"])
-@pytest.mark.parametrize("name", ["f5_prot11_exact", "f3_ragged_sigma7_g6m3", "f3_lowcomplexity_g5m2", "f5_prot11_variance_T1_it9"])
+@pytest.mark.parametrize("name", ["f6_prot219_skipvar16", "f3_ragged_sigma7_g6m3", "f3_lowcomplexity_g5m2", "f5_prot11_variance_T1_it9"])
 def test_emu_sparse_unpacked_entries_forced(emu_lib, monkeypatch, name, global_pairs):
     """tuning sparse_unpacked=1: the general entry format on the golden vectors, through the update streams and as atomics,
     exact and variance mode."""

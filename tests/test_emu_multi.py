@@ -263,7 +263,7 @@ def rccl(emu_lib):
 
 
 @pytest.mark.parametrize("name,devices", [("f4_ep300_exact", [0, 1]), ("f4_ep300_exact", [3, 1, 0, 2]), ("f4_ep300_exact", list(range(8))),
-                                          ("f3_ragged_sigma7_g6m3", [5, 2, 7, 1]), ("f5_prot11_exact", [0, 1, 2, 3, 4, 5, 6, 7]),
+                                          ("f3_ragged_sigma7_g6m3", [5, 2, 7, 1]), ("f6_prot219_skipvar16", [0, 1, 2, 3, 4, 5, 6, 7]),
                                           ("f1_small_g3m1", [0, 1, 2, 3, 4, 5, 6, 7])])
 def test_rccl_group_exact_equals_golden(rccl, name, devices):
     """fsk_create_multi(collective = RCCL) with 2, 4 and 8 ranks: ncclCommInitAll over the listed devices, one int32
