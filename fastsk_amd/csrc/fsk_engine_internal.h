@@ -106,6 +106,7 @@ using fsk_detail::DevBuf;
     X(list_max_words, 0, 0, (int64_t)1 << 31, "sparse: update words of one batch beyond which its pairs go to K with atomics (0: 2^31)") \
     X(seg_scan_chunked, 0, 0, 1, "sparse: the three-launch segment scan whatever the tile count")                                    \
     X(extract_slots, 0, 0, 4, "sparse: slots per k_sx_extract_win workgroup, 1 or 4 (0: by the size of the launch)")                  \
+    X(sparse_share, 0, -1, 254, "sparse: leading kept positions sorted once per group of consecutive combos that share them (0: by cost; -1: never)") \
     X(collective, 0, 0, 2, "fsk_create_multi: FSK_COLL_* when fsk_config.collective is FSK_COLL_AUTO")                                \
     X(deadline_ms, 120000, -1, 86400000, "fsk_create_multi: the fail-fast bound when fsk_config.deadline_ms is 0 (negative: none)")   \
     FSK_TUNING_TEST_KEYS(X)
@@ -138,7 +139,10 @@ struct SxScratch {
     DevBuf<int> d_tile_lrh, d_tile_rs, d_tile_lth, d_tile_ts;
     DevBuf<uint2> d_E;                    // entries: {sequence, multiplicity} (or the packed format)
     DevBuf<u64> d_sxstat;
+    DevBuf<uint32_t> d_group_of, d_group_head, d_winp;  // shared prefixes (k_sx_group_tables): slot -> group, group -> first slot,
+    DevBuf<unsigned char> d_part;                        // the windows and part records of every group in presorted order
     void release() {
+        d_group_of.release(); d_group_head.release(); d_winp.release(); d_part.release();
         for (auto& k : d_keys) k.release();
         d_blockhist.release(); d_totals.release(); d_tile_ent.release(); d_ebase.release(); d_Pk.release(); d_Tk.release();
         d_ucount.release(); d_uchunk.release(); d_utot.release(); d_list_off.release(); d_ulist.release(); d_part_base.release();

@@ -62,6 +62,84 @@ void plan_owner_bands(fsk_engine* e) {
     e->owner_ready = false;
 }
 
+// The LSD passes over `bits` bits from bit `shift0` of the records of n_slots slots (the digits of the first pass have been
+// counted by whoever wrote the records). *cur: which of rec[0] / rec[1] holds the result.
+template <typename T>
+int sx_sort(fsk_engine* e, SxScratch& S, hipStream_t stream, T* const rec[2], uint32_t nfeat, uint32_t tps, uint32_t n_slots, int shift0,
+            int bits, int* cur_out) {
+    const int passes = (bits + 7) / 8;
+    // the bits split evenly over the passes: 19 bits sort as 7 + 6 + 6, not 8 + 8 + 3 (a ballot per bit and record)
+    auto pass_bits = [&](int p) { return bits / passes + (p < bits % passes ? 1 : 0); };
+    int cur = 0;
+    for (int p = 0, shift = shift0; p < passes; shift += pass_bits(p), ++p) {
+        const int nbits = pass_bits(p);
+        if (p > 0)
+            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_hist<T>), dim3(tps, n_slots), dim3(256), 0, stream, (const T*)rec[cur], nfeat, tps, shift,
+                       (1u << nbits) - 1u, S.d_blockhist.p);
+        FSK_LAUNCH(fsk::k_sx_scan_slot, dim3(n_slots), dim3(1024), 0, stream, S.d_blockhist.p, tps, S.d_totals.p);
+        {   // (function pointers: a template-id with a comma cannot pass through the launch macro)
+            auto k_scatter = nbits <= 4 ? fsk::k_sx_scatter<T, 4> : nbits == 5 ? fsk::k_sx_scatter<T, 5>
+                             : nbits == 6 ? fsk::k_sx_scatter<T, 6> : nbits == 7 ? fsk::k_sx_scatter<T, 7>
+                                                                                 : fsk::k_sx_scatter<T, 8>;
+            FSK_LAUNCH(k_scatter, dim3(fsk::xcd_grid(tps * n_slots)), dim3(256), 0, stream, (const T*)rec[cur], rec[cur ^ 1], nfeat, tps, n_slots,
+                       shift, nbits, (const uint32_t*)S.d_blockhist.p, (const uint32_t*)S.d_totals.p);
+        }
+        cur ^= 1;
+        e->st.launches += 3;
+    }
+    *cur_out = cur;
+    return FSK_OK;
+}
+inline int sx_first_pass_bits(int bits) { const int passes = (bits + 7) / 8; return bits / passes + (bits % passes ? 1 : 0); }
+inline int sx_bits_below(u64 v) { int b = 0; while (b < 64 && ((u64)1 << b) < v) ++b; return b; }  // bits that hold 0 .. v - 1
+
+// Shared prefixes (k_sx_group_tables in fsk_sparse_kernels.inc): how many leading kept positions the slots of this batch
+// sort once per group. 0: none (every slot sorts its whole key).
+struct SxShare { int share = 0, topbits = 0, lowbits = 0, wb = 0; uint32_t groups = 0; bool pre64 = false; };
+SxShare sx_plan_share(fsk_engine* e, const int32_t* combos, int nb, int recbits_max) {
+    SxShare best;
+    const int k = e->k, want = (int)e->tune.sparse_share;
+    if (want < 0 || k < 2 || nb < 2 || !e->win_words || e->nfeat < 2) return best;
+    // (the presort is half a dozen launches: a batch below 2^24 records does not win them back)
+    if (want == 0 && (u64)nb * (u64)e->nfeat < ((u64)1 << 24)) return best;
+    // groups[s] = runs of consecutive slots with the same first s kept positions
+    std::vector<uint32_t> groups((size_t)k, 1u);
+    for (int i = 1; i < nb; ++i) {
+        const unsigned char *a = &e->all_pos[(size_t)combos[i] * k], *b = &e->all_pos[(size_t)combos[i - 1] * k];
+        int lcp = 0;
+        while (lcp < k && a[lcp] == b[lcp]) ++lcp;
+        for (int s = lcp + 1; s < k; ++s) groups[s] += 1u;
+    }
+    const int wb = std::max(1, sx_bits_below((u64)e->nfeat));
+    auto passes = [](int bits) { return (bits + 7) / 8; };
+    // In units of one scatter pass over a slot's records. Measured on config 4 (one MI355X, 250 slots of 460 K windows a batch,
+    // profiles/r05_shared_prefix_ab.txt): a slot's scatter pass 0.74 us, its histogram 0.33, its extraction 0.6; a GROUP costs
+    // its gather (20 bytes written, 24 read at random per window: 9 passes' worth), its extraction (2.2; twice that with 8-byte
+    // presort records), ~1.65 per presort pass, and 2.4 for the window loads its slots no longer share with their neighbours.
+    auto cost_slot = [&](int bits) { return 0.8 + passes(bits) + 0.45 * (passes(bits) - 1); };
+    const double plain = nb * cost_slot(e->sx_keybits);
+    double best_cost = want > 0 ? 1e300 : 0.93 * plain;
+    for (int s = 1; s < k; ++s) {
+        if (want > 0 && s != std::min(want, k - 1)) continue;
+        int tb, lb;
+        if (e->sx_symbits) { tb = s * e->sx_symbits; lb = (k - s) * e->sx_symbits; }
+        else {
+            u64 tv = 1, lv = 1;
+            for (int c = 0; c < s; ++c) tv *= e->sigma;
+            for (int c = s; c < k; ++c) lv *= e->sigma;
+            tb = sx_bits_below(tv); lb = sx_bits_below(lv);
+        }
+        if (tb < 1 || lb < 1 || tb + lb + e->sx_sb > recbits_max || tb + wb > 64) continue;
+        const bool pre64 = tb + wb > 32;
+        const double c = nb * cost_slot(lb) + groups[s] * (13.6 + (pre64 ? 2.2 : 0.0) + 1.65 * passes(tb));
+        if (c < best_cost) {
+            best_cost = c;
+            best.share = s; best.topbits = tb; best.lowbits = lb; best.wb = wb; best.groups = groups[s]; best.pre64 = pre64;
+        }
+    }
+    return best;
+}
+
 // `pos_pin` / `stat_pin`: pinned staging of this batch (positions in, {pairs, words} out), untouched by
 // anyone else until the batch's counts have been read. `guard_cap` == 0: the call waits for the
 // counts and sizes the streams exactly; else it only enqueues, for streams of at most guard_cap words.
@@ -79,12 +157,15 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     if (nrec == 0) return FSK_OK;
     // Only the k-mer bits are sorted: the records of a slot are generated in sequence order and every
     // LSD pass is stable, so equal k-mers end up contiguous with their sequence ids ascending.
-    const int keybits = e->sx_keybits;
     const int sb = e->sx_sb;
+    // (consecutive combos keep the same leading positions for long stretches: those are sorted once per group)
+    const SxShare sh = nb > 16 ? sx_plan_share(e, combos, nb, 8 * (int)sizeof(RecT)) : SxShare();
+    const int keybits = sh.share ? sh.lowbits : e->sx_keybits;  // what every slot sorts
+    if (e->trace())
+        fprintf(stderr, "[fsk] sparse batch: %d slots, shared leading positions %d (%u groups, %d + %d key bits; plain %d)\n", nb, sh.share, sh.groups,
+                sh.topbits, sh.lowbits, e->sx_keybits);
     const int passes = (keybits + 7) / 8;
-    // the k-mer bits split evenly over the passes: 19 bits sort as 7 + 6 + 6, not 8 + 8 + 3 (a ballot per bit and record)
-    auto pass_bits = [&](int p) { return keybits / passes + (p < keybits % passes ? 1 : 0); };
-    const uint32_t dmask = (1u << pass_bits(0)) - 1u;  // (the extraction counts the first pass's digits)
+    const uint32_t dmask = (1u << sx_first_pass_bits(keybits)) - 1u;  // (the extraction counts the first pass's digits)
     const uint32_t tps = (nfeat + fsk::SX_TILE - 1) / fsk::SX_TILE;   // sort tiles per slot
     const uint32_t tpg = (nfeat + fsk::SG_TILE - 1) / fsk::SG_TILE;   // segment tiles per slot
     const uint32_t ntiles = tpg * (uint32_t)nb;
@@ -92,7 +173,9 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     const int pairs = lists && e->sx_pairs ? 1 : 0;  // (unit products as bare cells, two to a word: plan_owner_bands)
     const bool slot16 = slot_stride != 0 && e->sx_slot16_used;  // (u16 slot triangles: set by accumulate_sparse for a deferred batch)
     const uint32_t O = e->n_owners;
-    for (int b = 0; b < 2; ++b) FSK_HIP(S.d_keys[b].reserve(nrec * sizeof(RecT)));
+    // (the presort's records, 4 or 8 bytes a window and group, go through the same two buffers first)
+    const size_t pre_bytes = sh.share ? (size_t)sh.groups * nfeat * (sh.pre64 ? 8 : 4) : 0;
+    for (int b = 0; b < 2; ++b) FSK_HIP(S.d_keys[b].reserve(std::max(pre_bytes, nrec * sizeof(RecT))));
     FSK_HIP(S.d_blockhist.reserve((size_t)256 * tps * nb));
     FSK_HIP(S.d_totals.reserve((size_t)256 * nb));
     FSK_HIP(S.d_tile_ent.reserve(ntiles));
@@ -168,7 +251,54 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     fsk::SxSrc src{};
     src.win = e->d_win.p; src.feat_seq = e->d_featseq.p; src.combo_pos = pos_tab;
     src.k = e->k; src.sb = sb; src.bits = e->bits; src.by_id = by_id ? 1 : 0; src.sigma = e->sigma; src.symbits = e->sx_symbits; src.ids = ids;
-    if (ww) {
+    src.c0 = 0;
+    if (sh.share) {
+        // the presort: the windows in the order of their leading part, once per group of slots; every slot then extracts from
+        // its group's copy and sorts by the rest of its key alone
+        const uint32_t G = sh.groups;
+        FSK_HIP(S.d_group_of.reserve((size_t)nb));
+        FSK_HIP(S.d_group_head.reserve((size_t)nb));
+        FSK_HIP(S.d_winp.reserve((size_t)G * nfeat * ww));
+        FSK_HIP(S.d_part.reserve((size_t)G * nfeat * sizeof(RecT)));
+        FSK_LAUNCH(fsk::k_sx_group_tables, dim3(1), dim3(1024), 0, stream, src, (uint32_t)nb, sh.share, S.d_group_of.p, S.d_group_head.p);
+        const uint32_t dmask_top = (1u << sx_first_pass_bits(sh.topbits)) - 1u;
+        const dim3 ggrid((nfeat + 255u) / 256u, G);
+        RecT* const part = reinterpret_cast<RecT*>(S.d_part.p);
+        int rcs = FSK_OK, pcur = 0;
+        if (!sh.pre64) {
+            uint32_t* pre[2] = {(uint32_t*)S.d_keys[0].p, (uint32_t*)S.d_keys[1].p};
+            auto k_ge = ww == 2 ? (small ? fsk::k_sx_group_extract<uint32_t, 2, true> : fsk::k_sx_group_extract<uint32_t, 2, false>)
+                                : (small ? fsk::k_sx_group_extract<uint32_t, 4, true> : fsk::k_sx_group_extract<uint32_t, 4, false>);
+            FSK_LAUNCH(k_ge, dim3(tps, G), dim3(256), 0, stream, src, (const uint32_t*)S.d_group_head.p, sh.share, sh.wb, nfeat, tps, pre[0],
+                       S.d_blockhist.p, dmask_top);
+            rcs = sx_sort<uint32_t>(e, S, stream, pre, nfeat, tps, G, sh.wb, sh.topbits, &pcur);
+            if (rcs) return rcs;
+            auto k_gg = ww == 2 ? fsk::k_sx_group_gather<uint32_t, RecT, 2> : fsk::k_sx_group_gather<uint32_t, RecT, 4>;
+            FSK_LAUNCH(k_gg, ggrid, dim3(256), 0, stream, (const uint32_t*)pre[pcur], (const uint32_t*)e->d_win.p, (const uint32_t*)e->d_featseq.p,
+                       nfeat, sh.wb, sh.lowbits + sb, S.d_winp.p, part);
+        } else {
+            u64* pre[2] = {(u64*)S.d_keys[0].p, (u64*)S.d_keys[1].p};
+            auto k_ge = ww == 2 ? fsk::k_sx_group_extract<u64, 2, false> : fsk::k_sx_group_extract<u64, 4, false>;
+            FSK_LAUNCH(k_ge, dim3(tps, G), dim3(256), 0, stream, src, (const uint32_t*)S.d_group_head.p, sh.share, sh.wb, nfeat, tps, pre[0],
+                       S.d_blockhist.p, dmask_top);
+            rcs = sx_sort<u64>(e, S, stream, pre, nfeat, tps, G, sh.wb, sh.topbits, &pcur);
+            if (rcs) return rcs;
+            auto k_gg = ww == 2 ? fsk::k_sx_group_gather<u64, RecT, 2> : fsk::k_sx_group_gather<u64, RecT, 4>;
+            FSK_LAUNCH(k_gg, ggrid, dim3(256), 0, stream, (const u64*)pre[pcur], (const uint32_t*)e->d_win.p, (const uint32_t*)e->d_featseq.p,
+                       nfeat, sh.wb, sh.lowbits + sb, S.d_winp.p, part);
+        }
+        e->st.launches += 3;
+        src.win = S.d_winp.p;
+        src.c0 = sh.share;
+        const bool four = e->tune.extract_slots ? e->tune.extract_slots == 4 : (u64)tps * (u64)nb >= 8192;
+#define FSK_EXTRACT_SHARED(SPW)                                                                                              \
+    (ww == 2 ? (small ? fsk::k_sx_extract_shared<RecT, 2, R32, SPW> : fsk::k_sx_extract_shared<RecT, 2, false, SPW>)          \
+             : (small ? fsk::k_sx_extract_shared<RecT, 4, R32, SPW> : fsk::k_sx_extract_shared<RecT, 4, false, SPW>))
+        auto k_ex = four ? FSK_EXTRACT_SHARED(4) : FSK_EXTRACT_SHARED(1);
+#undef FSK_EXTRACT_SHARED
+        FSK_LAUNCH(k_ex, dim3(tps, four ? ((uint32_t)nb + 3u) / 4u : (uint32_t)nb), dim3(256), 0, stream, src, (const uint32_t*)S.d_group_of.p,
+                   (const RecT*)part, nfeat, tps, (uint32_t)nb, rec[0], S.d_blockhist.p, dmask, zeroed_stats);
+    } else if (ww) {
         // (four slots per workgroup share the window loads when that still leaves a few thousand workgroups)
         const bool four = e->tune.extract_slots ? e->tune.extract_slots == 4 : (u64)tps * (u64)nb >= 8192;
 #define FSK_EXTRACT_WIN(SPW)                                                                                          \
@@ -187,22 +317,9 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
 
     e->tic(stream);
     int cur = 0;
-    for (int p = 0, shift = sb; p < passes; shift += pass_bits(p), ++p) {
-        const int nbits = pass_bits(p);
-        if (p > 0)  // (the extraction counted the first pass's digits)
-            FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_hist<RecT>), dim3(tps, nb), dim3(256), 0, stream, rec[cur], nfeat, tps, shift,
-                       (1u << nbits) - 1u, S.d_blockhist.p);
-        FSK_LAUNCH(fsk::k_sx_scan_slot, dim3(nb), dim3(1024), 0, stream, S.d_blockhist.p, tps, S.d_totals.p);
-        {   // (function pointers: a template-id with a comma cannot pass through the launch macro)
-            auto k_scatter = nbits <= 4 ? fsk::k_sx_scatter<RecT, 4> : nbits == 5 ? fsk::k_sx_scatter<RecT, 5>
-                             : nbits == 6 ? fsk::k_sx_scatter<RecT, 6> : nbits == 7 ? fsk::k_sx_scatter<RecT, 7>
-                                                                                     : fsk::k_sx_scatter<RecT, 8>;
-            FSK_LAUNCH(k_scatter, dim3(fsk::xcd_grid(tps * (uint32_t)nb)), dim3(256), 0, stream, (const RecT*)rec[cur], rec[cur ^ 1], nfeat, tps,
-                       (uint32_t)nb, shift, nbits,
-                       (const uint32_t*)S.d_blockhist.p, (const uint32_t*)S.d_totals.p);
-        }
-        cur ^= 1;
-        e->st.launches += 3;
+    {
+        const int rcs = sx_sort<RecT>(e, S, stream, rec, nfeat, tps, (uint32_t)nb, sb, keybits, &cur);
+        if (rcs) return rcs;
     }
     e->toc(&e->st.ms_sort, stream);
     e->st.sort_records += nrec;

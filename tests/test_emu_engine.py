@@ -955,3 +955,52 @@ def test_emu_sparse_long_runs_grouped_entries(emu_lib, port, skip):
     else:
         assert np.array_equal(got, raw) and e.stats()["cell_updates"] == U
     e.close()
+
+
+@pytest.mark.parametrize("case", ["protein_k4", "sigma300_u64", "bitfield_u128", "golden_k3"])
+def test_emu_sparse_shared_leading_positions(emu_lib, port, monkeypatch, case):
+    """Shared prefixes (k_sx_group_tables ... k_sx_extract_shared): the windows are sorted by the leading kept positions once per
+    group of consecutive slots that share them, every slot then sorts the rest of its key alone. Forced at every prefix length
+    (tuning sparse_share; the product decides by cost, from 2^24 records a batch on): 32-, 64- and 128-bit sort records, 4- and
+    8-byte presort records, a combo list with repeated and non-consecutive ids (groups of one), split calls, skip_test_block."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(5)
+    skip = False
+    if case == "golden_k3":
+        d = load_golden("f3_ragged_sigma7_g6m3")
+        tokens, offsets, g, m, N, ntr = d["tokens"], d["offsets"], d["g"], d["m"], d["n_train"] + d["n_test"], d["n_train"]
+        combos = np.asarray(d["combos"], dtype=np.int32)
+        shares = (1, 2)
+    else:
+        if case == "protein_k4":
+            sigma, g, m, N, shares, skip = 20, 7, 3, 70, (1, 2, 3), True
+        elif case == "sigma300_u64":
+            sigma, g, m, N, shares = 300, 7, 3, 40, (1, 3)         # 300^4 > 2^32: 64-bit records
+        else:
+            sigma, g, m, N, shares = 200, 16, 4, 24, (1, 5, 8)  # 200^12 > 2^62: bit-field keys in 128-bit records; 8-byte presort records
+                                                                  # (5), a leading part no presort record holds (8: sorted plainly)
+        X = [rng.integers(1, sigma + 1, size=int(L)).astype(np.int32) for L in rng.integers(g + 4, g + 22, size=N)]
+        X[3][:] = 2
+        tokens, offsets = _native.flatten(X)
+        ntr = N * 2 // 3
+        nc = port.num_combos(g, m)
+        first = 0 if nc < 40 else int(rng.integers(0, nc - 40))
+        combos = np.arange(first, min(nc, first + 35), dtype=np.int32)
+        if case == "protein_k4":  # (any list is a valid call: repeats, a jump back)
+            combos = np.concatenate([combos, combos[5:8], np.asarray([1, 30, 2], dtype=np.int32)])
+    raw, _, _ = port.raw_counts(tokens, offsets, g, m, combos, threads=4)
+    a, b = np.tril_indices(N)
+    keep = (b < ntr) | (a == b) if skip else np.ones(len(a), dtype=bool)
+    for share in shares:
+        for split in (False, True):
+            set_tuning_env(monkeypatch, sparse_share=str(share))
+            e = _native.Engine(g, m, path=2, lib=emu_lib, skip_test_block=skip)
+            e.load_sequences(tokens, offsets, ntr, N - ntr)
+            if split:
+                e.accumulate(combos[:19])
+                e.accumulate(combos[19:])
+            else:
+                e.accumulate(combos)
+            e.finalize()
+            assert np.array_equal(e.get_counts()[keep], raw[keep]), (case, share, split)
+            e.close()

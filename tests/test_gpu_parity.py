@@ -664,6 +664,52 @@ def test_sparse_paired_unit_words(native, port, monkeypatch, skip):
                 e.close()
 
 
+@pytest.mark.parametrize("share", ["0", "1", "2", "3", "-1"])
+def test_sparse_shared_leading_positions_config4(native, monkeypatch, share):
+    """Shared prefixes: BASELINE config 4 (1001 consecutive combos, k = 4 of 20 symbols — the batches are large enough for the
+    product to share by itself: share 0) with the windows presorted by the first 1, 2, 3 kept positions per group of slots
+    (4- and 8-byte presort records) and never: the reference's own triangle."""
+    set_tuning_env(monkeypatch, sparse_share=share)
+    d = load_golden("f7_cfg4_prot219_exact")
+    tokens, offsets, ntr, nte, _, _ = load_tokens(d["data"])
+    e = native.Engine(d["g"], d["m"], path=2)
+    e.compute(tokens, offsets, ntr, nte)
+    counts = e.get_counts()
+    assert np.array_equal(counts[d["sample_cells"]], d["sample_counts"]) and sha(counts) == d["counts_sha256"], share
+    e.close()
+
+
+def test_sparse_shared_leading_positions_lists(native, port, monkeypatch):
+    """The same on arbitrary combo lists (non-consecutive ids, repeats, jumps back: groups of one slot), 64-bit records (300
+    symbols), skip_test_block, split calls and row bands — the oracle's counts."""
+    rng = np.random.default_rng(77)
+    for sigma, g, m, N, L, shares in ((20, 7, 3, 900, 60, ("1", "2", "3")), (300, 7, 3, 500, 40, ("1", "3"))):
+        X = [rng.integers(1, sigma + 1, size=int(n)).astype(np.int32) for n in rng.integers(g + 4, L, size=N)]
+        X[3][:] = 2
+        tokens, offsets = native.flatten(X)
+        ntr = N * 2 // 3
+        combos = np.concatenate([np.arange(35, dtype=np.int32), np.asarray([7, 7, 1, 30, 2, 34, 33], dtype=np.int32)])
+        raw, _, _ = port.raw_counts(tokens, offsets, g, m, combos, threads=min(32, os.cpu_count() or 8))
+        a, b = np.tril_indices(N)
+        for skip in (False, True):
+            keep = (b < ntr) | (a == b) if skip else np.ones(len(a), dtype=bool)
+            for share in shares:
+                set_tuning_env(monkeypatch, sparse_share=share)
+                for how in ("whole", "two calls", "row bands"):
+                    e = native.Engine(g, m, path=2, skip_test_block=skip)
+                    e.load_sequences(tokens, offsets, ntr, N - ntr)
+                    if how == "whole":
+                        e.accumulate(combos)
+                    elif how == "two calls":
+                        e.accumulate(combos[:20]); e.accumulate(combos[20:])
+                    else:
+                        for lo, hi in ((0, 256), (256, N)):
+                            e.accumulate_rows(combos, lo, hi)
+                    e.finalize()
+                    assert np.array_equal(e.get_counts()[keep], raw[keep]), (sigma, skip, share, how)
+                    e.close()
+
+
 def test_pybind_surface_on_gpu(native):
     """The drop-in class: same calls as the reference's users make (test/run_check.py:45-49)."""
     from fastsk import FastSK

@@ -35,6 +35,9 @@ def main(iters=150, seed=0):
         tokens, offsets = _native.flatten(X)
         nc = _native.library().num_combos(g, m)
         combos = np.unique(rng.integers(0, nc, size=int(rng.integers(1, 24)))).astype(np.int32)
+        if rng.random() < 0.3:  # a long run of consecutive combos (with a few others): slots that share their leading positions
+            first = int(rng.integers(0, nc))
+            combos = np.concatenate([combos[:3], np.arange(first, min(nc, first + int(rng.integers(17, 60))), dtype=np.int32)]).astype(np.int32)
         ntr = int(rng.integers(1, N + 1))
         if os.environ.get("FSK_STRESS_VERBOSE"):  # (a crash loses the buffered line: say what is about to run)
             print("iter %d: sigma=%d g=%d m=%d N=%d Lmax=%d ntr=%d combos=%s" % (it, sigma, g, m, N, hi, ntr, combos.tolist()), flush=True)
@@ -56,6 +59,8 @@ def main(iters=150, seed=0):
                 tuning["sparse_batch_records"] = max(1, int(rng.integers(1, 5)) * int(sum(max(0, int(L) - g + 1) for L in lens)))
             if path == 2 and rng.random() < 0.3:
                 tuning["sparse_unpacked"] = 1
+            if path == 2 and k >= 2 and rng.random() < 0.6:  # windows presorted by the first 1 .. k - 1 kept positions per group of slots
+                tuning["sparse_share"] = int(rng.integers(1, k))
             if os.environ.get("FSK_STRESS_VERBOSE"):
                 print("   %s %s" % (name, tuning), flush=True)
             e = _native.Engine(g, m, path=path, tuning=tuning)
