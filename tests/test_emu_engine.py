@@ -992,7 +992,7 @@ def test_emu_sparse_shared_leading_positions(emu_lib, port, monkeypatch, case):
     a, b = np.tril_indices(N)
     keep = (b < ntr) | (a == b) if skip else np.ones(len(a), dtype=bool)
     for share in shares:
-        for split in (False, True):
+        for split in ((False, True) if case in ("protein_k4", "golden_k3") else (False,)):
             set_tuning_env(monkeypatch, sparse_share=str(share))
             e = _native.Engine(g, m, path=2, lib=emu_lib, skip_test_block=skip)
             e.load_sequences(tokens, offsets, ntr, N - ntr)
