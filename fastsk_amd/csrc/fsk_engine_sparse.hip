@@ -328,8 +328,11 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     e->tic(stream);
     const uint32_t maxprod = (1u << e->sx_pb) - 1u;
     const uint32_t cmax = maxprod / std::max<uint32_t>(1u, e->maxW);  // multiplicities up to here: one word per pair
-    FSK_LAUNCH(HIP_KERNEL_NAME(fsk::k_sx_seg_count<RecT>), dim3(tpg, nb), dim3(256), 0, stream, rec[cur], nfeat, tpg, sb,
-               S.d_tile_ent.p, S.d_tile_lrh.p, skip_from, skipping ? S.d_tile_lth.p : (int*)nullptr);
+    {
+        auto k_cnt = skipping ? fsk::k_sx_seg_count<RecT, true> : fsk::k_sx_seg_count<RecT, false>;
+        FSK_LAUNCH(k_cnt, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, S.d_tile_ent.p, S.d_tile_lrh.p, skip_from,
+                   skipping ? S.d_tile_lth.p : (int*)nullptr);
+    }
     {
         const int* lth = skipping ? (const int*)S.d_tile_lth.p : (const int*)nullptr;
         int* ts = skipping ? S.d_tile_ts.p : (int*)nullptr;
@@ -361,14 +364,16 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     // entries in the packed format (4 + 2 + 2 bytes) when sequence ids, multiplicities and ranks fit 16 bits
     const bool packed = e->N < 65535 && e->maxW < 65536u && !e->tune.sparse_unpacked;
     if (packed) {
-        auto k_seg = pairs ? fsk::k_sx_seg_write<RecT, true, true> : fsk::k_sx_seg_write<RecT, true, false>;
+        auto k_seg = skipping ? (pairs ? fsk::k_sx_seg_write<RecT, true, true, true> : fsk::k_sx_seg_write<RecT, true, false, true>)
+                              : (pairs ? fsk::k_sx_seg_write<RecT, true, true, false> : fsk::k_sx_seg_write<RecT, true, false, false>);
         FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)S.d_ebase.p,
                    (const int*)S.d_tile_rs.p, reinterpret_cast<uint32_t*>(S.d_E.p), reinterpret_cast<uint16_t*>(S.d_Pk.p), e->sx_own_shift, O,
                    lists ? S.d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, S.d_tile_stat.p,
                    skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr,
                    skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr);
     } else {
-        auto k_seg = pairs ? fsk::k_sx_seg_write<RecT, false, true> : fsk::k_sx_seg_write<RecT, false, false>;
+        auto k_seg = skipping ? (pairs ? fsk::k_sx_seg_write<RecT, false, true, true> : fsk::k_sx_seg_write<RecT, false, false, true>)
+                              : (pairs ? fsk::k_sx_seg_write<RecT, false, true, false> : fsk::k_sx_seg_write<RecT, false, false, false>);
         FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)S.d_ebase.p,
                    (const int*)S.d_tile_rs.p, S.d_E.p, S.d_Pk.p, e->sx_own_shift, O,
                    lists ? S.d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, S.d_tile_stat.p,

@@ -56,21 +56,22 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long x)
     return ((unsigned long long)readlane((uint32_t)(x >> 32), 63u) << 32) | readlane((uint32_t)x, 63u);
 }
 
-// running maximum over the lanes (lane l gets the maximum of lanes 0..l), values >= -1: DPP row shifts inside the rows
-// of 16 lanes, then row 0 -> 1 and 2 -> 3, then lane 31 -> rows 2-3; six VALU instructions, no LDS permute
+// running maximum over the lanes (lane l gets the maximum of lanes 0..l): DPP row shifts inside the rows of 16 lanes, then
+// row 0 -> 1 and 2 -> 3, then lane 31 -> rows 2-3. Six v_max_i32_dpp: the shift rides on the maximum itself, and a lane
+// whose source does not exist (the row's first lanes, the rows a broadcast leaves out) keeps its value because a DPP
+// instruction without bound_ctrl does not write it. (Through __builtin_amdgcn_update_dpp the compiler issues a v_mov of the
+// identity, a v_mov_dpp and the v_max per step — eighteen instructions, and k_sx_seg_write, which is bound by the VALU
+// instructions it issues, runs one or two of these scans per 64 records.) s_nop 1: the two wait states a DPP read of a
+// VGPR needs after the VALU write before it.
 __device__ __forceinline__ int wave_incl_max_i32(int x) {
-#define FSK_DPP_MAX(ctrl, rows)                                                        \
-    {                                                                                  \
-        const int y = __builtin_amdgcn_update_dpp(-1, x, ctrl, rows, 0xf, false);      \
-        x = y > x ? y : x;                                                             \
-    }
-    FSK_DPP_MAX(0x111, 0xf)  // row_shr:1
-    FSK_DPP_MAX(0x112, 0xf)  // row_shr:2
-    FSK_DPP_MAX(0x114, 0xf)  // row_shr:4
-    FSK_DPP_MAX(0x118, 0xf)  // row_shr:8
-    FSK_DPP_MAX(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
-    FSK_DPP_MAX(0x143, 0xc)  // row_bcast:31 into rows 2 and 3
-#undef FSK_DPP_MAX
+    asm("s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(x));
     return x;
 }
 
