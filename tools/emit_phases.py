@@ -26,6 +26,7 @@ for name in os.environ.get("AB_CASES", "f7_cfg1_prot11_approx_t1,f7_cfg4_prot219
     v = np.array(list(out), dtype=np.float64)
     tot = v[:6].sum()
     print(name, "workgroups %d, cycles per workgroup %.0f" % (v[15], tot / max(1, v[15])))
+    print("   longest workgroup %.0f cycles (%.1f x the mean); workgroups beyond 200 k cycles: %d, beyond 400 k: %d" % (v[14], v[14] / (tot / max(1, v[15])), v[13], v[12]))
     for i in range(6):
         print("   %-28s %5.1f %%   %8.0f cycles a workgroup" % (names[i], 100 * v[i] / tot, v[i] / max(1, v[15])))
     e.close()
