@@ -10,7 +10,7 @@ from conftest import load_golden, load_tokens
 from fastsk_amd import _native
 lib = _native.Library(sys.argv[1])
 raw = ctypes.CDLL(sys.argv[1])
-names = ["load + classify", "bin + fill slots", "word loop (short)", "list long", "long headers + half waves", "long entries", "", "", "", "", "", "", "", "", "", "workgroups"]
+names = ["load + classify", "fill slots + addresses", "word loop (short)", "list long", "long headers + half waves", "long entries", "zero + bin + scan", "", "", "", "", "", "", "", "", "workgroups"]
 for name in os.environ.get("AB_CASES", "f7_cfg1_prot11_approx_t1,f7_cfg4_prot219_exact").split(","):
     d = load_golden(name)
     tokens, offsets, ntr, nte, _, _ = load_tokens(d["data"])
@@ -24,9 +24,9 @@ for name in os.environ.get("AB_CASES", "f7_cfg1_prot11_approx_t1,f7_cfg4_prot219
     e.compute(tokens, offsets, ntr, nte)
     raw.fsk_debug_emit_clocks(out)
     v = np.array(list(out), dtype=np.float64)
-    tot = v[:6].sum()
+    tot = v[:7].sum()
     print(name, "workgroups %d, cycles per workgroup %.0f" % (v[15], tot / max(1, v[15])))
     print("   longest workgroup %.0f cycles (%.1f x the mean); workgroups beyond 200 k cycles: %d, beyond 400 k: %d" % (v[14], v[14] / (tot / max(1, v[15])), v[13], v[12]))
-    for i in range(6):
+    for i in (0, 6, 1, 2, 3, 4, 5):
         print("   %-28s %5.1f %%   %8.0f cycles a workgroup" % (names[i], 100 * v[i] / tot, v[i] / max(1, v[15])))
     e.close()
