@@ -111,6 +111,9 @@ __device__ __forceinline__ uint32_t wave_incl_sum_u32(uint32_t x) {
     return x;
 }
 
+// sum over the lanes, in every lane (the running sum's last lane, read as a scalar)
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) { return readlane(wave_incl_sum_u32(x), 63u); }
+
 // a copy of a VGPR the compiler cannot see through (see the flush of the tile kernels: a 64-bit operand built from
 // the accumulator itself makes hipcc keep every accumulator in the low half of a register pair)
 __device__ __forceinline__ uint32_t vgpr_copy(uint32_t x) {

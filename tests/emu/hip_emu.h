@@ -333,6 +333,10 @@ static inline int sbfe1(unsigned x, int b) { return (x >> b) & 1u ? -1 : 0; }
 static inline unsigned and_xnor(unsigned p, unsigned m, unsigned t) { return p & ~(m ^ t); }
 static inline unsigned bfe(unsigned x, unsigned off, unsigned width) { return (x >> off) & (width >= 32u ? 0xffffffffu : (1u << width) - 1u); }
 static inline unsigned readlane(unsigned x, unsigned src) { return __shfl(x, (int)src); }
+static inline unsigned wave_sum_u32(unsigned x) {
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+    return x;
+}
 static inline unsigned long long wave_sum_u64(unsigned long long x) {
     for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
     return x;
