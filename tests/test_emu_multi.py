@@ -34,10 +34,11 @@ def engine_for(emu_lib, d, devices, path=0, **kw):
 @pytest.mark.parametrize("name,devices", [("f4_ep300_exact", [0]), ("f4_ep300_exact", [0, 1]), ("f4_ep300_exact", [3, 1, 0, 2]),
                                           ("f4_ep300_exact", [0, 0, 0]), ("f3_ragged_sigma7_g6m3", [0]),
                                           ("f3_ragged_sigma7_g6m3", [0, 1]), ("f3_ragged_sigma7_g6m3", [5, 5, 2, 7, 1]),
-                                          ("f5_prot11_exact", [0, 1, 2])])
+                                          ("f3_lowcomplexity_g5m2:sparse", [0, 1, 2])])
 def test_group_exact_equals_golden(emu_lib, name, devices):
+    name, _, flow = name.partition(":")   # (":sparse": the group's engines on the sparse dataflow)
     d = load_golden(name)
-    e = engine_for(emu_lib, d, devices)
+    e = engine_for(emu_lib, d, devices, **({"path": 2} if flow else {}))
     e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
     assert np.array_equal(e.get_counts(), d["counts"])
     assert np.array_equal(e.get_triangle(), d["tri"])
