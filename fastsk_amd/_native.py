@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfastsk_amd.so")
 
 PATH_AUTO, PATH_DENSE, PATH_SPARSE = 0, 1, 2
 COLL_AUTO, COLL_RCCL, COLL_P2P = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ERRORS = {-1: "FSK_EINVAL", -2: "FSK_ESHORT", -3: "FSK_ESTATE", -4: "FSK_EDEVICE", -5: "FSK_ENOMEM",
           -6: "FSK_EUNSUPPORTED"}
@@ -73,7 +73,7 @@ SYMBOLS = ["fsk_create", "fsk_destroy", "fsk_last_error", "fsk_abi_version", "fs
            "fsk_combo_positions", "fsk_stream_wait_engine", "fsk_engine_wait_stream", "fsk_read_fasta", "fsk_sequential_sum",
            "fsk_run_chains", "fsk_get_kernel_sum_device", "fsk_set_kernel_sum_device", "fsk_create_multi", "fsk_get_multi_info",
            "fsk_counts_digest", "fsk_alloc_block_device", "fsk_free_device", "fsk_set_skip_test_block",
-           "fsk_get_triangle_device", "fsk_alloc_triangle_device", "fsk_set_tuning", "fsk_get_tuning", "fsk_tuning_keys"]
+           "fsk_get_triangle_device", "fsk_alloc_triangle_device", "fsk_set_tuning", "fsk_get_tuning", "fsk_tuning_keys", "fsk_seed_order"]
 
 
 _hip_shared = False
@@ -204,6 +204,7 @@ class Library:
             "fsk_set_tuning": ([vp, C.c_char_p, i64], C.c_int),
             "fsk_get_tuning": ([vp, C.c_char_p, C.POINTER(i64)], C.c_int),
             "fsk_tuning_keys": ([], C.c_char_p),
+            "fsk_seed_order": ([C.c_uint64, i64, vp], C.c_int),
         }
         for name, (argtypes, restype) in sig.items():
             fn = getattr(L, name)
@@ -220,6 +221,14 @@ class Library:
         if rc:
             raise FskError(rc, "bad combination id")
         return out
+
+    def seed_order(self, seed, n):
+        """The combo order ``fsk_set_seed(seed)`` stands for: the reference's std::shuffle with time(0) == seed."""
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        rc = self.L.fsk_seed_order(seed, n, out.ctypes.data)
+        if rc:
+            raise FskError(rc, "bad length")
+        return out[:n]
 
     def device_count(self):
         return int(self.L.fsk_device_count())

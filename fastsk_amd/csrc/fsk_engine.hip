@@ -272,8 +272,45 @@ int make_diag(fsk_engine* e) {
     return FSK_OK;
 }
 
+// The order the reference draws for this seed: std::shuffle(indexes, std::default_random_engine{seed}) of libstdc++
+// (fastsk_kernel.cpp:31-38 seeds it with time(0)), restated. default_random_engine is minstd_rand0, x <- 16807 x mod
+// (2^31 - 1), values in [1, 2^31 - 2]; uniform_int_distribution over [0, r] takes its "downscaling" branch (reject draws
+// from urange / (r + 1) * (r + 1) on, divide by the scaling); std::shuffle swaps element i with a draw from [0, i] —
+// two elements per draw (one number below i * (i + 1) split by / and %) while n * n fits the generator's range, after
+// a single swap up front when n is even.
+void libstdcxx_shuffle_order(uint64_t seed, int64_t n, int32_t* out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = (int32_t)i;
+    if (n < 2) return;
+    const uint64_t M = 2147483647ull, RANGE = M - 2;  // max() - min()
+    uint64_t x = seed % M;
+    if (x == 0) x = 1;  // linear_congruential_engine::seed with c = 0
+    auto below = [&](uint64_t count) {  // uniform in [0, count): uniform_int_distribution{0, count - 1}
+        if (count - 1 == RANGE) { x = x * 16807ull % M; return x - 1; }
+        const uint64_t scaling = RANGE / count, past = count * scaling;
+        uint64_t r;
+        do { x = x * 16807ull % M; r = x - 1; } while (r >= past);
+        return r / scaling;
+    };
+    const uint64_t un = (uint64_t)n;
+    if (RANGE / un >= un) {
+        int64_t i = 1;
+        if (un % 2 == 0) { std::swap(out[i], out[below(2)]); ++i; }
+        while (i < n) {
+            const uint64_t r = (uint64_t)i + 1, both = below(r * (r + 1));
+            std::swap(out[i], out[both / (r + 1)]); ++i;
+            std::swap(out[i], out[both % (r + 1)]); ++i;
+        }
+        return;
+    }
+    for (int64_t i = 1; i < n; ++i) std::swap(out[i], out[below((uint64_t)i + 1)]);
+}
+
 void default_order(fsk_engine* e) {
     e->order.resize((size_t)e->ncomb);
+    if (e->tune.seed_splitmix == 0) {  // the reference's own sample for this seed
+        libstdcxx_shuffle_order(e->seed, e->ncomb, e->order.data());
+        return;
+    }
     for (int64_t i = 0; i < e->ncomb; ++i) e->order[i] = (int32_t)i;
     uint64_t s = e->seed;
     for (int64_t i = e->ncomb - 1; i > 0; --i) {
@@ -315,6 +352,12 @@ int fetch_block(fsk_engine* e, int64_t i0, int64_t i1, int64_t j0, int64_t j1, d
 extern "C" {
 
 int fsk_abi_version(void) { return FSK_ABI_VERSION; }
+
+int fsk_seed_order(uint64_t seed, int64_t n, int32_t* out) {
+    if (n < 0 || n > 0x7fffffff || (n > 0 && !out)) return FSK_EINVAL;
+    fsk_detail::libstdcxx_shuffle_order(seed, n, out);
+    return FSK_OK;
+}
 
 int fsk_device_count(void) {
     int n = 0;

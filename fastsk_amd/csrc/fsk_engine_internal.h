@@ -107,6 +107,7 @@ using fsk_detail::DevBuf;
     X(seg_scan_chunked, 0, 0, 1, "sparse: the three-launch segment scan whatever the tile count")                                    \
     X(extract_slots, 0, 0, 4, "sparse: slots per k_sx_extract_win workgroup, 1 or 4 (0: by the size of the launch)")                  \
     X(sparse_share, 0, -1, 254, "sparse: leading kept positions sorted once per group of consecutive combos that share them (0: by cost; -1: never)") \
+    X(seed_splitmix, 0, 0, 1, "approx modes: 1 = fsk_set_seed draws the engine's older splitmix64 Fisher-Yates order (0: the reference's std::shuffle of minstd_rand0)") \
     X(collective, 0, 0, 2, "fsk_create_multi: FSK_COLL_* when fsk_config.collective is FSK_COLL_AUTO")                                \
     X(deadline_ms, 120000, -1, 86400000, "fsk_create_multi: the fail-fast bound when fsk_config.deadline_ms is 0 (negative: none)")   \
     FSK_TUNING_TEST_KEYS(X)
@@ -364,6 +365,7 @@ int do_accumulate(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t r
                   int defer = -1);
 int make_diag(fsk_engine* e);
 void default_order(fsk_engine* e);
+void libstdcxx_shuffle_order(uint64_t seed, int64_t n, int32_t* out);
 
 // fsk_engine_dense.hip
 struct DensePlan { uint32_t CH = 0, Vcq = 0; size_t lds = 0; };

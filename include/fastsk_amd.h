@@ -28,10 +28,11 @@
 extern "C" {
 #endif
 
-#define FSK_ABI_VERSION 4  /* 2: fsk_create_multi + fsk_config.collective/bands, fsk_counts_digest, device-block allocation;
+#define FSK_ABI_VERSION 5  /* 2: fsk_create_multi + fsk_config.collective/bands, fsk_counts_digest, device-block allocation;
                               3: fsk_get_triangle_device / fsk_alloc_triangle_device, fsk_config.deadline_ms;
                               4: fsk_set_tuning / fsk_get_tuning / fsk_tuning_keys (one FSK_TUNING variable instead of
-                                 two dozen FSK_* switches) */
+                                 two dozen FSK_* switches);
+                              5: fsk_seed_order; fsk_set_seed draws the reference's own std::shuffle order */
 
 enum {
     FSK_OK = 0,
@@ -190,8 +191,12 @@ int fsk_compute(fsk_engine* e, const int32_t* tokens, const int64_t* offsets, in
 
 /* Combo order used by the approx modes. Replaces the time(0)-seeded std::shuffle of
  * fastsk_kernel.cpp:29-38 with an explicit permutation (or prefix of one) of 0..C(g,m)-1.
- * Without it approx mode draws its own seeded Fisher-Yates order (fsk_set_seed). */
+ * Without it approx mode draws the order of fsk_set_seed's seed (0 when none was set). */
 int fsk_set_combo_order(fsk_engine* e, const int32_t* order, int32_t n);
+/* The seed of that shuffle: the order is the one the reference draws when time(0) == seed —
+ * libstdc++'s std::shuffle over std::default_random_engine (minstd_rand0), fastsk_kernel.cpp:31-38,
+ * restated in the engine (fsk_seed_order returns it). So FastSK(approx=True, seed=S) samples the
+ * combos the reference sampled in the second S. */
 int fsk_set_seed(fsk_engine* e, uint64_t seed);
 
 /* ---- staged path (multi-GPU sharding, benchmarking with inputs resident in HBM) ------------ */
@@ -294,6 +299,9 @@ int fsk_get_stats(fsk_engine* e, fsk_stats* out);
 /* ---- helpers shared with the host side --------------------------------------------------- */
 int64_t fsk_num_combos(int32_t g, int32_t m);                              /* nchoosek */
 int fsk_combo_positions(int32_t g, int32_t k, int64_t combo, int32_t* out); /* getCombinations */
+/* the permutation of 0..n-1 that std::shuffle(begin, end, std::default_random_engine{seed}) of libstdc++ produces
+ * (fastsk_kernel.cpp:31-38 with n = C(g,m) and seed = time(0)); host only */
+int fsk_seed_order(uint64_t seed, int64_t n, int32_t* out);
 
 
 /* ---- input: native counterpart of FastaUtility.read_data + Vocabulary (src/fastsk/utils.py:5-96)

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(product_lib):
     assert sorted(_native.SYMBOLS) == names, "ctypes view and header disagree"
     for n in names:
         assert hasattr(product_lib.L, n), n
-    assert product_lib.L.fsk_abi_version() == _native.ABI_VERSION == 4
+    assert product_lib.L.fsk_abi_version() == _native.ABI_VERSION == 5
 
 
 def test_tuning_keys_and_no_ambient_switches(product_lib):

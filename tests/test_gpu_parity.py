@@ -727,6 +727,11 @@ def test_pybind_surface_on_gpu(native):
     f.compute_kernel(X[:60], X[60:])
     assert np.array_equal(np.array(f.get_stdevs()), d["stdevs"])
     assert np.array_equal(f.get_test_kernel_np(), d["test"])
+    # the same WITHOUT an injected order: seed= is the reference's seed (its std::shuffle with time(0) == 777 drew d["order"])
+    f = FastSK(10, 6, 1, True, 0.025, 17, seed=int(d["seed"]))
+    f.compute_kernel(X[:60], X[60:])
+    assert np.array_equal(np.array(f.get_stdevs()), d["stdevs"])
+    assert np.array_equal(f.get_test_kernel_np(), d["test"]) and np.array_equal(f.get_train_kernel_np(), d["train"])
     f = FastSK(g=10, m=6)
     f.compute_train(X[:60])
     assert f.get_test_kernel() == []

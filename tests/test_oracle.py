@@ -203,3 +203,31 @@ def test_fast_fasta_reader_equals_slow_reader(tmp_path):
         assert offs.tolist() == np.concatenate([[0], np.cumsum([len(x) for x in X])]).tolist()
         assert toks.tolist() == [t for x in X for t in x]
     assert str(slow._vocab) == str(fast._vocab)
+
+
+def test_seed_order_is_the_references_shuffle(ref):
+    """fsk_set_seed(S) stands for the order the reference draws when time(0) == S: libstdc++'s std::shuffle over
+    std::default_random_engine (fastsk_kernel.cpp:31-38), restated in the engine (fsk_seed_order) — against the compiled
+    reference's own std::shuffle for lengths on both sides of its two-swaps-a-draw limit (n * n <= 2^31 - 3) and seeds
+    incl. the ones minstd_rand0 folds (0 and 2^31 - 1 both seed as 1)."""
+    from fastsk_amd import _native
+    lib = _native.library()
+    for n in (0, 1, 2, 3, 4, 210, 495, 1001, 38760, 46340, 46341, 50000, 184756):
+        for seed in (0, 1, 42, 777, 2 ** 31 - 2, 2 ** 31 - 1, 2 ** 31, 1759622400, 2 ** 40 + 12345):
+            want = ref.shuffle_order(seed, n) if n else np.zeros(0, dtype=np.int32)
+            got = lib.seed_order(seed, n)
+            assert np.array_equal(got, want), (n, seed)
+
+
+def test_seed_order_reproduces_every_golden_order():
+    """... and the orders stored in the committed fixtures (written by the compiled reference with time() pinned to `seed`)."""
+    from conftest import golden_names
+    from fastsk_amd import _native
+    lib = _native.library()
+    seen = 0
+    for name in golden_names(("f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8")):
+        d = load_golden(name)
+        if "order" in d and "seed" in d and len(d["order"]):
+            assert np.array_equal(lib.seed_order(d["seed"], len(d["order"])), d["order"]), name
+            seen += 1
+    assert seen >= 5

@@ -21,8 +21,12 @@ def main():
     tag = sys.argv[1]
     base = os.path.join(ROOT, "gpurun_out", "pmc", tag)
     kernels = {}
+    first_set = {}  # a counter listed in several passes (SQ_INSTS_VALU rides along as the yardstick) counts from the first one only
     for cc in sorted(glob.glob(os.path.join(base, "set*", "*", "*_counter_collection.csv"))):
+        which = os.path.relpath(cc, base).split(os.sep)[0]
         for r in csv.DictReader(open(cc)):
+            if first_set.setdefault(r["Counter_Name"], which) != which:
+                continue
             k = kernels.setdefault(short(r["Kernel_Name"]), {"counters": {}})
             c = k["counters"]
             c[r["Counter_Name"]] = c.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
@@ -41,9 +45,21 @@ def main():
         if c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0) > 0:
             k["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
         if c.get("SQ_WAVE_CYCLES"):
-            for name in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+            for name in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS"):
                 if name in c:
                     k[name.lower() + "_frac_of_wave_cycles"] = c[name] / c["SQ_WAVE_CYCLES"]
+    for k in kernels.values():
+        c = k["counters"]
+        # measured price of a VALU instruction: SQ_INST_CYCLES_VALU (cycles the VALU spent on them) per SQ_INSTS_VALU, and the
+        # share of the kernel's SIMD time that is (total_ms x 1024 SIMDs x the 2.4 GHz peak clock: a lower bound of the share)
+        if c.get("SQ_INST_CYCLES_VALU") and c.get("SQ_INSTS_VALU"):
+            k["valu_cycles_per_inst"] = c["SQ_INST_CYCLES_VALU"] / c["SQ_INSTS_VALU"]
+            if k.get("total_ms"):
+                k["valu_issue_occupancy"] = c["SQ_INST_CYCLES_VALU"] / (k["total_ms"] * 1e-3 * 2.4e9 * 1024)
+        if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_INSTS_VALU"):
+            k["active_inst_valu_quadcycles_per_inst"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"]
+        if c.get("SQ_LDS_IDX_ACTIVE"):
+            k["lds_conflict_frac_of_idx_active"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
     fsk = {n: v for n, v in kernels.items() if "fsk::" in n}
     out = {"tag": tag, "command": "tools/pmc_passes.sh %s ... (one rocprofv3 --pmc pass per counter set + one --kernel-trace --stats pass)" % tag,
            "kernels": dict(sorted(fsk.items(), key=lambda kv: -kv[1].get("total_ms", 0.0)))}
