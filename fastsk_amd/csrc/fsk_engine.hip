@@ -1315,6 +1315,10 @@ int fsk_detail::one_get_stats(fsk_engine* e, fsk_stats* out) {
         }
     }
     e->st.batches_redone = (double)e->sx_redone;
+    e->st.sparse_form = (double)e->sx_form_used;
+    e->st.sparse_passes = (double)e->sx_passes;
+    e->st.share_positions = (double)e->sx_share_used;
+    e->st.share_groups = (double)e->sx_share_groups;
     *out = e->st;
     // (every flagged-row remainder product is one more dot8 per cell of its tile: 8 count-MACs x 128 x 128)
     out->dense_macs += rem_rows * (u64)fsk::TILE * fsk::TILE * 8;

@@ -106,6 +106,11 @@ using fsk_detail::DevBuf;
     X(list_max_words, 0, 0, (int64_t)1 << 31, "sparse: update words of one batch beyond which its pairs go to K with atomics (0: 2^31)") \
     X(seg_scan_chunked, 0, 0, 1, "sparse: the three-launch segment scan whatever the tile count")                                    \
     X(extract_slots, 0, 0, 4, "sparse: slots per k_sx_extract_win workgroup, 1 or 4 (0: by the size of the launch)")                  \
+    X(sparse_form, 0, 0, 3, "sparse: the update stage — 1 = owner bands whenever they exist, 2 = two-level blocks, 3 = 64-bit atomics (0: bands up to three LDS rounds a band, blocks beyond)") \
+    X(blocks_sub_shift, 14, 4, 14, "sparse, blocks: log2 of the cells one k_sxb_consume workgroup sums in LDS (tests: small blocks on small inputs)") \
+    X(blocks_max_bands, 512, 2, 512, "sparse, blocks: bands of one pass at most (tests: several passes on small inputs)")            \
+    X(blocks_band_shift_max, 23, 4, 23, "sparse, blocks: log2 of a band's cells at most (tests)")                                    \
+    X(blocks_pass_words, 0, 0, (int64_t)1 << 32, "sparse, blocks: update words of one pass at most (0: 2^31)")                       \
     X(sparse_share, 0, -1, 254, "sparse: leading kept positions sorted once per group of consecutive combos that share them (0: by cost; -1: never)") \
     X(seed_splitmix, 0, 0, 1, "approx modes: 1 = fsk_set_seed draws the engine's older splitmix64 Fisher-Yates order (0: the reference's std::shuffle of minstd_rand0)") \
     X(collective, 0, 0, 2, "fsk_create_multi: FSK_COLL_* when fsk_config.collective is FSK_COLL_AUTO")                                \
@@ -142,7 +147,9 @@ struct SxScratch {
     DevBuf<u64> d_sxstat;
     DevBuf<uint32_t> d_group_of, d_group_head, d_winp;  // shared prefixes (k_sx_group_tables): slot -> group, group -> first slot,
     DevBuf<unsigned char> d_part;                        // the windows and part records of every group in presorted order
+    DevBuf<uint32_t> d_ulist2, d_subcnt, d_suboff, d_subcur;  // blocks form: the stream split by sub-band, words / start / cursor per (band, sub-band)
     void release() {
+        d_ulist2.release(); d_subcnt.release(); d_suboff.release(); d_subcur.release();
         d_group_of.release(); d_group_head.release(); d_winp.release(); d_part.release();
         for (auto& k : d_keys) k.release();
         d_blockhist.release(); d_totals.release(); d_tile_ent.release(); d_ebase.release(); d_Pk.release(); d_Tk.release();
@@ -236,6 +243,12 @@ struct fsk_engine {
     int sx_pb = 16, sx_sb = 1, sx_keybits = 1, sx_own_shift = 13;
     int sx_symbits = 0;  // != 0: the k-mer space passes 2^62 and a key is the symbols' sx_symbits-bit fields side by side, not a mixed-radix number
     bool sx_lists = false, owner_ready = false;
+    int sx_form = 0;  // the update stage of the sparse dataflow for these sequences: 0 = owner bands, 1 = 64-bit atomics, 2 = two-level blocks
+    int sx_form_used = -1;  // ... what the last batch really took (tuning key sparse_form_used reads it)
+    u64 sx_passes = 0;      // blocks form: passes run since the sequences were loaded
+    int sx_share_used = 0;  // shared prefixes: leading positions / groups of the last batch (fsk_stats)
+    uint32_t sx_share_groups = 0;
+    DevBuf<uint32_t> d_blk_r0;  // blocks form: the band table of the pass at hand
     bool sx_pairs_asked = true;
     bool sx_pairs = false;  // update streams: unit products travel as 15-bit cells, two to a 32-bit container (bands of < 32767 cells)
     int64_t owner_N = -1;                 // the number of sequences the owner bands were planned for
@@ -376,6 +389,9 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
 // fsk_engine_sparse.hip
 // which lane (scratch set + stream) the deferred batch `defer` of variance mode runs in
 inline int sx_lane_of(const fsk_engine* e, int defer) { return (defer >= 0 && !e->profile_sync()) ? (defer & 1) : 0; }
+// the bands of one pass of the two-level form over rows [ra, rb) (fsk_sparse_blocks.inc)
+struct SxPass { int64_t ra = 0, rb = 0; int t = 14, sub_shift = 14, pb = 8; uint32_t n_owners = 0, submax = 0, own_base = 0; std::vector<uint32_t> r0; };
+bool blocks_plan_pass(fsk_engine* e, int64_t ra, int64_t rb, SxPass* out);
 void plan_owner_bands(fsk_engine* e);
 bool sx_harvest(fsk_engine* e, int slot);
 int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0, int64_t row1, u64 slot_stride = 0,

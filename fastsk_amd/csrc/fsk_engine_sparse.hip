@@ -17,6 +17,48 @@ constexpr uint32_t SX_CAP = 19456;        // u32 cells of K one k_sx_consume wor
 constexpr uint32_t SX_MAX_ROUNDS = 16;
 constexpr uint32_t SX_CAP_SLOT = 20480;   // by-slot form (no parts table in LDS): 80 KiB, two workgroups per CU
 
+// ---- two-level form (fsk_sparse_blocks.inc): the bands of ONE pass over rows [ra, rb) ------------------------------
+constexpr uint32_t SX_BLOCKS_FROM_ROUNDS = 3;  // the owner bands up to this many LDS rounds a band, blocks beyond
+// Bands of 2^t cells counted from the pass's first row, t the smallest that leaves at most `blocks_max_bands` bands; a band's
+// cell offsets (2^t + a row at most) and an 8-bit product at least share the 32-bit word, so t <= 23 and a pass covers
+// fewer than 2^32 cells. false: rows [ra, rb) do not fit one pass (the caller halves the range) or the sub-bands of a band
+// outnumber the scatter's histogram (sequences in the millions: 64-bit atomics then).
+bool blocks_plan_pass(fsk_engine* e, int64_t ra, int64_t rb, SxPass* out) {
+    const u64 N = (u64)e->N;
+    const u64 c_lo = (u64)ra * ((u64)ra + 1) / 2, c_hi = (u64)rb * ((u64)rb + 1) / 2, cells = c_hi - c_lo;
+    const int sub_shift = (int)e->tune.blocks_sub_shift;
+    const u64 max_bands = (u64)e->tune.blocks_max_bands;
+    int t_max = (int)e->tune.blocks_band_shift_max;
+    while (t_max > sub_shift && ((u64)1 << t_max) + N > ((u64)1 << 24)) --t_max;  // (pb >= 8)
+    if (((u64)1 << t_max) + N > ((u64)1 << 24)) return false;
+    if ((((((u64)1 << t_max) + N) >> sub_shift) + 1) > (u64)fsk::SXB_MAX_SUB) return false;
+    if (!out) return true;  // (the form exists for these sequences)
+    if (rb - ra > 1 && (cells > ((max_bands - 1) << t_max) || cells >= ((u64)1 << 32))) return false;  // (one row is always a pass)
+    int t = sub_shift;
+    while (t < t_max && ((cells + (((u64)1) << t) - 1) >> t) > max_bands) ++t;
+    u64 nb = std::max<u64>(1, (cells + (((u64)1) << t) - 1) >> t);
+    if (nb > (u64)fsk::SX_MAX_OWNERS) return false;  // (a single row longer than the bands allow: N beyond 2^23 — excluded above)
+    out->ra = ra; out->rb = rb; out->t = t; out->sub_shift = sub_shift;
+    out->n_owners = (uint32_t)nb;
+    out->own_base = (uint32_t)c_lo;  // (mod 2^32, as sx_tri32 computes it)
+    out->r0.assign((size_t)nb + 1, (uint32_t)rb);
+    u64 largest = 0;
+    {
+        uint32_t o = 0;  // r0[o] = first row whose first cell, counted from the pass's first cell, reaches o << t
+        for (u64 i = (u64)ra; i < (u64)rb && o <= nb; ++i)
+            while (o <= nb && (i * (i + 1) / 2 - c_lo) >= ((u64)o << t)) out->r0[o++] = (uint32_t)i;
+        for (u64 q = 0; q < nb; ++q) {
+            const u64 a = out->r0[q], b = out->r0[q + 1];
+            largest = std::max(largest, b * (b + 1) / 2 - a * (a + 1) / 2);
+        }
+    }
+    int L = 1;
+    while (((u64)1 << L) < largest) ++L;
+    out->pb = 32 - L;
+    out->submax = (uint32_t)(((largest + (((u64)1) << sub_shift) - 1) >> sub_shift) + 1);
+    return out->pb >= 8 && out->submax <= fsk::SXB_MAX_SUB;
+}
+
 void plan_owner_bands(fsk_engine* e) {
     // band o = the rows whose first cell index lies in [o << t, (o + 1) << t): a row's band is a shift
     // of its triangular index, bands hold about 2^t cells (2^t + N at most: the last row of a band is
@@ -60,6 +102,21 @@ void plan_owner_bands(fsk_engine* e) {
     e->sx_cap_slot = (uint32_t)std::max<u64>(1, std::min<u64>(SX_CAP_SLOT, largest));
     e->sx_lists = e->n_owners <= (uint32_t)fsk::SX_MAX_OWNERS && e->sx_rounds <= SX_MAX_ROUNDS && e->sx_pb >= 8;
     e->owner_ready = false;
+}
+
+// Which form the update stage takes (fsk_sparse_blocks.inc): the owner bands while a band is a few LDS rounds (every
+// round re-reads the band's stream), the two-level blocks beyond — and wherever the bands do not exist at all.
+// Tuning sparse_form: 1 = bands whenever they exist, 2 = blocks always, 3 = one 64-bit atomic per += (as sparse_global).
+void sx_choose_form(fsk_engine* e) {
+    const int64_t want = e->tune.sparse_form;
+    const bool blocks_ok = blocks_plan_pass(e, 0, e->N, nullptr);
+    e->sx_form = (want == 3 || e->tune.sparse_global) ? 1
+                 : (want == 2 && blocks_ok)          ? 2
+                 : (want == 1 && e->sx_lists)        ? 0
+                 : e->sx_lists && e->sx_rounds <= SX_BLOCKS_FROM_ROUNDS ? 0
+                 : blocks_ok                                            ? 2
+                 : e->sx_lists                                          ? 0
+                                                                        : 1;
 }
 
 // The LSD passes over `bits` bits from bit `shift0` of the records of n_slots slots (the digits of the first pass have been
@@ -161,6 +218,8 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     // (consecutive combos keep the same leading positions for long stretches: those are sorted once per group)
     const SxShare sh = nb > 16 ? sx_plan_share(e, combos, nb, 8 * (int)sizeof(RecT)) : SxShare();
     const int keybits = sh.share ? sh.lowbits : e->sx_keybits;  // what every slot sorts
+    e->sx_share_used = sh.share;
+    e->sx_share_groups = sh.groups;
     if (e->trace())
         fprintf(stderr, "[fsk] sparse batch: %d slots, shared leading positions %d (%u groups, %d + %d key bits; plain %d)\n", nb, sh.share, sh.groups,
                 sh.topbits, sh.lowbits, e->sx_keybits);
@@ -169,10 +228,14 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     const uint32_t tps = (nfeat + fsk::SX_TILE - 1) / fsk::SX_TILE;   // sort tiles per slot
     const uint32_t tpg = (nfeat + fsk::SG_TILE - 1) / fsk::SG_TILE;   // segment tiles per slot
     const uint32_t ntiles = tpg * (uint32_t)nb;
-    const bool lists = e->sx_lists && !e->tune.sparse_global;
+    // the form of the update stage (sx_choose_form); a batch of slot triangles (variance mode) knows the owner bands only
+    const int form = slot_stride != 0 ? ((e->sx_lists && e->sx_form != 1) ? 0 : 1) : e->sx_form;
+    const bool blocks = form == 2;
+    const bool lists = form == 0;
+    e->sx_form_used = form;
     const int pairs = lists && e->sx_pairs ? 1 : 0;  // (unit products as bare cells, two to a word: plan_owner_bands)
     const bool slot16 = slot_stride != 0 && e->sx_slot16_used;  // (u16 slot triangles: set by accumulate_sparse for a deferred batch)
-    const uint32_t O = e->n_owners;
+    const uint32_t O = blocks ? (uint32_t)e->tune.blocks_max_bands : e->n_owners;  // (blocks: the most bands a pass can have)
     // (the presort's records, 4 or 8 bytes a window and group, go through the same two buffers first)
     const size_t pre_bytes = sh.share ? (size_t)sh.groups * nfeat * (sh.pre64 ? 8 : 4) : 0;
     for (int b = 0; b < 2; ++b) FSK_HIP(S.d_keys[b].reserve(std::max(pre_bytes, nrec * sizeof(RecT))));
@@ -205,7 +268,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     // chunk kernels have a few hundred workgroups and short chains of dependent steps
     const uint32_t uc = ntiles >= 16384u ? (uint32_t)fsk::UC_CHUNK : ntiles >= 4096u ? 16u : 8u;
     const uint32_t nchunks = (ntiles + uc - 1) / uc;
-    if (lists) {
+    if (lists || blocks) {
         FSK_HIP(S.d_ucount.reserve((size_t)O * ntiles));
         FSK_HIP(S.d_uchunk.reserve((size_t)O * nchunks));
         FSK_HIP(S.d_utot.reserve(O));
@@ -363,6 +426,140 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     }
     // entries in the packed format (4 + 2 + 2 bytes) when sequence ids, multiplicities and ranks fit 16 bits
     const bool packed = e->N < 65535 && e->maxW < 65536u && !e->tune.sparse_unpacked;
+    if (blocks) {
+        // ---- the two-level form (fsk_sparse_blocks.inc): passes over disjoint row ranges, each sized exactly (a pass is
+        // milliseconds of work: the wait for its word count does not show). A range that does not fit one pass — more cells
+        // than 2^32 or than its bands cover, more words than 32-bit offsets address — is halved by cells.
+        const u64 pass_words = e->tune.blocks_pass_words > 0 ? (u64)e->tune.blocks_pass_words : ((u64)1 << 31);
+        const u64 total_cells = (u64)e->N * ((u64)e->N + 1) / 2;
+        stat_pin[0] = stat_pin[1] = 0;
+        e->toc(&e->st.ms_segment, stream);
+        e->tic(stream);
+        std::vector<std::pair<int64_t, int64_t>> todo;
+        todo.emplace_back(row0, row1);
+        bool first_pass = true;
+        while (!todo.empty()) {
+            const int64_t ra = todo.back().first, rb = todo.back().second;
+            todo.pop_back();
+            if (rb <= ra) continue;
+            auto halve = [&]() {  // by cells: the row whose first cell is the middle one
+                const u64 ca = (u64)ra * ((u64)ra + 1) / 2, cb = (u64)rb * ((u64)rb + 1) / 2, mid = ca + (cb - ca) / 2;
+                int64_t lo = ra + 1, hi = rb - 1;
+                while (lo < hi) {
+                    const int64_t m = (lo + hi) / 2;
+                    if ((u64)m * ((u64)m + 1) / 2 < mid) lo = m + 1; else hi = m;
+                }
+                todo.emplace_back(lo, rb);  // (the lower rows first: the stack pops them next)
+                todo.emplace_back(ra, lo);
+            };
+            SxPass P;
+            // (what the range is expected to emit, by its share of the triangle: a range that would overflow a pass is not tried)
+            const u64 cells = (u64)rb * ((u64)rb + 1) / 2 - (u64)ra * ((u64)ra + 1) / 2;
+            const bool too_many = e->sx_wpr != 0 && rb - ra > 1 &&
+                                  (double)e->sx_words_of(nrec) * ((double)cells / (double)std::max<u64>(1, total_cells)) > 0.9 * (double)pass_words;
+            if (too_many || !blocks_plan_pass(e, ra, rb, &P)) {
+                if (rb - ra <= 1) return e->fail(FSK_EUNSUPPORTED, "sparse dataflow: row %lld does not fit one pass of the two-level form", (long long)ra);
+                halve();
+                continue;
+            }
+            const uint32_t Op = P.n_owners;
+            FSK_HIP(e->d_blk_r0.reserve((size_t)fsk::SX_MAX_OWNERS + 1));
+            // (the previous pass has been waited for: nothing reads the table any more)
+            FSK_HIP(hipMemcpy(e->d_blk_r0.p, P.r0.data(), P.r0.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            if (!first_pass) FSK_HIP(hipMemsetAsync(S.d_sxstat.p, 0, 3 * sizeof(u64), stream));  // (the first pass: zeroed by the extraction kernel)
+            first_pass = false;
+            const uint32_t maxprod_p = (1u << P.pb) - 1u, cmax_p = maxprod_p / std::max<uint32_t>(1u, e->maxW);
+            u64 pass_stat[2] = {0, 0};
+            // stat_pin is pinned host memory the device writes: this pass's totals land there, the batch's are summed below
+            u64* const pin = stat_pin;
+            pin[0] = pin[1] = 0;
+            if (packed) {
+                auto k_seg = skipping ? fsk::k_sx_seg_write<RecT, true, false, true> : fsk::k_sx_seg_write<RecT, true, false, false>;
+                FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)S.d_ebase.p,
+                           (const int*)S.d_tile_rs.p, reinterpret_cast<uint32_t*>(S.d_E.p), reinterpret_cast<uint16_t*>(S.d_Pk.p), P.t, Op,
+                           S.d_ucount.p, (uint32_t)ra, (uint32_t)rb, e->maxW, maxprod_p, cmax_p, S.d_tile_stat.p, skip_from,
+                           skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr,
+                           skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr, P.own_base);
+            } else {
+                auto k_seg = skipping ? fsk::k_sx_seg_write<RecT, false, false, true> : fsk::k_sx_seg_write<RecT, false, false, false>;
+                FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)S.d_ebase.p,
+                           (const int*)S.d_tile_rs.p, S.d_E.p, S.d_Pk.p, P.t, Op, S.d_ucount.p, (uint32_t)ra, (uint32_t)rb, e->maxW, maxprod_p,
+                           cmax_p, S.d_tile_stat.p, skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr,
+                           skipping ? S.d_Tk.p : (uint32_t*)nullptr, P.own_base);
+            }
+            FSK_LAUNCH(fsk::k_sx_ucol_sum, dim3(nchunks), dim3(256), 0, stream, (const uint32_t*)S.d_ucount.p, ntiles, Op, S.d_uchunk.p,
+                       (const u64*)S.d_tile_stat.p, S.d_sxstat.p, pin, uc);
+            FSK_LAUNCH(fsk::k_sx_ucol_scan, dim3(Op), dim3(256), 0, stream, S.d_uchunk.p, nchunks, Op, S.d_utot.p);
+            FSK_LAUNCH(fsk::k_sx_ucol_apply, dim3(nchunks), dim3(256), 0, stream, S.d_ucount.p, ntiles, Op, (const uint32_t*)S.d_uchunk.p,
+                       (const uint32_t*)S.d_utot.p, S.d_list_off.p, uc);
+            e->st.launches += 4;
+            FSK_HIP(hipStreamSynchronize(stream));
+            pass_stat[0] = pin[0]; pass_stat[1] = pin[1];
+            const u64 words = pass_stat[1];
+            if (words >= pass_words && rb - ra > 1) {  // (does not fit 32-bit offsets with room to spare: the halves, each from its own count)
+                halve();
+                first_pass = false;
+                continue;
+            }
+            if (words >= ((u64)1 << 32))
+                return e->fail(FSK_EUNSUPPORTED, "sparse dataflow: row %lld alone emits %llu update words a batch", (long long)ra, (unsigned long long)words);
+            e->u_extra += pass_stat[0];
+            e->sx_passes += 1;
+            if (e->trace())
+                fprintf(stderr, "[fsk] sparse blocks: pass rows [%lld, %lld), %u bands of 2^%d cells, %u sub-bands a band, %d product bits, %llu words\n",
+                        (long long)ra, (long long)rb, Op, P.t, P.submax, P.pb, (unsigned long long)words);
+            if (words == 0) continue;
+            if ((size_t)words > S.d_ulist.cap) FSK_HIP(S.d_ulist.reserve((size_t)(words + words / 8)));
+            if ((size_t)words > S.d_ulist2.cap) FSK_HIP(S.d_ulist2.reserve((size_t)(words + words / 8)));
+            const size_t nsub = (size_t)Op * P.submax;
+            FSK_HIP(S.d_subcnt.reserve(nsub));
+            FSK_HIP(S.d_suboff.reserve(nsub));
+            FSK_HIP(S.d_subcur.reserve(nsub));
+            FSK_HIP(hipMemsetAsync(S.d_subcnt.p, 0, nsub * sizeof(uint32_t), stream));
+            if (k_wait) { FSK_HIP(hipStreamWaitEvent(stream, k_wait, 0)); k_wait = nullptr; }
+            if (packed) {
+                auto k_emit = skipping ? fsk::k_sx_emit<false, true, true> : fsk::k_sx_emit<false, false, true>;
+                FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, reinterpret_cast<const uint32_t*>(S.d_E.p),
+                           reinterpret_cast<const uint16_t*>(S.d_Pk.p), (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_blk_r0.p, P.t, Op,
+                           (const uint32_t*)S.d_list_off.p, (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)ra, (uint32_t)rb, e->maxW,
+                           maxprod_p, cmax_p, P.pb, K, tpg, (u64)0,
+                           skipping ? reinterpret_cast<const uint16_t*>(S.d_Tk.p) : (const uint16_t*)nullptr, (const u64*)S.d_sxstat.p, ~(u64)0,
+                           ntiles, 0, P.own_base);
+            } else {
+                auto k_emit = skipping ? fsk::k_sx_emit<false, true, false> : fsk::k_sx_emit<false, false, false>;
+                FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, (const uint2*)S.d_E.p, (const uint32_t*)S.d_Pk.p,
+                           (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_blk_r0.p, P.t, Op, (const uint32_t*)S.d_list_off.p,
+                           (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)ra, (uint32_t)rb, e->maxW, maxprod_p, cmax_p, P.pb, K, tpg, (u64)0,
+                           skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)S.d_sxstat.p, ~(u64)0, ntiles, 0, P.own_base);
+            }
+            const uint32_t n_split = Op + (uint32_t)((words + fsk::SXB_TILE - 1) / fsk::SXB_TILE);  // tiles of the bands' streams, at most
+            FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, stream, (const uint32_t*)S.d_list_off.p, Op, (uint32_t)fsk::SXB_TILE, S.d_part_base.p,
+                       (const u64*)S.d_sxstat.p, ~(u64)0);
+            FSK_LAUNCH(fsk::k_sxb_count, dim3(n_split), dim3(fsk::SXB_THREADS), 0, stream, (const uint32_t*)S.d_ulist.p, (const uint32_t*)S.d_list_off.p,
+                       (const uint32_t*)S.d_part_base.p, Op, P.pb, P.sub_shift, P.submax, S.d_subcnt.p);
+            FSK_LAUNCH(fsk::k_sxb_scan, dim3(Op), dim3(fsk::SXB_THREADS), 0, stream, (const uint32_t*)S.d_subcnt.p, (const uint32_t*)S.d_list_off.p, P.submax,
+                       S.d_suboff.p, S.d_subcur.p);
+            FSK_LAUNCH(fsk::k_sxb_scatter, dim3(n_split), dim3(fsk::SXB_THREADS), 0, stream, (const uint32_t*)S.d_ulist.p, (const uint32_t*)S.d_list_off.p,
+                       (const uint32_t*)S.d_part_base.p, Op, P.pb, P.sub_shift, P.submax, S.d_subcur.p, S.d_ulist2.p);
+            const size_t lds_sub = sizeof(uint32_t) << P.sub_shift;
+            FSK_HIP(fsk_hw::allow_dynamic_lds(fsk::k_sxb_consume, lds_sub));
+            FSK_LAUNCH(fsk::k_sxb_consume, dim3(P.submax, Op), dim3(fsk::SXB_THREADS), lds_sub, stream, (const uint32_t*)S.d_ulist2.p,
+                       (const uint32_t*)S.d_suboff.p, (const uint32_t*)S.d_subcnt.p, (const uint32_t*)e->d_blk_r0.p, P.pb, P.sub_shift, P.submax, K);
+            e->st.launches += 6;
+            FSK_HIP(hipStreamSynchronize(stream));  // (the next pass overwrites the band table, the entries' unit marks and the streams)
+            e->sx_saw(words * std::max<u64>(1, total_cells / std::max<u64>(1, cells)), nrec);  // (words per record as if the whole triangle emitted at this rate)
+        }
+        if (k_wait) FSK_HIP(hipStreamWaitEvent(stream, k_wait, 0));
+        if (row1 > row0)
+            FSK_LAUNCH(fsk::k_sx_diag_windows, dim3((uint32_t)((row1 - row0 + 255) / 256), 1), dim3(256), 0, stream, (const uint32_t*)e->d_fstart.p,
+                       (uint32_t)row0, (uint32_t)row1, (uint32_t)nb, K, (u64)0, (const u64*)nullptr, ~(u64)0, 0, (uint32_t*)nullptr);
+        e->st.launches += 1;
+        if (k_done) FSK_HIP(hipEventRecord(k_done, stream));
+        e->toc(&e->st.ms_pairs, stream);
+        FSK_HIP(hipGetLastError());
+        stat_pin[0] = stat_pin[1] = 0;  // (every pass has been added to u_extra already)
+        return FSK_OK;
+    }
     if (packed) {
         auto k_seg = skipping ? (pairs ? fsk::k_sx_seg_write<RecT, true, true, true> : fsk::k_sx_seg_write<RecT, true, false, true>)
                               : (pairs ? fsk::k_sx_seg_write<RecT, true, true, false> : fsk::k_sx_seg_write<RecT, true, false, false>);
@@ -370,14 +567,14 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                    (const int*)S.d_tile_rs.p, reinterpret_cast<uint32_t*>(S.d_E.p), reinterpret_cast<uint16_t*>(S.d_Pk.p), e->sx_own_shift, O,
                    lists ? S.d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, S.d_tile_stat.p,
                    skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr,
-                   skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr);
+                   skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr, 0u);
     } else {
         auto k_seg = skipping ? (pairs ? fsk::k_sx_seg_write<RecT, false, true, true> : fsk::k_sx_seg_write<RecT, false, false, true>)
                               : (pairs ? fsk::k_sx_seg_write<RecT, false, true, false> : fsk::k_sx_seg_write<RecT, false, false, false>);
         FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)S.d_ebase.p,
                    (const int*)S.d_tile_rs.p, S.d_E.p, S.d_Pk.p, e->sx_own_shift, O,
                    lists ? S.d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, S.d_tile_stat.p,
-                   skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr, skipping ? S.d_Tk.p : (uint32_t*)nullptr);
+                   skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr, skipping ? S.d_Tk.p : (uint32_t*)nullptr, 0u);
     }
     stat_pin[0] = stat_pin[1] = 0;
     e->st.launches += 3;
@@ -420,13 +617,13 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                            reinterpret_cast<const uint16_t*>(S.d_Pk.p), (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p,
                            e->sx_own_shift, O, (const uint32_t*)S.d_list_off.p, (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)row0,
                            (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg, slot_stride,
-                           skipping ? reinterpret_cast<const uint16_t*>(S.d_Tk.p) : (const uint16_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles, pairs);
+                           skipping ? reinterpret_cast<const uint16_t*>(S.d_Tk.p) : (const uint16_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles, pairs, 0u);
             } else {
                 auto k_emit = skipping ? fsk::k_sx_emit<false, true, false> : fsk::k_sx_emit<false, false, false>;
                 FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, (const uint2*)S.d_E.p, (const uint32_t*)S.d_Pk.p,
                            (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)S.d_list_off.p,
                            (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
-                           slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles, pairs);
+                           slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles, pairs, 0u);
             }
             const size_t lds = (size_t)e->sx_cap * sizeof(uint32_t), lds_slot = (size_t)e->sx_cap_slot * sizeof(uint32_t);
             FSK_HIP(fsk_hw::allow_dynamic_lds(fsk::k_sx_consume<false>, lds));
@@ -468,13 +665,13 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                        reinterpret_cast<const uint16_t*>(S.d_Pk.p), (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift,
                        O, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod,
                        cmax, e->sx_pb, K, tpg, slot_stride, skipping ? reinterpret_cast<const uint16_t*>(S.d_Tk.p) : (const uint16_t*)nullptr,
-                       (const u64*)nullptr, ~(u64)0, ntiles, 0);
+                       (const u64*)nullptr, ~(u64)0, ntiles, 0, 0u);
         } else {
             auto k_emit = skipping ? fsk::k_sx_emit<true, true, false> : fsk::k_sx_emit<true, false, false>;
             FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, (const uint2*)S.d_E.p, (const uint32_t*)S.d_Pk.p,
                        (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)nullptr,
                        (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
-                       slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)nullptr, ~(u64)0, ntiles, 0);
+                       slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)nullptr, ~(u64)0, ntiles, 0, 0u);
         }
         e->st.launches += 1;
     }
@@ -549,10 +746,11 @@ int sx_pinned(fsk_engine* e, size_t tail_pos_bytes, size_t tail_stat_words) {
 }
 
 // how many words a batch may hold when it is enqueued before its count is known (0: size it exactly)
-u64 sx_guard_for(fsk_engine* e, int lane, u64 nrec) {
+u64 sx_guard_for(fsk_engine* e, int lane, u64 nrec, bool by_slot = false) {
     DevBuf<uint32_t>& ulist = e->sxs[lane].d_ulist;
     if (e->sx_exactly() || e->profile_sync()) return 0;
-    if (!e->sx_lists || e->tune.sparse_global) return ~(u64)0;       // no streams: nothing to size
+    if (!by_slot && e->sx_form == 2) return 0;                          // the two-level form sizes every pass exactly
+    if (by_slot ? (!e->sx_lists || e->sx_form == 1) : e->sx_form != 0) return ~(u64)0;  // no streams: nothing to size
     if (e->sx_wpr == 0) return 0;                                       // (the first batch of these sequences)
     if (e->tune.guard_cap)  // (testing: pretend the stream buffer holds this many words)
         return ulist.reserve((size_t)e->tune.guard_cap) == hipSuccess ? (u64)e->tune.guard_cap : 0;
@@ -593,6 +791,8 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     { int rcz = materialise_zero(e); if (rcz) return rcz; }
     int rc = ensure_featseq(e);
     if (rc) return rc;
+    sx_choose_form(e);
+    const bool blocks_form = e->sx_form == 2 && slot_stride == 0;
     // Batch so that (i) the record count stays below the cap, (ii) the owner bands can sum a batch in u32 LDS cells
     // (per cell and combo <= maxW^2), (iii) a batch's update words stay well inside what one stream addresses
     // (2^31: beyond it the pairs go to K with atomics, an order of magnitude slower) — judged by the most words per
@@ -601,8 +801,9 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     const u64 by_cells = std::max<u64>(1, 0xffffffffull / std::max<u64>(1, (u64)e->maxW * e->maxW));
     auto batch_combos = [&](int left) {
         size_t recs = e->tune.sparse_batch_records ? (size_t)e->tune.sparse_batch_records : SPARSE_MAX_RECORDS;
+        // (the two-level form takes a batch of any word count in passes, and sweeps K once a batch: as many records as the cap allows)
         if (e->sx_wpr == 0) recs = std::min<size_t>(recs, (size_t)1 << 25);
-        else recs = std::min<size_t>(recs, (size_t)std::max(1.0, (double)(e->sx_max_words() / 2) / e->sx_wpr));
+        else if (!blocks_form) recs = std::min<size_t>(recs, (size_t)std::max(1.0, (double)(e->sx_max_words() / 2) / e->sx_wpr));
         const u64 B = std::max<u64>(1, std::min<u64>({(u64)(recs / nfeat), (u64)left, by_cells, (u64)65535}));  // (65535: grid.y)
         return (int)B;
     };
@@ -627,7 +828,7 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
         e->sx_slot16_used = e->sx_slot16 && slot_stride != 0 && e->sx_lists && !e->tune.sparse_global;
         e->sx_ovf_now = e->h_sx_head_flag + defer;
         e->h_sx_head_flag[defer] = 0u;
-        const u64 guard = sx_guard_for(e, lane, (u64)n * nfeat);
+        const u64 guard = sx_guard_for(e, lane, (u64)n * nfeat, slot_stride != 0);
         e->sx_defer[defer].active = guard != 0;
         e->sx_defer[defer].cap = guard;
         e->sx_defer[defer].nrec = (u64)n * nfeat;
@@ -651,7 +852,7 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
         nb_steady = (int)std::max<u64>(1, std::min<u64>({(u64)(recs / nfeat), (u64)n, by_cells, (u64)65535}));
     }
     const bool many = (n + nb_steady - 1) / nb_steady >= 6;
-    const bool two = (e->tune.sparse_exact_lanes >= 2 || (e->tune.sparse_exact_lanes == 0 && many)) && !e->profile_sync() && !e->sx_exactly() && slot_stride == 0 && nb0 < n;
+    const bool two = (e->tune.sparse_exact_lanes >= 2 || (e->tune.sparse_exact_lanes == 0 && many)) && !e->profile_sync() && !e->sx_exactly() && slot_stride == 0 && nb0 < n && !blocks_form;
     if (two) {
         if (!e->lane_stream) FSK_HIP(hipStreamCreateWithFlags(&e->lane_stream, hipStreamNonBlocking));
         for (auto& ev : e->ev_lane)

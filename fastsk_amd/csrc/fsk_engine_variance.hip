@@ -158,7 +158,7 @@ int run_variance_mode(fsk_engine* e, int T, int chain_first, int chain_step) {
     // land in AHEAD separate triangles; dense dataflow: one iteration at a time into the engine's triangle
     // (u32 triangles written whole by k_sx_consume; without update streams — huge N — pairs go to K with
     // atomics and the iterations run one at a time like the dense ones)
-    bool grouped = e->path == FSK_PATH_SPARSE && e->sx_lists && !e->tune.sparse_global;
+    bool grouped = e->path == FSK_PATH_SPARSE && e->sx_lists && !e->tune.sparse_global && e->tune.sparse_form != 3;
     // Dense dataflow with a tile kernel that can STORE (one workgroup per tile, the direct-to-LDS kernel, no
     // key compaction, no test-block filter): every iteration's tile launch stores its counts into a u64
     // triangle of its own — no zero fill — and the batch's Welford updates run as one pass like the sparse

@@ -7,5 +7,6 @@
 namespace fsk {
 
 #include "fsk_sparse_kernels.inc"
+#include "fsk_sparse_blocks.inc"
 
 }  // namespace fsk

@@ -135,6 +135,12 @@ typedef struct fsk_stats {
     double batches_redone;   /* sparse: batches enqueued ahead of their word count that did not fit */
     double combos_issued;    /* combos whose kernels ran: combos_done + the iterations variance mode ran ahead of
                                 its stop test and dropped (cell_updates and the ms_* cover all of them)      */
+    /* ABI 5 */
+    double sparse_form;      /* sparse: the update stage the last batch took — 0 owner bands (k_sx_consume), 1 one 64-bit
+                                atomic per +=, 2 two-level blocks (k_sxb_*); -1: no sparse batch yet               */
+    double sparse_passes;    /* sparse, blocks: passes over disjoint row ranges run since the sequences were loaded */
+    double share_positions;  /* sparse: leading kept positions the last batch sorted once per group of slots (0: none) */
+    double share_groups;     /* ... and the groups it had                                                          */
 } fsk_stats;
 
 /* ---- lifecycle: replaces FastSK::FastSK (fastsk.cpp:19-28) and ~nothing (the reference leaks) */

@@ -1030,3 +1030,44 @@ def test_emu_sparse_shared_leading_positions(emu_lib, port, monkeypatch, case):
             e.finalize()
             assert np.array_equal(e.get_counts()[keep], raw[keep]), (case, share, split)
             e.close()
+
+
+@pytest.mark.parametrize("skip", [False, True])
+def test_emu_sparse_two_level_blocks(emu_lib, port, skip):
+    """The two-level form of the update stage (fsk_sparse_blocks.inc: bands binned by k_sx_emit, every band's stream split by
+    sub-band, one workgroup a sub-band) — what N beyond the owner bands takes instead of one atomic per += — forced on a small
+    input with small blocks: several passes over row ranges (few bands a pass, a word budget that halves ranges), several bands a
+    pass, several sub-bands a band; packed and general entries; protein-like runs with a low-complexity sequence and long DNA
+    runs; whole, in two calls and in row bands; skip_test_block. Against the oracle's counts and its exact U."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(21)
+    N, ntr = 140, 90
+    X1 = [rng.integers(1, 21, size=int(L)).astype(np.int32) for L in rng.integers(20, 30, size=N)]
+    X1[5][:] = 7   # a low-complexity sequence: multiplicities above 1, own cells
+    X2 = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(24, 40, size=N)]  # 64 keys: runs of a hundred entries
+    a, b = np.tril_indices(N)
+    keep = (b < ntr) | (a == b) if skip else np.ones(len(a), dtype=bool)
+    plans = [(X1, 4, 2, np.arange(4, dtype=np.int32), {"sparse_form": 2}, "whole"),
+             (X1, 4, 2, np.arange(4, dtype=np.int32), {"sparse_form": 2, "blocks_sub_shift": 6, "blocks_max_bands": 5, "blocks_band_shift_max": 9}, "row bands"),
+             (X2, 5, 2, np.array([0, 9], dtype=np.int32), {"sparse_form": 2, "blocks_sub_shift": 5, "blocks_max_bands": 12, "blocks_band_shift_max": 8,
+                                                           "blocks_pass_words": 30000, "sparse_unpacked": 1}, "two calls")]
+    for X, g, m, combos, tun, how in plans:
+        tokens, offsets = _native.flatten(X)
+        raw, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=4)
+        e = _native.Engine(g, m, path=2, lib=emu_lib, skip_test_block=skip, tuning=tun)
+        e.load_sequences(tokens, offsets, ntr if skip else N, N - ntr if skip else 0)
+        if how == "whole":
+            e.accumulate(combos)
+        elif how == "two calls":
+            for part in np.array_split(combos, 2):
+                e.accumulate(part)
+        else:
+            for lo, hi in ((0, 128), (128, N)):  # (row bands: multiples of 128)
+                e.accumulate_rows(combos, lo, hi)
+        e.finalize()
+        st = e.stats()
+        assert st["sparse_form"] == 2
+        assert len(tun) == 1 or st["sparse_passes"] > 2
+        assert np.array_equal(e.get_counts()[keep], raw[keep]), (g, m, tun, how)
+        assert skip or st["cell_updates"] == U
+        e.close()

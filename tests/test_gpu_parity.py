@@ -531,6 +531,79 @@ def test_sparse_dataflow_large_n(native, port, N, lo, hi, ncombo, n_sub):
     sub.close()
 
 
+# ---- the two-level form of the update stage (fsk_sparse_blocks.inc): what countAndUpdateTri (shared.cpp:268-333) takes where the
+# owner bands end — bands binned by k_sx_emit, every band's stream split by sub-band, one workgroup a sub-band
+@pytest.mark.parametrize("skip", [False, True])
+def test_sparse_two_level_blocks_100k_protein_like(native, port, skip):
+    """N = 100,000 protein-like ragged sequences (20 letters, 60-220 long), g=10 m=6, four combos: 5 * 10^9 cells — more than
+    one pass's 32-bit cell offsets cover, several passes by word count too — through the blocks form. Random 1400-sequence subset
+    (rows on both sides of 65,535) against the oracle, U on that subset, the digest of the whole triangle against the same combos
+    added with one 64-bit atomic per += (tuning sparse_form=3); with skip_test_block."""
+    N, g, m = 100000, 10, 6
+    X = protein_like(N, 60, 221, seed=100)
+    tokens, offsets = native.flatten(X)
+    combos = np.array([0, 71, 140, 209], dtype=np.int32)
+    n_train = 60000
+    e = native.Engine(g, m, path=2, skip_test_block=skip)
+    e.load_sequences(tokens, offsets, n_train if skip else N, N - n_train if skip else 0)
+    e.accumulate(combos)
+    e.finalize()
+    st = e.stats()
+    assert st["path_used"] == 2 and st["sparse_form"] == 2 and st["sparse_passes"] >= 2 and st["n_seq"] == N
+    rng = np.random.Generator(np.random.PCG64(9))
+    idx = np.sort(np.concatenate([rng.choice(65535, size=800, replace=False), 65535 + rng.choice(N - 65535, size=600, replace=False)]))
+    stoks, soff, U = _subset_against_oracle(native, port, e, X, idx, g, m, combos, n_train if skip else None)
+    dg = e.counts_digest()
+    e.close()
+    if not skip:
+        sub = native.Engine(g, m, path=2, tuning={"sparse_form": 2, "sparse_unpacked": 1})
+        sub.load_sequences(stoks, soff, len(idx), 0)
+        sub.accumulate(combos)
+        sub.finalize()
+        assert sub.stats()["cell_updates"] == U and sub.stats()["sparse_form"] == 2
+        sub.close()
+    d = native.Engine(g, m, path=2, skip_test_block=skip, tuning={"sparse_form": 3})
+    d.load_sequences(tokens, offsets, n_train if skip else N, N - n_train if skip else 0)
+    d.accumulate(combos)
+    d.finalize()
+    assert d.stats()["sparse_form"] == 1 and d.counts_digest() == dg
+    assert skip or d.stats()["cell_updates"] == st["cell_updates"]
+    d.close()
+
+
+def test_sparse_two_level_blocks_forced_small(native, port):
+    """The same form forced on inputs the owner bands hold (tuning sparse_form=2), with small blocks so that one call takes
+    many passes, bands and sub-bands: whole triangles against the oracle, the band form and the atomics, exact U; DNA runs of
+    hundreds of entries (long entries, multiplicities) and protein-like ones; row bands; three calls."""
+    for X, g, m, combos in ((protein_like(1500, 40, 160, seed=31), 10, 6, np.arange(0, 210, 9, dtype=np.int32)),
+                            ([x for x in synthetic_dna(1200, 90, seed=5)[0].reshape(1200, 90)], 9, 4, np.array([0, 50, 125], dtype=np.int32))):
+        N = len(X)
+        tokens, offsets = native.flatten(X)
+        want, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=min(32, os.cpu_count() or 8))
+        for tun in ({"sparse_form": 1}, {"sparse_form": 3}, {"sparse_form": 2},
+                    {"sparse_form": 2, "blocks_sub_shift": 8, "blocks_max_bands": 7, "blocks_band_shift_max": 12},
+                    {"sparse_form": 2, "blocks_sub_shift": 10, "blocks_max_bands": 64, "blocks_band_shift_max": 13, "blocks_pass_words": 400000,
+                     "sparse_unpacked": 1}):
+            for how in ("whole", "three calls", "row bands"):
+                e = native.Engine(g, m, path=2, tuning=tun)
+                e.load_sequences(tokens, offsets, N, 0)
+                if how == "whole":
+                    e.accumulate(combos)
+                elif how == "three calls":
+                    for part in np.array_split(combos, 3):
+                        e.accumulate(part)
+                else:
+                    for lo, hi in ((0, 512), (512, 1024), (1024, N)):
+                        e.accumulate_rows(combos, lo, hi)
+                e.finalize()
+                st = e.stats()
+                assert st["sparse_form"] == {1: 0, 2: 2, 3: 1}[tun["sparse_form"]]
+                assert len(tun) == 1 or st["sparse_passes"] >= 4
+                assert np.array_equal(e.get_counts(), want), (g, m, tun, how)
+                assert st["cell_updates"] == U
+                e.close()
+
+
 # ---- the unpacked entry format (8 + 4 (+ 4) bytes) of the sparse dataflow: N >= 65,535 sequences, or a sequence of >= 65,536
 # windows — k_sx_seg_write<RecT, false> and k_sx_emit<DIRECT | lists, SKIP, false>, the path of countAndUpdateTri
 # (shared.cpp:268-333) for inputs whose ids or multiplicities do not fit 16 bits

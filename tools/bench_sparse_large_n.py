@@ -44,7 +44,7 @@ def make(name):
 
 def run(name, n_combos=0, tuning=None, reps=2):
     tokens, offsets, N, g, m = make(name)
-    e = _native.Engine(g, m, path=_native.PATH_SPARSE, profile=True, tuning=tuning)
+    e = _native.Engine(g, m, path=_native.PATH_SPARSE, profile=2, tuning=tuning)  # (2: the product dataflow, events harvested by stats())
     nc = e.lib.num_combos(g, m)
     if not n_combos:
         n_combos = min(nc, 40)
@@ -63,10 +63,7 @@ def run(name, n_combos=0, tuning=None, reps=2):
         e.synchronize()
         best = min(best, time.perf_counter() - t0)
     st = e.stats()
-    try:
-        form = FORMS.get(e.get_tuning("sparse_form_used"), "?")
-    except Exception:
-        form = "direct" if N > 23000 else "bands"
+    form = FORMS.get(int(st["sparse_form"]), "?")
     per = best / len(combos)
     reps_total = reps + 1
     U = st["cell_updates"] / reps_total / len(combos)
@@ -80,7 +77,7 @@ def run(name, n_combos=0, tuning=None, reps=2):
                 algorithmic_GBs=round(alg / 1e9 / per, 1), frac_of_hbm_peak=round(alg / 1e9 / per / HBM_PEAK_GBS, 4),
                 atomic_added_GBs=round(8.0 * U / 1e9 / per, 1), frac_of_atomic_ceiling=round(8.0 * U / 1e9 / per / ATOMIC_CEILING_GBS, 3),
                 path_used="dense" if st["path_used"] == 1 else "sparse", sparse_form=form,
-                batches_redone=st["batches_redone"], full_kernel_seconds_estimate=round(per * nc, 2),
+                batches_redone=st["batches_redone"], passes=int(st["sparse_passes"]), full_kernel_seconds_estimate=round(per * nc, 2),
                 ms={k: round(st[k] / reps_total, 2) for k in ("ms_extract", "ms_sort", "ms_segment", "ms_pairs", "ms_total")},
                 digest=format(dg[0], "x") + "." + format(dg[1], "x"))
 
