@@ -306,6 +306,15 @@ def other_configs(_native):
                         "k_digest": digest}
     except Exception as exc:  # the headline line must not depend on the extras
         out["error"] = repr(exc)
+    # the sparse dataflow beyond the owner bands (N = 32k / 64k / 100k protein-like, DNA k = 8 at N = 32k): ms a combo, U,
+    # algorithmic bytes, fraction of the HBM roofline and of the 64-bit-atomic ceiling, the form the update stage took
+    # (tools/bench_sparse_large_n.py; 20 combos each, a few seconds in all)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_sparse_large_n as large_n
+        out["sparse_large_n"] = {name: large_n.run(name, 20) for name in large_n.DEFAULT}
+    except Exception as exc:
+        out["sparse_large_n_error"] = repr(exc)
     return out or None
 
 

@@ -421,6 +421,14 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
         g_create_error = "cannot create HIP stream/events";
         return FSK_EDEVICE;
     }
+#ifndef FSK_EMU
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->cfg.device) == hipSuccess && cus > 0) e->n_cu = cus;
+    }
+#else
+    e->n_cu = 2;  // (the emulation: a few persistent workgroups, so that chunks of several tiles and several bands occur)
+#endif
     e->st.n_combos_total = (int32_t)e->ncomb;
     *out = e;
     return FSK_OK;

@@ -106,10 +106,11 @@ using fsk_detail::DevBuf;
     X(list_max_words, 0, 0, (int64_t)1 << 31, "sparse: update words of one batch beyond which its pairs go to K with atomics (0: 2^31)") \
     X(seg_scan_chunked, 0, 0, 1, "sparse: the three-launch segment scan whatever the tile count")                                    \
     X(extract_slots, 0, 0, 4, "sparse: slots per k_sx_extract_win workgroup, 1 or 4 (0: by the size of the launch)")                  \
-    X(sparse_form, 0, 0, 3, "sparse: the update stage — 1 = owner bands whenever they exist, 2 = two-level blocks, 3 = 64-bit atomics (0: bands up to three LDS rounds a band, blocks beyond)") \
+    X(sparse_form, 0, 0, 3, "sparse: the update stage — 1 = owner bands whenever they exist, 2 = two-level blocks, 3 = 64-bit atomics (0: bands up to four LDS rounds a band, blocks beyond)") \
     X(blocks_sub_shift, 14, 4, 14, "sparse, blocks: log2 of the cells one k_sxb_consume workgroup sums in LDS (tests: small blocks on small inputs)") \
     X(blocks_max_bands, 512, 2, 512, "sparse, blocks: bands of one pass at most (tests: several passes on small inputs)")            \
     X(blocks_band_shift_max, 23, 4, 23, "sparse, blocks: log2 of a band's cells at most (tests)")                                    \
+    X(blocks_scatter_threads, 0, 0, 1024, "sparse, blocks: threads of a k_sxb_scatter workgroup, 256 / 512 / 1024 (0: 256)")          \
     X(blocks_pass_words, 0, 0, (int64_t)1 << 32, "sparse, blocks: update words of one pass at most (0: 2^31)")                       \
     X(sparse_share, 0, -1, 254, "sparse: leading kept positions sorted once per group of consecutive combos that share them (0: by cost; -1: never)") \
     X(seed_splitmix, 0, 0, 1, "approx modes: 1 = fsk_set_seed draws the engine's older splitmix64 Fisher-Yates order (0: the reference's std::shuffle of minstd_rand0)") \
@@ -243,6 +244,7 @@ struct fsk_engine {
     int sx_pb = 16, sx_sb = 1, sx_keybits = 1, sx_own_shift = 13;
     int sx_symbits = 0;  // != 0: the k-mer space passes 2^62 and a key is the symbols' sx_symbits-bit fields side by side, not a mixed-radix number
     bool sx_lists = false, owner_ready = false;
+    int n_cu = 256;   // compute units of the device (persistent launches)
     int sx_form = 0;  // the update stage of the sparse dataflow for these sequences: 0 = owner bands, 1 = 64-bit atomics, 2 = two-level blocks
     int sx_form_used = -1;  // ... what the last batch really took (tuning key sparse_form_used reads it)
     u64 sx_passes = 0;      // blocks form: passes run since the sequences were loaded

@@ -18,7 +18,7 @@ constexpr uint32_t SX_MAX_ROUNDS = 16;
 constexpr uint32_t SX_CAP_SLOT = 20480;   // by-slot form (no parts table in LDS): 80 KiB, two workgroups per CU
 
 // ---- two-level form (fsk_sparse_blocks.inc): the bands of ONE pass over rows [ra, rb) ------------------------------
-constexpr uint32_t SX_BLOCKS_FROM_ROUNDS = 3;  // the owner bands up to this many LDS rounds a band, blocks beyond
+constexpr uint32_t SX_BLOCKS_FROM_ROUNDS = 4;  // the owner bands up to this many LDS rounds a band, blocks beyond (measured: protein-like N = 8,000, four rounds: bands 0.041 ms a combo, blocks 0.046; N = 12,000, fourteen rounds: 0.133 against 0.075)
 // Bands of 2^t cells counted from the pass's first row, t the smallest that leaves at most `blocks_max_bands` bands; a band's
 // cell offsets (2^t + a row at most) and an 8-bit product at least share the 32-bit word, so t <= 23 and a pass covers
 // fewer than 2^32 cells. false: rows [ra, rb) do not fit one pass (the caller halves the range) or the sub-bands of a band
@@ -532,19 +532,30 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                            (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)ra, (uint32_t)rb, e->maxW, maxprod_p, cmax_p, P.pb, K, tpg, (u64)0,
                            skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)S.d_sxstat.p, ~(u64)0, ntiles, 0, P.own_base);
             }
-            const uint32_t n_split = Op + (uint32_t)((words + fsk::SXB_TILE - 1) / fsk::SXB_TILE);  // tiles of the bands' streams, at most
+            // (persistent launches: two workgroups of 1024 threads a CU walk the tiles of the bands' streams in contiguous chunks)
+            const uint32_t n_tiles_max = Op + (uint32_t)((words + fsk::SXB_TILE - 1) / fsk::SXB_TILE);
+            const uint32_t n_split = std::min<uint32_t>(n_tiles_max, 2u * (uint32_t)std::max(1, e->n_cu));
             FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, stream, (const uint32_t*)S.d_list_off.p, Op, (uint32_t)fsk::SXB_TILE, S.d_part_base.p,
                        (const u64*)S.d_sxstat.p, ~(u64)0);
             FSK_LAUNCH(fsk::k_sxb_count, dim3(n_split), dim3(fsk::SXB_THREADS), 0, stream, (const uint32_t*)S.d_ulist.p, (const uint32_t*)S.d_list_off.p,
                        (const uint32_t*)S.d_part_base.p, Op, P.pb, P.sub_shift, P.submax, S.d_subcnt.p);
             FSK_LAUNCH(fsk::k_sxb_scan, dim3(Op), dim3(fsk::SXB_THREADS), 0, stream, (const uint32_t*)S.d_subcnt.p, (const uint32_t*)S.d_list_off.p, P.submax,
                        S.d_suboff.p, S.d_subcur.p);
-            FSK_LAUNCH(fsk::k_sxb_scatter, dim3(n_split), dim3(fsk::SXB_THREADS), 0, stream, (const uint32_t*)S.d_ulist.p, (const uint32_t*)S.d_list_off.p,
-                       (const uint32_t*)S.d_part_base.p, Op, P.pb, P.sub_shift, P.submax, S.d_subcur.p, S.d_ulist2.p);
+            {   // (workgroups of 256 threads, three a CU by their LDS; tuning blocks_scatter_threads: 512 / 1024 for the A/B)
+                const int nt = e->tune.blocks_scatter_threads ? (int)e->tune.blocks_scatter_threads : 256;
+                const uint32_t per_cu = nt == 1024 ? 2u : 3u;
+                const uint32_t grid = std::min<uint32_t>(n_tiles_max, per_cu * (uint32_t)std::max(1, e->n_cu));
+                auto k_sc = nt == 1024 ? fsk::k_sxb_scatter<1024> : nt == 512 ? fsk::k_sxb_scatter<512> : fsk::k_sxb_scatter<256>;
+                FSK_LAUNCH(k_sc, dim3(grid), dim3((uint32_t)nt), 0, stream, (const uint32_t*)S.d_ulist.p, (const uint32_t*)S.d_list_off.p,
+                           (const uint32_t*)S.d_part_base.p, Op, P.pb, P.sub_shift, P.submax, S.d_subcur.p, S.d_ulist2.p);
+            }
             const size_t lds_sub = sizeof(uint32_t) << P.sub_shift;
-            FSK_HIP(fsk_hw::allow_dynamic_lds(fsk::k_sxb_consume, lds_sub));
-            FSK_LAUNCH(fsk::k_sxb_consume, dim3(P.submax, Op), dim3(fsk::SXB_THREADS), lds_sub, stream, (const uint32_t*)S.d_ulist2.p,
-                       (const uint32_t*)S.d_suboff.p, (const uint32_t*)S.d_subcnt.p, (const uint32_t*)e->d_blk_r0.p, P.pb, P.sub_shift, P.submax, K);
+            {   // (a block of 2^13 cells and fewer: workgroups of 512 threads, four a CU)
+                auto k_cs = P.sub_shift <= 13 ? fsk::k_sxb_consume<512> : fsk::k_sxb_consume<1024>;
+                FSK_HIP(fsk_hw::allow_dynamic_lds(k_cs, lds_sub));
+                FSK_LAUNCH(k_cs, dim3(P.submax, Op), dim3(P.sub_shift <= 13 ? 512u : 1024u), lds_sub, stream, (const uint32_t*)S.d_ulist2.p,
+                           (const uint32_t*)S.d_suboff.p, (const uint32_t*)S.d_subcnt.p, (const uint32_t*)e->d_blk_r0.p, P.pb, P.sub_shift, P.submax, K);
+            }
             e->st.launches += 6;
             FSK_HIP(hipStreamSynchronize(stream));  // (the next pass overwrites the band table, the entries' unit marks and the streams)
             e->sx_saw(words * std::max<u64>(1, total_cells / std::max<u64>(1, cells)), nrec);  // (words per record as if the whole triangle emitted at this rate)

@@ -28,7 +28,14 @@ WORKLOADS = {
     "protein_like_64k": (64000, 20, 60, 220, 10, 6),
     "protein_like_100k": (100000, 20, 60, 220, 10, 6),
     "dna_k8_32k": (32000, 4, 300, 300, 12, 4),
+    # where the owner bands take several LDS rounds a band (the crossover to the two-level form): not part of the default list
+    "protein_like_6k": (6000, 20, 60, 220, 10, 6),
+    "protein_like_8k": (8000, 20, 60, 220, 10, 6),
+    "protein_like_12k": (12000, 20, 60, 220, 10, 6),
+    "protein_like_16k": (16000, 20, 60, 220, 10, 6),
+    "protein_like_20k": (20000, 20, 60, 220, 10, 6),
 }
+DEFAULT = ["protein_like_32k", "protein_like_64k", "protein_like_100k", "dna_k8_32k"]
 FORMS = {0: "bands", 1: "direct", 2: "blocks"}
 
 
@@ -42,9 +49,9 @@ def make(name):
     return tokens, offsets, N, g, m
 
 
-def run(name, n_combos=0, tuning=None, reps=2):
+def run(name, n_combos=0, tuning=None, reps=2, lib=None):
     tokens, offsets, N, g, m = make(name)
-    e = _native.Engine(g, m, path=_native.PATH_SPARSE, profile=2, tuning=tuning)  # (2: the product dataflow, events harvested by stats())
+    e = _native.Engine(g, m, path=_native.PATH_SPARSE, profile=2, tuning=tuning, lib=lib)  # (2: the product dataflow, events harvested by stats())
     nc = e.lib.num_combos(g, m)
     if not n_combos:
         n_combos = min(nc, 40)
@@ -83,7 +90,7 @@ def run(name, n_combos=0, tuning=None, reps=2):
 
 
 def main():
-    names = list(WORKLOADS)
+    names = list(DEFAULT)
     n_combos, tuning = 0, None
     args = sys.argv[1:]
     if "--quick" in args:
@@ -94,8 +101,9 @@ def main():
         n_combos = int(args[args.index("--combos") + 1])
     if "--tuning" in args:
         tuning = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args[args.index("--tuning") + 1].split(",")}
+    lib = _native.Library(args[args.index("--lib") + 1]) if "--lib" in args else None   # (a variant build: tools/build_variant.sh)
     for name in names:
-        print(json.dumps(run(name, n_combos, tuning)), flush=True)
+        print(json.dumps(run(name, n_combos, tuning, lib=lib)), flush=True)
 
 
 if __name__ == "__main__":
