@@ -390,6 +390,7 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
     }
     if (cfg->g > 255) { g_create_error = "g > 255 unsupported"; return FSK_EUNSUPPORTED; }
     if (cfg->t == 0 || cfg->t < -1) { g_create_error = "t must be -1 or >= 1"; return FSK_EINVAL; }
+    if (cfg->profile < 0 || cfg->profile > 2) { g_create_error = "profile must be 0, 1 or 2"; return FSK_EINVAL; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         g_create_error = "no HIP device visible: the MI355X engine has no CPU fallback";
@@ -413,6 +414,7 @@ int fsk_create(const fsk_config* cfg, fsk_engine** out) {
             return FSK_EINVAL;
         }
     }
+    e->cfg_profile0 = e->cfg.profile;  // (what tuning key profile = -1 goes back to)
     if (e->tune.profile >= 0) e->cfg.profile = (int)e->tune.profile;
     if (e->trace()) fprintf(stderr, "[fsk] tuning: %s\n", tuning_in_force(e->tune).c_str());
     if (hipStreamCreate(&e->stream) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
@@ -1348,9 +1350,10 @@ extern "C" int fsk_set_tuning(fsk_engine* e, const char* key, int64_t value) {
     // (a group: every engine runs with the same tuning; the group's own keys are read from engine 0 by fsk_multi.hip)
     const int rc = e->group ? fsk_detail::group_set_tuning(e, key, value, why) : fsk_detail::tuning_set(e->tune, key, value, why);
     if (rc) return e->fail(rc, "%s", why.c_str());
-    if (e->tune.profile >= 0) {  // (a group: every engine)
-        if (e->group) fsk_detail::group_set_profile(e, (int)e->tune.profile);
-        else { e->harvest_times(); e->cfg.profile = (int)e->tune.profile; }
+    {   // the profile key: 0 .. 2 from here on, -1 = as the engine was created (a group: every engine)
+        const int want = e->tune.profile >= 0 ? (int)e->tune.profile : e->cfg_profile0;
+        if (e->group) fsk_detail::group_set_profile(e, want);
+        else if (want != e->cfg.profile) { e->harvest_times(); e->cfg.profile = want; }
     }
     if (e->trace()) fprintf(stderr, "[fsk] tuning: %s\n", fsk_detail::tuning_in_force(e->tune).c_str());
     return FSK_OK;
@@ -1372,3 +1375,43 @@ extern "C" const char* fsk_tuning_keys(void) {
     }();
     return text.c_str();
 }
+
+#ifdef FSK_TEST_HOOKS
+// ---- test builds only (tests/hooks, the CPU emulation; never the product): the hand-written wave primitives of fsk_gfx950.h,
+// one call each per element, for a direct comparison with their definitions (tests/test_gpu_parity.py::test_wave_primitives) —
+// the emulator replaces them with shuffle loops, so the kernels' own tests never run the inline asm on the CPU.
+namespace fsk {
+__global__ __launch_bounds__(256) void k_test_wave_ops(const int32_t* in, const uint32_t* aux, int32_t n, int32_t* out_max, uint32_t* out_sum,
+                                                       u64* out_sum64, uint32_t* out_xnor, int32_t* out_sbfe, uint32_t* out_mbcnt) {
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    const int32_t v = i < n ? in[i] : 0;  // (whole waves call the primitives: n is a multiple of 64)
+    const uint32_t a = i < n ? aux[i] : 0u;
+    const int32_t mx = fsk_hw::wave_incl_max_i32(v);
+    const uint32_t sm = fsk_hw::wave_incl_sum_u32((uint32_t)v & 0xffffu);
+    const u64 s64 = fsk_hw::wave_incl_sum_u64(((u64)a << 20) | ((uint32_t)v & 0xfffffu));
+    const uint32_t xn = fsk_hw::and_xnor((uint32_t)v, a, a * 2654435761u);
+    const int32_t sb = fsk_hw::sbfe1((uint32_t)v, (int)(a & 31u));
+    const unsigned long long bal = __ballot((a & 1u) != 0u);
+    const uint32_t mb = fsk_mbcnt((uint32_t)bal, (uint32_t)(bal >> 32));
+    if (i < n) { out_max[i] = mx; out_sum[i] = sm; out_sum64[i] = s64; out_xnor[i] = xn; out_sbfe[i] = sb; out_mbcnt[i] = mb; }
+}
+}  // namespace fsk
+extern "C" int fsk_test_wave_ops(const int32_t* in, const uint32_t* aux, int32_t n, int32_t* out_max, uint32_t* out_sum, unsigned long long* out_sum64,
+                                 uint32_t* out_xnor, int32_t* out_sbfe, uint32_t* out_mbcnt) {
+    if (n <= 0 || n % 64) return FSK_EINVAL;
+    void* d[8] = {nullptr};
+    const size_t sz[8] = {4, 4, 4, 4, 8, 4, 4, 4};
+    bool ok = true;
+    for (int q = 0; q < 8 && ok; ++q) ok = hipMalloc(&d[q], sz[q] * (size_t)n) == hipSuccess;
+    if (ok) ok = hipMemcpy(d[0], in, 4 * (size_t)n, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d[1], aux, 4 * (size_t)n, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        FSK_LAUNCH(fsk::k_test_wave_ops, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t) nullptr, (const int32_t*)d[0], (const uint32_t*)d[1], n,
+                   (int32_t*)d[2], (uint32_t*)d[3], (u64*)d[4], (uint32_t*)d[5], (int32_t*)d[6], (uint32_t*)d[7]);
+        ok = hipDeviceSynchronize() == hipSuccess;
+    }
+    void* host[8] = {nullptr, nullptr, out_max, out_sum, out_sum64, out_xnor, out_sbfe, out_mbcnt};
+    for (int q = 2; q < 8 && ok; ++q) ok = hipMemcpy(host[q], d[q], sz[q] * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess;
+    for (int q = 0; q < 8; ++q) if (d[q]) (void)hipFree(d[q]);
+    return ok ? FSK_OK : FSK_EDEVICE;
+}
+#endif

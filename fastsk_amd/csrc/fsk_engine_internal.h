@@ -112,7 +112,7 @@ using fsk_detail::DevBuf;
     X(blocks_band_shift_max, 23, 4, 23, "sparse, blocks: log2 of a band's cells at most (tests)")                                    \
     X(blocks_scatter_threads, 0, 0, 1024, "sparse, blocks: threads of a k_sxb_scatter workgroup, 256 / 512 / 1024 (0: 256)")          \
     X(blocks_pass_words, 0, 0, (int64_t)1 << 32, "sparse, blocks: update words of one pass at most (0: 2^31)")                       \
-    X(sparse_share, 0, -1, 254, "sparse: leading kept positions sorted once per group of consecutive combos that share them (0: by cost; -1: never)") \
+    X(sparse_share, 0, -1, 254, "sparse: leading kept positions sorted once per group of consecutive combos that share them (0: by cost; -1: never); batches of more than 16 slots only (smaller ones read their positions by id), and never when the presort's scratch passes a quarter of the free memory") \
     X(seed_splitmix, 0, 0, 1, "approx modes: 1 = fsk_set_seed draws the engine's older splitmix64 Fisher-Yates order (0: the reference's std::shuffle of minstd_rand0)") \
     X(collective, 0, 0, 2, "fsk_create_multi: FSK_COLL_* when fsk_config.collective is FSK_COLL_AUTO")                                \
     X(deadline_ms, 120000, -1, 86400000, "fsk_create_multi: the fail-fast bound when fsk_config.deadline_ms is 0 (negative: none)")   \
@@ -162,6 +162,7 @@ struct SxScratch {
 
 struct fsk_engine {
     fsk_config cfg{};
+    int cfg_profile0 = 0;  // fsk_config.profile as the engine was created (tuning key profile = -1 restores it)
     fsk_tuning tune{};  // (fsk_set_tuning / FSK_TUNING at fsk_create; see FSK_TUNING_KEYS)
     std::string err;
     int k = 0;
@@ -329,10 +330,29 @@ struct fsk_engine {
         }
         lazy_pending.clear();
     }
+    // the intervals whose end event has been reached already (never a wait: profile = 2 leaves the dataflow alone)
+    void harvest_finished() {
+        size_t keep = 0;
+        for (size_t i = 0; i < lazy_pending.size(); ++i) {
+            const LazyTime t = lazy_pending[i];
+            float ms = 0;
+            if (hipEventQuery(t.b) == hipSuccess) {
+                if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) *t.acc += ms;
+                lazy_free.push_back(t.a);
+                lazy_free.push_back(t.b);
+            } else {
+                (void)hipGetLastError();
+                lazy_pending[keep++] = t;
+            }
+        }
+        lazy_pending.resize(keep);
+    }
     void lazy_interval(hipEvent_t a, hipEvent_t b, double* acc) {
         if (!a || !b) { if (a) lazy_free.push_back(a); if (b) lazy_free.push_back(b); return; }
         lazy_pending.push_back(LazyTime{a, b, acc});
-        if (lazy_pending.size() >= 512) harvest_times();
+        // (a long accumulate: collect what has finished; what has not stays pending — the vector grows, nothing blocks.
+        // Only fsk_get_stats, a change of mode and fsk_destroy wait: harvest_times)
+        if (lazy_pending.size() >= 512 && lazy_pending.size() % 128 == 0) harvest_finished();
     }
     void tic(hipStream_t s = nullptr) {
         if (cfg.profile == 1) (void)hipEventRecord(ev0, s ? s : stream);

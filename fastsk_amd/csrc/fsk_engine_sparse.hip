@@ -157,6 +157,8 @@ SxShare sx_plan_share(fsk_engine* e, const int32_t* combos, int nb, int recbits_
     SxShare best;
     const int k = e->k, want = (int)e->tune.sparse_share;
     if (want < 0 || k < 2 || nb < 2 || !e->win_words || e->nfeat < 2) return best;
+    size_t mem_free = 0, mem_total = 0;
+    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 0;
     // (the presort is half a dozen launches: a batch below 2^24 records does not win them back)
     if (want == 0 && (u64)nb * (u64)e->nfeat < ((u64)1 << 24)) return best;
     // groups[s] = runs of consecutive slots with the same first s kept positions
@@ -187,6 +189,8 @@ SxShare sx_plan_share(fsk_engine* e, const int32_t* combos, int nb, int recbits_
             tb = sx_bits_below(tv); lb = sx_bits_below(lv);
         }
         if (tb < 1 || lb < 1 || tb + lb + e->sx_sb > recbits_max || tb + wb > 64) continue;
+        // (the presort's scratch: the windows and a part record of every group — never more than a quarter of what is free)
+        if (mem_free && (double)groups[s] * (double)e->nfeat * (4.0 * e->win_words + recbits_max / 8.0) > 0.25 * (double)mem_free) continue;
         const bool pre64 = tb + wb > 32;
         const double c = nb * cost_slot(lb) + groups[s] * (13.6 + (pre64 ? 2.2 : 0.0) + 1.65 * passes(tb));
         if (c < best_cost) {

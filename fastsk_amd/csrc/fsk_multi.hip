@@ -597,6 +597,10 @@ int member_await_exchange(fsk_group* g, int r) {
     for (int b = 0; b < g->bands_in_flight && b < (int)g->ev_xb[(size_t)r].size(); ++b) {
         // The deadline bounds a band's EXCHANGE, so its clock starts when the band's own kernels have run (the accumulate is
         // asynchronous: a long one — many combos, the sparse dataflow at large g — is not a peer that does not answer).
+        // (That wait has a bound of its own, generous — the band's kernels are this engine's own work, minutes at the largest
+        // inputs —: a compute kernel that never finishes must not leave the worker polling for ever.)
+        const auto tc0 = std::chrono::steady_clock::now();
+        const long long compute_bound_ms = std::max<long long>(600000, 100ll * g->deadline_ms);
         for (;;) {
             const hipError_t q = hipEventQuery(g->ev_cb[(size_t)r][(size_t)b]);
             if (q == hipSuccess) break;
@@ -607,6 +611,12 @@ int member_await_exchange(fsk_group* g, int r) {
                 return code;
             }
             if (g->poisoned.load()) return g->poisoned_rc(e);
+            if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - tc0).count() > compute_bound_ms) {
+                const int code = e->fail(FSK_EDEVICE, "the kernels of band %d of %d did not finish within %lld ms on device %d (engine %d)", b,
+                                         g->bands_in_flight, compute_bound_ms, e->cfg.device, r);
+                g->poison(e->err);
+                return code;
+            }
             std::this_thread::sleep_for(std::chrono::microseconds(200));
         }
         const auto t0 = std::chrono::steady_clock::now();
@@ -768,6 +778,7 @@ int group_set_tuning(fsk_engine* lead, const char* key, int64_t value, std::stri
 
 void group_set_profile(fsk_engine* lead, int profile) {
     for (fsk_engine* e : lead->group->member) {
+        if (e->cfg.profile == profile) continue;
         DeviceScope on(e->cfg.device);
         e->harvest_times();
         e->cfg.profile = profile;

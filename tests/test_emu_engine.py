@@ -30,6 +30,14 @@ def run_case(emu_lib, d, path):
     return e
 
 
+def test_emu_wave_primitives_stand_ins(emu_lib):
+    """The emulator's shuffle-loop stand-ins for the wave primitives meet the same definitions the GPU's inline asm is checked
+    against (tests/test_gpu_parity.py::test_wave_primitives)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_parity import _wave_primitives_check
+    _wave_primitives_check(emu_lib)
+
+
 def test_emu_seed_is_the_references_seed(emu_lib):
     """approx mode with fsk_set_seed(S) and no injected order == the reference run with time(0) == S (fastsk_kernel.cpp:31-38):
     variance mode (stdevs included) and skip-variance, both dataflows; the older splitmix order stays behind a tuning key."""

@@ -531,6 +531,39 @@ def test_sparse_dataflow_large_n(native, port, N, lo, hi, ncombo, n_sub):
     sub.close()
 
 
+def _wave_primitives_check(lib):
+    """fsk_test_wave_ops (test builds only): wave_incl_max_i32 (six hand-written v_max_i32_dpp), wave_incl_sum_u32 / _u64,
+    and_xnor (v_bitop3), sbfe1, mbcnt ranking — against their definitions, on random, negative and packed (entry << 10 | count)
+    values. The CPU emulation swaps these for shuffle loops, so only this runs the inline asm against a reference."""
+    import ctypes as C
+    rng = np.random.Generator(np.random.PCG64(64))
+    n = 64 * 512
+    v = rng.integers(-2 ** 31, 2 ** 31, size=n, dtype=np.int64).astype(np.int32)
+    v[:64 * 128] = ((rng.integers(0, 2048, size=64 * 128) << 10) | rng.integers(0, 1024, size=64 * 128)).astype(np.int32)  # what k_sx_seg_write scans
+    v[64 * 128:64 * 160] = -1
+    v[64 * 160:64 * 192] = rng.integers(-5, 5, size=64 * 32).astype(np.int32)
+    aux = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+    out = [np.zeros(n, dtype=t) for t in (np.int32, np.uint32, np.uint64, np.uint32, np.int32, np.uint32)]
+    fn = lib.L.fsk_test_wave_ops
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p] * 2 + [C.c_int32] + [C.c_void_p] * 6
+    assert fn(v.ctypes.data, aux.ctypes.data, n, *[o.ctypes.data for o in out]) == 0
+    V, A = v.reshape(-1, 64), aux.reshape(-1, 64)
+    assert np.array_equal(out[0].reshape(-1, 64), np.maximum.accumulate(V, axis=1))
+    assert np.array_equal(out[1].reshape(-1, 64), np.cumsum(V.astype(np.uint32) & 0xffff, axis=1, dtype=np.uint32))
+    w64 = (A.astype(np.uint64) << np.uint64(20)) | (V.astype(np.uint32).astype(np.uint64) & np.uint64(0xfffff))
+    assert np.array_equal(out[2].reshape(-1, 64), np.cumsum(w64, axis=1, dtype=np.uint64))
+    t = (A.astype(np.uint64) * np.uint64(2654435761)).astype(np.uint32)
+    assert np.array_equal(out[3].reshape(-1, 64), V.astype(np.uint32) & ~(A ^ t))
+    assert np.array_equal(out[4].reshape(-1, 64), -(((V.astype(np.uint32) >> (A & 31)) & 1).astype(np.int32)))
+    bit = (A & 1).astype(np.uint32)
+    assert np.array_equal(out[5].reshape(-1, 64), np.cumsum(bit, axis=1, dtype=np.uint32) - bit)
+
+
+def test_wave_primitives(native):
+    _wave_primitives_check(hooks_library(native))
+
+
 # ---- the two-level form of the update stage (fsk_sparse_blocks.inc): what countAndUpdateTri (shared.cpp:268-333) takes where the
 # owner bands end — bands binned by k_sx_emit, every band's stream split by sub-band, one workgroup a sub-band
 @pytest.mark.parametrize("skip", [False, True])
