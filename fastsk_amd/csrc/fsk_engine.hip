@@ -457,7 +457,7 @@ void fsk_detail::one_destroy(fsk_engine* e) {
     if (e->lazy_open) (void)hipEventDestroy(e->lazy_open);
     for (hipEvent_t ev : e->lazy_free) (void)hipEventDestroy(ev);
     for (auto& lane : e->sxs) lane.release();
-    e->d_owner_r0.release(); e->d_U.release(); e->d_U2.release();
+    e->d_owner_r0.release(); e->d_U.release(); e->d_U2.release(); e->d_stage32.release(); e->d_blk_r0.release();
     if (e->h_prod) (void)hipHostFree(e->h_prod);
     if (e->h_sx_pos) (void)hipHostFree(e->h_sx_pos);
     if (e->h_sx_stat) (void)hipHostFree(e->h_sx_stat);

@@ -345,7 +345,12 @@ int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_
                        (const uint32_t*)e->d_rowmask.p, (const uint32_t*)e->d_tiletab.p, (uint32_t)n_tiles, (uint32_t)nb, nst, compact ? 1 : 0,
                        e->d_U.p + 1);
         e->tic();
-        if (compact)
+        // (small N, the combo range split over several workgroups a tile: their sums through 32-bit staging blocks, not atomics)
+        const bool small = n_splits >= 2 && e->tune.dense_small != 0 && dense_small_stage_bytes(n_tiles, n_splits) <= ((size_t)2 << 30);
+        if (small) {
+            const int rcs = dense_tile_small(e, compact, n_tiles, n_splits, nb, Vq8, nst, K, slots_per_split);
+            if (rcs) return rcs;
+        } else if (compact)
             FSK_LAUNCH(fsk::k_dense_tile_dma_compact, dim3((uint32_t)n_tiles, n_splits), dim3(256), 0, e->stream, e->d_C4.p, e->d_C4H.p,
                        e->d_rowmask.p, e->d_tiletab.p, nb, Vq8, nst, (uint32_t)e->N, K, slots_per_split, 0, (const uint16_t*)e->d_vc.p);
         else

@@ -92,6 +92,7 @@ using fsk_detail::DevBuf;
     X(compact, -1, -1, 1, "dense: key compaction off / on whatever the alphabet says (-1: a rare symbol decides)")                   \
     X(compact_rare, -1, -1, 1, "dense: keys that occur from the places of the rare symbols (1) or a marking pass over every window (0)") \
     X(tile_splits, 0, 0, 4096, "dense: combo splits per tile (0: by the size of the launch)")                                        \
+    X(dense_small, 0, 0, 1, "dense: 1 = a split tile launch (small N) leaves its sums as 32-bit staging blocks that k_dense_widen adds into K (0: one 64-bit atomic a cell and split — measured faster: the atomics drain under other workgroups' dot products)")                                        \
     X(dense_chunk, 0, 0, 1 << 24, "dense: cap of the count kernel's staging chunk, in windows (0: none)")                             \
     X(variance_dense_slots, 1, 0, 1, "variance mode, dense: 0 = zero fill + k_welford per iteration instead of storing slot triangles") \
     X(var_slots16, 1, 0, 1, "variance mode, sparse: 0 = u32 slot triangles from the start")                                          \
@@ -217,6 +218,7 @@ struct fsk_engine {
 
     // dense scratch
     DevBuf<uint32_t> d_C4, d_C4H, d_rowmask, d_flag;  // lo / hi nibble planes, per-row hi masks
+    DevBuf<uint32_t> d_stage32;   // small N: the split tile launch's staging blocks (fsk_engine_dense_small.hip)
     DevBuf<uint32_t> d_keybits;   // key compaction: per-combo bitmap of the keys that occur
     DevBuf<uint16_t> d_lut, d_vc; //                  rank table and key count per combo
     bool compact = false;         // decided at load: the alphabet has a rare symbol
@@ -407,6 +409,9 @@ struct DensePlan { uint32_t CH = 0, Vcq = 0; size_t lds = 0; };
 DensePlan dense_plan(uint32_t maxW, int g, uint32_t Vq, size_t extra = 0);
 int fetch_pending_u(fsk_engine* e);
 int accumulate_dense(fsk_engine* e, const int32_t* combos, int n, u64* K, int64_t row0, int64_t row1);
+// fsk_engine_dense_small.hip: the split tile launch at small N through 32-bit staging blocks
+size_t dense_small_stage_bytes(u64 n_tiles, int n_splits);
+int dense_tile_small(fsk_engine* e, bool compact, u64 n_tiles, int n_splits, int nb, uint32_t Vq8, uint32_t nst, u64* K, int slots_per_split);
 
 // fsk_engine_sparse.hip
 // which lane (scratch set + stream) the deferred batch `defer` of variance mode runs in
