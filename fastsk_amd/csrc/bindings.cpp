@@ -34,14 +34,56 @@ namespace {
 struct Flat {
     std::vector<int32_t> tokens;
     std::vector<int64_t> offsets{0};
-    void add(const std::vector<std::vector<int>>& X) {
-        size_t total = tokens.size();
-        for (auto& r : X) total += r.size();
-        tokens.reserve(total);
-        for (auto& r : X) {
-            tokens.insert(tokens.end(), r.begin(), r.end());
+    // The rows of X — what FastaUtility.read_data returns (a list of lists of ints), or any sequence of sequences, of int32
+    // arrays, or a 2-D integer array — straight into the packed token buffer: the reference's signature copies a
+    // std::vector<std::vector<int>> by value (fastsk.cpp:30), i.e. every token twice through pybind's generic casters before
+    // the engine sees it; here a list row is one PyLong_AsLong per token and an int32 array row one memcpy.
+    size_t add(const py::handle& X) {
+        if (py::isinstance<py::array>(X)) {
+            auto a = py::array_t<int32_t, py::array::c_style | py::array::forcecast>::ensure(X);
+            if (a && a.ndim() == 2) {
+                const py::ssize_t n = a.shape(0), L = a.shape(1);
+                tokens.insert(tokens.end(), a.data(), a.data() + n * L);
+                for (py::ssize_t i = 0; i < n; ++i) offsets.push_back(offsets.back() + L);
+                return (size_t)n;
+            }
+        }
+        PyObject* seq = PySequence_Fast(X.ptr(), "expected a sequence of token sequences");
+        if (!seq) throw py::error_already_set();
+        py::object hold = py::reinterpret_steal<py::object>(seq);
+        const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
+        PyObject** rows = PySequence_Fast_ITEMS(seq);
+        {   // one reservation for every row whose length is cheap to ask for
+            size_t total = tokens.size();
+            for (Py_ssize_t i = 0; i < n; ++i) {
+                const Py_ssize_t len = PyObject_Length(rows[i]);
+                if (len < 0) { PyErr_Clear(); continue; }
+                total += (size_t)len;
+            }
+            tokens.reserve(total);
+        }
+        for (Py_ssize_t i = 0; i < n; ++i) {
+            PyObject* r = rows[i];
+            if (PyList_CheckExact(r) || PyTuple_CheckExact(r)) {
+                const Py_ssize_t len = PySequence_Fast_GET_SIZE(r);
+                PyObject** it = PySequence_Fast_ITEMS(r);
+                const size_t at = tokens.size();
+                tokens.resize(at + (size_t)len);
+                int32_t* dst = tokens.data() + at;
+                for (Py_ssize_t q = 0; q < len; ++q) {
+                    const long v = PyLong_AsLong(it[q]);
+                    if (v == -1 && PyErr_Occurred()) throw py::error_already_set();
+                    if (v < INT32_MIN || v > INT32_MAX) throw py::value_error("token ids must fit 32 bits");
+                    dst[q] = (int32_t)v;
+                }
+            } else {  // an array (or any other sequence) row
+                auto a = py::array_t<int32_t, py::array::c_style | py::array::forcecast>::ensure(py::handle(r));
+                if (!a || a.ndim() != 1) { PyErr_Clear(); throw py::value_error("every sequence must be a list, a tuple or a 1-D array of token ids"); }
+                tokens.insert(tokens.end(), a.data(), a.data() + a.shape(0));
+            }
             offsets.push_back((int64_t)tokens.size());
         }
+        return (size_t)n;
     }
 };
 
@@ -164,12 +206,23 @@ class FastSK {
         if (rows > 0) check(test ? fsk_get_test(h_, out.mutable_data()) : fsk_get_train(h_, out.mutable_data()));
         return out;
     }
-    static std::vector<std::vector<double>> to_lists(const py::array_t<double>& a) {
+    // the reference's return type, vector<vector<double>> -> a list of lists of floats, built from the block's one host copy
+    // (no vector of vectors in between; what is left is one PyFloat per cell: ~12 ns each, 8 * 10^6 of them at EP300)
+    static py::list to_lists(const py::array_t<double>& a) {
         const py::ssize_t r = a.shape(0), c = a.shape(1);
-        std::vector<std::vector<double>> v((size_t)r);
         const double* p = a.data();
-        for (py::ssize_t i = 0; i < r; ++i) v[(size_t)i].assign(p + i * c, p + (i + 1) * c);
-        return v;
+        py::list out(r);
+        for (py::ssize_t i = 0; i < r; ++i) {
+            PyObject* row = PyList_New(c);
+            if (!row) throw py::error_already_set();
+            for (py::ssize_t j = 0; j < c; ++j) {
+                PyObject* v = PyFloat_FromDouble(p[i * c + j]);
+                if (!v) { Py_DECREF(row); throw py::error_already_set(); }
+                PyList_SET_ITEM(row, j, v);
+            }
+            PyList_SET_ITEM(out.ptr(), i, row);  // (py::list(r) holds r null slots)
+        }
+        return out;
     }
 
 public:
@@ -208,29 +261,13 @@ public:
     FastSK(const FastSK&) = delete;
     FastSK& operator=(const FastSK&) = delete;
 
-    // FastSK::compute_kernel, fastsk.cpp:30-118 (arguments copied by value, as there)
-    void compute_kernel(std::vector<std::vector<int>> Xtrain, std::vector<std::vector<int>> Xtest) {
-        if (Xtrain.empty() || Xtest.empty()) throw py::value_error("Xtrain and Xtest must be non-empty (use compute_train for train only)");
+    // FastSK::compute_kernel, fastsk.cpp:30-118. Xtrain / Xtest: lists of lists of ints as the reference takes them — or
+    // tuples, int arrays per sequence, one 2-D integer array (fixed-length sequences) — see Flat::add
+    void compute_kernel(py::object Xtrain, py::object Xtest) {
         Flat f;
-        f.add(Xtrain);
-        f.add(Xtest);
-        run(f, (int64_t)Xtrain.size(), (int64_t)Xtest.size());
-    }
-    // Additive fast path: fixed-length sequences as 2-D int32 arrays (no per-element boxing; the
-    // list-of-lists form costs seconds at 100k x 300)
-    void compute_kernel_np(py::array_t<int32_t, py::array::c_style> Xtrain, py::array_t<int32_t, py::array::c_style> Xtest) {
-        if (Xtrain.ndim() != 2 || Xtest.ndim() != 2 || Xtrain.shape(0) == 0 || Xtest.shape(0) == 0)
-            throw py::value_error("expected non-empty 2-D int32 arrays");
-        Flat f;
-        add_array(f, Xtrain);
-        add_array(f, Xtest);
-        run(f, (int64_t)Xtrain.shape(0), (int64_t)Xtest.shape(0));
-    }
-    void compute_train_np(py::array_t<int32_t, py::array::c_style> Xtrain) {
-        if (Xtrain.ndim() != 2 || Xtrain.shape(0) == 0) throw py::value_error("expected a non-empty 2-D int32 array");
-        Flat f;
-        add_array(f, Xtrain);
-        run(f, (int64_t)Xtrain.shape(0), 0);
+        const size_t ntr = f.add(Xtrain), nte = f.add(Xtest);
+        if (ntr == 0 || nte == 0) throw py::value_error("Xtrain and Xtest must be non-empty (use compute_train for train only)");
+        run(f, (int64_t)ntr, (int64_t)nte);
     }
     // Additive: ragged sequences already flattened (tokens + offsets, train rows first), e.g.
     // from FastaUtility.read_packed
@@ -242,20 +279,15 @@ public:
         if (offsets.data()[0] != 0 || offsets.data()[n] != (int64_t)tokens.shape(0)) throw py::value_error("offsets must start at 0 and end at len(tokens)");
         run_flat(tokens.data(), offsets.data(), n_train, n - n_train);
     }
-    static void add_array(Flat& f, const py::array_t<int32_t, py::array::c_style>& X) {
-        const py::ssize_t n = X.shape(0), L = X.shape(1);
-        f.tokens.insert(f.tokens.end(), X.data(), X.data() + n * L);
-        for (py::ssize_t i = 0; i < n; ++i) f.offsets.push_back(f.offsets.back() + L);
-    }
     // FastSK::compute_train, fastsk.cpp:120-188
-    void compute_train(std::vector<std::vector<int>> Xtrain) {
-        if (Xtrain.empty()) throw py::value_error("Xtrain must be non-empty");
+    void compute_train(py::object Xtrain) {
         Flat f;
-        f.add(Xtrain);
-        run(f, (int64_t)Xtrain.size(), 0);
+        const size_t ntr = f.add(Xtrain);
+        if (ntr == 0) throw py::value_error("Xtrain must be non-empty");
+        run(f, (int64_t)ntr, 0);
     }
-    std::vector<std::vector<double>> get_train_kernel() const { return to_lists(block(false)); }  // fastsk.cpp:190-200
-    std::vector<std::vector<double>> get_test_kernel() const { return to_lists(block(true)); }    // fastsk.cpp:202-217
+    py::list get_train_kernel() const { return to_lists(block(false)); }  // fastsk.cpp:190-200
+    py::list get_test_kernel() const { return to_lists(block(true)); }    // fastsk.cpp:202-217
     py::array_t<double> get_train_kernel_np() const { return block(false); }
     py::array_t<double> get_test_kernel_np() const { return block(true); }
     std::vector<double> get_stdevs() const {  // fastsk.cpp:219-221
@@ -382,11 +414,9 @@ PYBIND11_MODULE(_fastsk, m) {
              py::arg("max_iters") = -1, py::arg("skip_variance") = false, py::arg("device") = 0,
              py::arg("path") = "auto", py::arg("seed") = py::none(), py::arg("skip_test_block") = false,
              py::arg("devices") = py::none(), py::arg("collective") = "auto", py::arg("deadline_ms") = 0)
-        .def("compute_kernel", &FastSK::compute_kernel_np, py::arg("Xtrain").noconvert(), py::arg("Xtest").noconvert())
         .def("compute_kernel", &FastSK::compute_kernel, py::arg("Xtrain"), py::arg("Xtest"))
         .def("compute_kernel_flat", &FastSK::compute_kernel_flat, py::arg("tokens").noconvert(), py::arg("offsets").noconvert(),
              py::arg("n_train"))
-        .def("compute_train", &FastSK::compute_train_np, py::arg("Xtrain").noconvert())
         .def("compute_train", &FastSK::compute_train, py::arg("Xtrain"))
         .def("get_train_kernel", &FastSK::get_train_kernel)
         .def("get_test_kernel", &FastSK::get_test_kernel)

@@ -102,3 +102,25 @@ def test_pybind_surface_signature():
     assert _fastsk.__version__ == "dev"
     import fastsk  # the drop-in package name
     assert fastsk.FastSK is _fastsk.FastSK and fastsk.FastaUtility is not None
+
+
+def test_headline_tile_kernel_resources():
+    """k_dense_tile_dma — 98.6 % of the headline's GPU time — keeps the register allocation it is priced with (126 VGPRs, no
+    scratch, 40 KB of LDS: four workgroups a CU) whatever else the library gains: the small-N variants of the same body live
+    in a translation unit of their own (fsk_engine_dense_small.hip). From the compiler's own resource report (cross-compiled)."""
+    import re
+    import subprocess
+    import __graft_entry__ as ge
+    src = os.path.join(ge.CSRC, "fsk_engine_dense.hip")
+    r = subprocess.run([ge.HIPCC] + ge.HIPCC_FLAGS + ["-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", r.stderr)
+    found = {}
+    for b in blocks[1:]:
+        name = b.split()[0]
+        get = lambda key: int(re.search(key + r": (\d+)", b).group(1))
+        found[name] = (get("VGPRs"), get(r"ScratchSize \[bytes/lane\]"), get(r"LDS Size \[bytes/block\]"))
+    head = [v for k, v in found.items() if "k_dense_tile_dma" in k and "compact" not in k]
+    assert head and head[0] == (126, 0, 40960), found
+    compact = [v for k, v in found.items() if "k_dense_tile_dma_compact" in k]
+    assert compact and compact[0][1] == 0 and compact[0][0] <= 128 and compact[0][2] == 40960, found

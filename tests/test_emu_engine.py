@@ -30,6 +30,20 @@ def run_case(emu_lib, d, path):
     return e
 
 
+def test_emu_dense_split_launch_through_staging_blocks(emu_lib):
+    """The dense dataflow's split tile launch with its sums in 32-bit staging blocks (k_dense_tile_small + k_dense_widen, tuning
+    dense_small=1, its own translation unit) instead of 64-bit atomics: goldens incl. counts above 15 (the hi plane) and a
+    rare symbol (the compact kernel), three splits a tile."""
+    from fastsk_amd import _native
+    for name in ("f3_lowcomplexity_g5m2", "f3_ragged_sigma7_g6m3", "f2_docsdemo_g3m2"):
+        d = load_golden(name)
+        for tun in ({"dense_small": 1, "tile_splits": 3}, {"dense_small": 1, "tile_splits": 2, "compact": 1}):
+            e = _native.Engine(d["g"], d["m"], path=1, lib=emu_lib, tuning=tun)
+            e.compute(d["tokens"], d["offsets"], d["n_train"], d["n_test"])
+            assert np.array_equal(e.get_counts(), d["counts"]), (name, tun)
+            e.close()
+
+
 def test_emu_wave_primitives_stand_ins(emu_lib):
     """The emulator's shuffle-loop stand-ins for the wave primitives meet the same definitions the GPU's inline asm is checked
     against (tests/test_gpu_parity.py::test_wave_primitives)."""

@@ -560,6 +560,24 @@ def _wave_primitives_check(lib):
     assert np.array_equal(out[5].reshape(-1, 64), np.cumsum(bit, axis=1, dtype=np.uint32) - bit)
 
 
+def test_dense_split_launch_through_staging_blocks(native):
+    """tuning dense_small=1: the small-N tile launch (several workgroups a tile) leaves 32-bit staging blocks that k_dense_widen
+    adds into K — BASELINE configs 2 and 3 at full size against the committed digests of their integer triangles."""
+    for name in ("f7_cfg2_ep300_exact", "f7_cfg3_ep47848_100combos"):
+        d = load_golden(name)
+        tokens, offsets, ntr, nte, _, _ = load_tokens(d["data"])
+        base = None
+        for tun in ({"dense_small": 0}, {"dense_small": 1}, {"dense_small": 1, "tile_splits": 5}):
+            e = native.Engine(d["g"], d["m"], t=d["t"], approx=bool(d["approx"]), max_iters=d["max_iters"], skip_variance=bool(d["skip_variance"]),
+                              path=1, tuning=tun)
+            if d["approx"]:
+                e.set_combo_order(d["order"])
+            e.compute(tokens, offsets, ntr, nte)
+            import hashlib
+            assert hashlib.sha256(e.get_counts().tobytes()).hexdigest() == d["counts_sha256"], (name, tun)
+            e.close()
+
+
 def test_wave_primitives(native):
     _wave_primitives_check(hooks_library(native))
 
