@@ -12,8 +12,8 @@ from oracle import loader
 
 tokens, offsets, ntr, nte, _, _ = load_tokens("EP300")
 N = ntr + nte
-for g, m in ((12, 6), (16, 10), (20, 14)):
-    e = _native.Engine(g, m, profile=True)
+for g, m in [tuple(int(x) for x in a.split(',')) for a in sys.argv[1:]] or ((12, 6), (16, 10), (20, 14)):
+    e = _native.Engine(g, m, profile=2)  # (2: the product dataflow, its kernels' times from events harvested by stats())
     nc = e.lib.num_combos(g, m)
     t0 = time.perf_counter()
     e.compute(tokens, offsets, ntr, nte)
@@ -31,7 +31,17 @@ for g, m in ((12, 6), (16, 10), (20, 14)):
     want, _, _ = loader.port().raw_counts(tokens[:offsets[600]], offsets[:601], g, m, sub, threads=os.cpu_count())
     ok = bool(np.array_equal(e2.get_counts(), want))
     tr = e.get_block(0, 4, 0, 4)
+    # algorithmic bytes of the direct-atomic dataflow = 16 U + 16 P nfeat + packed input, per combo (two calls were counted)
+    U = st["cell_updates"] / 2
+    P = (max(1, int(np.ceil(np.log2(max(2, st["key_space"]))))) + 7) // 8
+    alg = 16.0 * U + nc * (16.0 * P * st["n_feat"] + st["n_feat"] * st["bits_per_symbol"] / 8.0)
+    dg = e.counts_digest()
     print(json.dumps(dict(g=g, m=m, combos=nc, N=N, seconds=dt, first_call_seconds=dt_first, combos_per_s=nc / dt, path="dense" if st["path_used"] == 1 else "sparse",
-                          tile_ms=st["ms_tile"], count_ms=st["ms_count"], tile_launches=st["n_tile_launches"], subset_parity=ok,
+                          U=int(U), U_per_combo=int(U / nc), words_per_record=round(U / (nc * st["n_feat"]), 2), algorithmic_GB=round(alg / 1e9, 1),
+                          algorithmic_GBs=round(alg / 1e9 / dt, 1), frac_of_hbm_peak=round(alg / 1e9 / dt / 8000.0, 3),
+                          sparse_form={0: "bands", 1: "direct", 2: "blocks"}.get(int(st["sparse_form"]), "-"),
+                          share_positions_last_batch=int(st["share_positions"]), share_groups_last_batch=int(st["share_groups"]),
+                          ms={k: round(st[k] / 2, 1) for k in ("ms_extract", "ms_sort", "ms_segment", "ms_pairs", "ms_total")},
+                          digest=format(dg[0], "x") + "." + format(dg[1], "x"), subset_parity=ok,
                           diag_ok=bool(np.all(np.diag(tr) == 1.0)))), flush=True)
     e.close(); e2.close()

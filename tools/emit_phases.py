@@ -12,12 +12,16 @@ lib = _native.Library(sys.argv[1])
 raw = ctypes.CDLL(sys.argv[1])
 names = ["load + classify", "fill slots + addresses", "word loop (short)", "list long", "long headers + half waves", "long entries", "zero + bin + scan", "", "", "", "", "", "", "", "", "workgroups"]
 for name in os.environ.get("AB_CASES", "f7_cfg1_prot11_approx_t1,f7_cfg4_prot219_exact").split(","):
-    d = load_golden(name)
-    tokens, offsets, ntr, nte, _, _ = load_tokens(d["data"])
-    e = _native.Engine(d["g"], d["m"], t=d["t"], approx=bool(d["approx"]), delta=d["delta"], max_iters=d["max_iters"],
-                       skip_variance=bool(d["skip_variance"]), lib=lib)
-    if d["approx"]:
-        e.set_combo_order(d["order"])
+    if name == "large_g":  # the paper's large-g regime: EP300, k = 6, g = 20
+        tokens, offsets, ntr, nte, _, _ = load_tokens("EP300")
+        e = _native.Engine(20, 14, lib=lib)
+    else:
+        d = load_golden(name)
+        tokens, offsets, ntr, nte, _, _ = load_tokens(d["data"])
+        e = _native.Engine(d["g"], d["m"], t=d["t"], approx=bool(d["approx"]), delta=d["delta"], max_iters=d["max_iters"],
+                           skip_variance=bool(d["skip_variance"]), lib=lib)
+        if d["approx"]:
+            e.set_combo_order(d["order"])
     e.compute(tokens, offsets, ntr, nte)
     out = (ctypes.c_ulonglong * 16)()
     raw.fsk_debug_emit_clocks(out)
