@@ -81,7 +81,8 @@ def kernel_hashes(files=KERNEL_FILES):
 
 
 # the sources of the sparse pipeline (kernels + the host code that batches and sizes them)
-SPARSE_FILES = ("fastsk_amd/csrc/fsk_sparse_kernels.inc", "fastsk_amd/csrc/fsk_common.h", "fastsk_amd/csrc/fsk_engine_sparse.hip")
+SPARSE_FILES = ("fastsk_amd/csrc/fsk_sparse_kernels.inc", "fastsk_amd/csrc/fsk_sparse_blocks.inc", "fastsk_amd/csrc/fsk_common.h",
+                "fastsk_amd/csrc/fsk_engine_sparse.hip")
 
 
 def host_cpus():
@@ -1132,6 +1133,10 @@ def main():
                                 "note": "every stage of a multi-GPU run is bounded; an overrun prints one JSON error line on rank 0 and exits 2"}
         if end_to_end is not None:
             out["end_to_end"] = end_to_end
+            # SURVEY 8(d)'s boundary (host buffers in: pack + H2D once + every combo + finalize + the whole triangle) beside the
+            # contract's (`value`: inputs resident in HBM when the clock starts — host buffers and PCIe are never part of it)
+            out["end_to_end_combos_per_s"] = end_to_end["combos_per_s"]
+            out["resident_combos_per_s"] = out["value"]
     stage("closing barrier", step_bound)
     if use_dist:
         dist.barrier()

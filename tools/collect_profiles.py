@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r06"
 
 
 def newest(pattern):
@@ -97,6 +97,14 @@ def main():
                    "source": "profiles/%s_pmc_sparse_config4.json: sum over the pipeline's kernels of FETCH_SIZE KiB x1024 x2 (gfx950 "
                              "correction) + WRITE_SIZE KiB x1024, one fsk_compute of all 1001 combos" % TAG},
                   open(os.path.join(DST, "traffic_config4.json"), "w"), indent=1)
+    for src, dst in (("sparse_large_n.jsonl", TAG + "_sparse_large_n.jsonl"), ("sparse_mid_n.jsonl", TAG + "_sparse_mid_n_bands_vs_blocks.jsonl"),
+                     ("dropin_wall.json", TAG + "_dropin_wall.json"), ("ubench_sparse_ops.txt", TAG + "_ubench_sparse_ops.txt"),
+                     ("ubench_rmw.txt", TAG + "_ubench_rmw_shapes.txt")):
+        if os.path.exists(os.path.join(SRC, src)) and os.path.getsize(os.path.join(SRC, src)) > 0:
+            shutil.copy(os.path.join(SRC, src), os.path.join(DST, dst))
+    b64 = os.path.join(ROOT, "gpurun_out", "pmc", TAG + "_blocks64k", "summary.json")
+    if os.path.exists(b64):
+        shutil.copy(b64, os.path.join(DST, TAG + "_pmc_sparse_blocks_64k.json"))
     for src, dst in (("config1_timeline.txt", TAG + "_config1_timeline.txt"), ("kprof_cfg4/kstats.txt", TAG + "_kernel_times_config4.txt"),
                      ("kprof_cfg1/kstats.txt", TAG + "_kernel_times_config1.txt"), ("ep300_approx.txt", TAG + "_ep300_approx_ms.txt")):
         if os.path.exists(os.path.join(SRC, src)):

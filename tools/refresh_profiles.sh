@@ -5,7 +5,7 @@
 # and the micro-benchmarks. Raw output lands in gpurun_out/prof/ and gpurun_out/pmc/;
 # tools/collect_profiles.py turns it into the files under profiles/.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
 rm -rf "$O"; mkdir -p "$O"
@@ -38,4 +38,11 @@ tools/trace_cfg1.sh > "$O/config1_timeline.txt" 2>&1
 tools/kprof.sh f7_cfg4_prot219_exact prof/kprof_cfg4 > /dev/null 2>&1
 tools/kprof.sh f7_cfg1_prot11_approx_t1 prof/kprof_cfg1 > /dev/null 2>&1
 python3 tools/time_ep300_approx.py > "$O/ep300_approx.txt" 2>&1
+# round 6: the sparse dataflow beyond the owner bands (the two-level blocks), its counters at N = 64k, the drop-in wall clock
+python3 tools/bench_sparse_large_n.py --combos 20 > "$O/sparse_large_n.jsonl" 2> "$O/sparse_large_n.err"
+python3 tools/bench_sparse_large_n.py --only protein_like_8k,protein_like_12k,protein_like_16k --combos 40 > "$O/sparse_mid_n.jsonl" 2>> "$O/sparse_large_n.err"
+tools/pmc_passes.sh ${TAG}_blocks64k "$R/tools/bench_sparse_large_n.py" --only protein_like_64k --combos 20 > "$O/pmc_blocks64k.log" 2>&1
+python3 tools/time_dropin.py > "$O/dropin_wall.json" 2> "$O/dropin_wall.err"
+[ -x tools/ubench_sparse_ops ] && tools/ubench_sparse_ops > "$O/ubench_sparse_ops.txt" 2>&1
+[ -x tools/ubench_rmw ] && tools/ubench_rmw > "$O/ubench_rmw.txt" 2>&1
 ls -R "$O" | head -60
