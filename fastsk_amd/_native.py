@@ -46,7 +46,8 @@ class Stats(C.Structure):
                 ("n_tile_launches", C.c_int64), ("dense_macs", C.c_uint64), ("panel_bytes", C.c_uint64),
                 ("u4_tile_launches", C.c_double), ("max_windows", C.c_double), ("count_launches", C.c_double),
                 ("compact_keys_avg", C.c_double), ("batches_redone", C.c_double), ("combos_issued", C.c_double),
-                ("sparse_form", C.c_double), ("sparse_passes", C.c_double), ("share_positions", C.c_double), ("share_groups", C.c_double)]
+                ("sparse_form", C.c_double), ("sparse_passes", C.c_double), ("share_positions", C.c_double), ("share_groups", C.c_double),
+                ("sparse_desc", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -753,7 +753,7 @@ int fsk_detail::one_load_sequences(fsk_engine* e, const int32_t* tokens, const i
         // result. Tuning sparse_hint = 0: every set of sequences starts from nothing (testing).
         const bool same = e->tune.sparse_hint && e->loaded && e->sx_shape[0] == (u64)N && e->sx_shape[1] == (u64)nfeat && e->sx_shape[2] == (u64)sigma &&
                           e->sx_shape[3] == (u64)longest;
-        if (!same) { e->sx_wpr = 0; e->slots16_ok = true; }
+        if (!same) { e->sx_wpr = 0; e->sx_ppr = 0; e->slots16_ok = true; }
         e->sx_shape[0] = (u64)N; e->sx_shape[1] = (u64)nfeat; e->sx_shape[2] = (u64)sigma; e->sx_shape[3] = (u64)longest;
     }
     for (auto& d : e->sx_defer) d.active = false;
@@ -1327,6 +1327,7 @@ int fsk_detail::one_get_stats(fsk_engine* e, fsk_stats* out) {
     e->st.batches_redone = (double)e->sx_redone;
     e->st.sparse_form = (double)e->sx_form_used;
     e->st.sparse_passes = (double)e->sx_passes;
+    e->st.sparse_desc = e->sx_desc_used ? 1.0 : 0.0;
     e->st.share_positions = (double)e->sx_share_used;
     e->st.share_groups = (double)e->sx_share_groups;
     *out = e->st;

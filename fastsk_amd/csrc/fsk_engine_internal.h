@@ -113,6 +113,9 @@ using fsk_detail::DevBuf;
     X(blocks_band_shift_max, 23, 4, 23, "sparse, blocks: log2 of a band's cells at most (tests)")                                    \
     X(blocks_scatter_threads, 0, 0, 1024, "sparse, blocks: threads of a k_sxb_scatter workgroup, 256 / 512 / 1024 (0: 256)")          \
     X(blocks_pass_words, 0, 0, (int64_t)1 << 32, "sparse, blocks: update words of one pass at most (0: 2^31)")                       \
+    X(sparse_desc, 0, -1, 1, "sparse, owner bands: entries of many partners leave k_sx_emit as ONE descriptor each that k_sx_consume expands in LDS — 1 = always, -1 = never (0: once a batch of these sequences has shown sparse_desc_from pairs per record)") \
+    X(sparse_desc_min, 0, 0, 48, "sparse, descriptors: entries of more partners than this become descriptors (0: 48, what k_sx_emit bins in LDS)") \
+    X(sparse_desc_from, 8, 1, 1 << 20, "sparse, descriptors: the pairs per sort record of a batch from which on the following batches use them (sparse_desc = 0)") \
     X(sparse_share, 0, -1, 254, "sparse: leading kept positions sorted once per group of consecutive combos that share them (0: by cost; -1: never); batches of more than 16 slots only (smaller ones read their positions by id), and never when the presort's scratch passes a quarter of the free memory") \
     X(seed_splitmix, 0, 0, 1, "approx modes: 1 = fsk_set_seed draws the engine's older splitmix64 Fisher-Yates order (0: the reference's std::shuffle of minstd_rand0)") \
     X(collective, 0, 0, 2, "fsk_create_multi: FSK_COLL_* when fsk_config.collective is FSK_COLL_AUTO")                                \
@@ -283,9 +286,21 @@ struct fsk_engine {
     uint32_t* sx_ovf_now = nullptr;      // the flag of the batch being enqueued
     int sx_last_lane = 0;                // the lane (scratch + stream) the last accumulate_sparse ran in
     u64 sx_shape[4] = {0, 0, 0, 0};      // sequences, windows, alphabet, longest sequence of the set at hand
+    double sx_ppr = 0;                   // most pairs (the reference's +=) per sort record of a batch since the sequences were loaded
+    bool sx_desc_used = false;           // the last batch of the owner-band form sent descriptors (fsk_stats.sparse_desc)
     double sx_wpr = 0;                   // most update words per sort record of a batch since the sequences were loaded (0: none seen)
     u64 sx_words_of(u64 nrec) const { return (u64)(sx_wpr * (double)nrec) + 1; }  // what a batch of nrec records is expected to emit
     void sx_saw(u64 words, u64 nrec) { if (nrec) sx_wpr = std::max(sx_wpr, std::max(1e-9, (double)words / (double)nrec)); }
+    // descriptors (tuning sparse_desc): forced, or once the sequences have shown long runs. The batch that tips the
+    // decision forgets the words per record seen so far — with descriptors a batch emits a fraction of them — so the
+    // next batch is sized exactly again.
+    bool sx_desc_now() const { return tune.sparse_desc > 0 || (tune.sparse_desc == 0 && sx_ppr >= (double)tune.sparse_desc_from); }
+    void sx_saw_pairs(u64 pairs, u64 nrec) {
+        if (!nrec) return;
+        const bool was = sx_desc_now();
+        sx_ppr = std::max(sx_ppr, (double)pairs / (double)nrec);
+        if (!was && sx_desc_now()) sx_wpr = 0;
+    }
     struct SxDefer { bool active = false; u64 cap = 0, nrec = 0; } sx_defer[8];
     u64 sx_redone = 0;                   // batches redone because they did not fit
     bool sx_redoing = false;             // set around such a redo: the batch waits for its word count and is sized exactly

@@ -119,6 +119,9 @@ void sx_choose_form(fsk_engine* e) {
                                                                         : 1;
 }
 
+// descriptors for this batch? (owner bands only; see fsk_engine::sx_desc_now)
+inline bool sx_desc_wanted(const fsk_engine* e) { return e->sx_desc_now(); }
+
 // The LSD passes over `bits` bits from bit `shift0` of the records of n_slots slots (the digits of the first pass have been
 // counted by whoever wrote the records). *cur: which of rec[0] / rec[1] holds the result.
 template <typename T>
@@ -240,6 +243,12 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     const int pairs = lists && e->sx_pairs ? 1 : 0;  // (unit products as bare cells, two to a word: plan_owner_bands)
     const bool slot16 = slot_stride != 0 && e->sx_slot16_used;  // (u16 slot triangles: set by accumulate_sparse for a deferred batch)
     const uint32_t O = blocks ? (uint32_t)e->tune.blocks_max_bands : e->n_owners;  // (blocks: the most bands a pass can have)
+    // descriptors (owner bands only): entries of more than short_max partners leave k_sx_emit as one descriptor each and
+    // k_sx_consume walks their partners; the count matrix and the stream offsets then have two columns a band
+    const uint32_t desc = lists && sx_desc_wanted(e) ? 1u : 0u;
+    const uint32_t short_max = desc && e->tune.sparse_desc_min > 0 ? (uint32_t)std::min<int64_t>(e->tune.sparse_desc_min, (int64_t)fsk::SX_SHORT) : fsk::SX_SHORT;
+    const uint32_t OC = desc ? 2u * O : O;  // columns
+    e->sx_desc_used = desc != 0;
     // (the presort's records, 4 or 8 bytes a window and group, go through the same two buffers first)
     const size_t pre_bytes = sh.share ? (size_t)sh.groups * nfeat * (sh.pre64 ? 8 : 4) : 0;
     for (int b = 0; b < 2; ++b) FSK_HIP(S.d_keys[b].reserve(std::max(pre_bytes, nrec * sizeof(RecT))));
@@ -273,11 +282,11 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     const uint32_t uc = ntiles >= 16384u ? (uint32_t)fsk::UC_CHUNK : ntiles >= 4096u ? 16u : 8u;
     const uint32_t nchunks = (ntiles + uc - 1) / uc;
     if (lists || blocks) {
-        FSK_HIP(S.d_ucount.reserve((size_t)O * ntiles));
-        FSK_HIP(S.d_uchunk.reserve((size_t)O * nchunks));
-        FSK_HIP(S.d_utot.reserve(O));
-        FSK_HIP(S.d_list_off.reserve((size_t)O + 1));
-        FSK_HIP(S.d_part_base.reserve((size_t)O + 1));
+        FSK_HIP(S.d_ucount.reserve((size_t)OC * ntiles));
+        FSK_HIP(S.d_uchunk.reserve((size_t)OC * nchunks));
+        FSK_HIP(S.d_utot.reserve(OC));
+        FSK_HIP(S.d_list_off.reserve((size_t)OC + 1));
+        FSK_HIP(S.d_part_base.reserve((size_t)O + 2));
     }
     fsk::SxIds ids{};
     const bool by_id = nb <= 16;  // (variance mode: a handful of combos per batch) positions from the resident table
@@ -483,13 +492,13 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                            (const int*)S.d_tile_rs.p, reinterpret_cast<uint32_t*>(S.d_E.p), reinterpret_cast<uint16_t*>(S.d_Pk.p), P.t, Op,
                            S.d_ucount.p, (uint32_t)ra, (uint32_t)rb, e->maxW, maxprod_p, cmax_p, S.d_tile_stat.p, skip_from,
                            skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr,
-                           skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr, P.own_base);
+                           skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr, P.own_base, fsk::SX_SHORT, 0u);
             } else {
                 auto k_seg = skipping ? fsk::k_sx_seg_write<RecT, false, false, true> : fsk::k_sx_seg_write<RecT, false, false, false>;
                 FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)S.d_ebase.p,
                            (const int*)S.d_tile_rs.p, S.d_E.p, S.d_Pk.p, P.t, Op, S.d_ucount.p, (uint32_t)ra, (uint32_t)rb, e->maxW, maxprod_p,
                            cmax_p, S.d_tile_stat.p, skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr,
-                           skipping ? S.d_Tk.p : (uint32_t*)nullptr, P.own_base);
+                           skipping ? S.d_Tk.p : (uint32_t*)nullptr, P.own_base, fsk::SX_SHORT, 0u);
             }
             FSK_LAUNCH(fsk::k_sx_ucol_sum, dim3(nchunks), dim3(256), 0, stream, (const uint32_t*)S.d_ucount.p, ntiles, Op, S.d_uchunk.p,
                        (const u64*)S.d_tile_stat.p, S.d_sxstat.p, pin, uc);
@@ -528,19 +537,19 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                            (const uint32_t*)S.d_list_off.p, (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)ra, (uint32_t)rb, e->maxW,
                            maxprod_p, cmax_p, P.pb, K, tpg, (u64)0,
                            skipping ? reinterpret_cast<const uint16_t*>(S.d_Tk.p) : (const uint16_t*)nullptr, (const u64*)S.d_sxstat.p, ~(u64)0,
-                           ntiles, 0, P.own_base);
+                           ntiles, 0, P.own_base, fsk::SX_SHORT, 0u);
             } else {
                 auto k_emit = skipping ? fsk::k_sx_emit<false, true, false> : fsk::k_sx_emit<false, false, false>;
                 FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, (const uint2*)S.d_E.p, (const uint32_t*)S.d_Pk.p,
                            (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_blk_r0.p, P.t, Op, (const uint32_t*)S.d_list_off.p,
                            (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)ra, (uint32_t)rb, e->maxW, maxprod_p, cmax_p, P.pb, K, tpg, (u64)0,
-                           skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)S.d_sxstat.p, ~(u64)0, ntiles, 0, P.own_base);
+                           skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)S.d_sxstat.p, ~(u64)0, ntiles, 0, P.own_base, fsk::SX_SHORT, 0u);
             }
             // (persistent launches: two workgroups of 1024 threads a CU walk the tiles of the bands' streams in contiguous chunks)
             const uint32_t n_tiles_max = Op + (uint32_t)((words + fsk::SXB_TILE - 1) / fsk::SXB_TILE);
             const uint32_t n_split = std::min<uint32_t>(n_tiles_max, 2u * (uint32_t)std::max(1, e->n_cu));
             FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, stream, (const uint32_t*)S.d_list_off.p, Op, (uint32_t)fsk::SXB_TILE, S.d_part_base.p,
-                       (const u64*)S.d_sxstat.p, ~(u64)0);
+                       (const u64*)S.d_sxstat.p, ~(u64)0, 0u);
             FSK_LAUNCH(fsk::k_sxb_count, dim3(n_split), dim3(fsk::SXB_THREADS), 0, stream, (const uint32_t*)S.d_ulist.p, (const uint32_t*)S.d_list_off.p,
                        (const uint32_t*)S.d_part_base.p, Op, P.pb, P.sub_shift, P.submax, S.d_subcnt.p);
             FSK_LAUNCH(fsk::k_sxb_scan, dim3(Op), dim3(fsk::SXB_THREADS), 0, stream, (const uint32_t*)S.d_subcnt.p, (const uint32_t*)S.d_list_off.p, P.submax,
@@ -582,23 +591,23 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                    (const int*)S.d_tile_rs.p, reinterpret_cast<uint32_t*>(S.d_E.p), reinterpret_cast<uint16_t*>(S.d_Pk.p), e->sx_own_shift, O,
                    lists ? S.d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, S.d_tile_stat.p,
                    skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr,
-                   skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr, 0u);
+                   skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr, 0u, short_max, desc);
     } else {
         auto k_seg = skipping ? (pairs ? fsk::k_sx_seg_write<RecT, false, true, true> : fsk::k_sx_seg_write<RecT, false, false, true>)
                               : (pairs ? fsk::k_sx_seg_write<RecT, false, true, false> : fsk::k_sx_seg_write<RecT, false, false, false>);
         FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)S.d_ebase.p,
                    (const int*)S.d_tile_rs.p, S.d_E.p, S.d_Pk.p, e->sx_own_shift, O,
                    lists ? S.d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, S.d_tile_stat.p,
-                   skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr, skipping ? S.d_Tk.p : (uint32_t*)nullptr, 0u);
+                   skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr, skipping ? S.d_Tk.p : (uint32_t*)nullptr, 0u, short_max, desc);
     }
     stat_pin[0] = stat_pin[1] = 0;
     e->st.launches += 3;
     u64 words = 0;
     if (lists) {  // where every (tile, owner) share of the update streams starts (+ the batch's pair and word totals)
-        FSK_LAUNCH(fsk::k_sx_ucol_sum, dim3(nchunks), dim3(256), 0, stream, (const uint32_t*)S.d_ucount.p, ntiles, O, S.d_uchunk.p,
+        FSK_LAUNCH(fsk::k_sx_ucol_sum, dim3(nchunks), dim3(256), 0, stream, (const uint32_t*)S.d_ucount.p, ntiles, OC, S.d_uchunk.p,
                    (const u64*)S.d_tile_stat.p, S.d_sxstat.p, stat_pin, uc);
-        FSK_LAUNCH(fsk::k_sx_ucol_scan, dim3(O), dim3(256), 0, stream, S.d_uchunk.p, nchunks, O, S.d_utot.p);
-        FSK_LAUNCH(fsk::k_sx_ucol_apply, dim3(nchunks), dim3(256), 0, stream, S.d_ucount.p, ntiles, O, (const uint32_t*)S.d_uchunk.p,
+        FSK_LAUNCH(fsk::k_sx_ucol_scan, dim3(OC), dim3(256), 0, stream, S.d_uchunk.p, nchunks, OC, S.d_utot.p);
+        FSK_LAUNCH(fsk::k_sx_ucol_apply, dim3(nchunks), dim3(256), 0, stream, S.d_ucount.p, ntiles, OC, (const uint32_t*)S.d_uchunk.p,
                    (const uint32_t*)S.d_utot.p, S.d_list_off.p, uc);
         e->st.launches += 3;
     } else {
@@ -615,6 +624,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         e->u_extra += stat_pin[0];
         words = stat_pin[1];
         e->sx_saw(words, nrec);
+        e->sx_saw_pairs(stat_pin[0], nrec);
     }
     e->toc(&e->st.ms_segment, stream);
 
@@ -632,13 +642,13 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                            reinterpret_cast<const uint16_t*>(S.d_Pk.p), (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p,
                            e->sx_own_shift, O, (const uint32_t*)S.d_list_off.p, (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)row0,
                            (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg, slot_stride,
-                           skipping ? reinterpret_cast<const uint16_t*>(S.d_Tk.p) : (const uint16_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles, pairs, 0u);
+                           skipping ? reinterpret_cast<const uint16_t*>(S.d_Tk.p) : (const uint16_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles, pairs, 0u, short_max, desc);
             } else {
                 auto k_emit = skipping ? fsk::k_sx_emit<false, true, false> : fsk::k_sx_emit<false, false, false>;
                 FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, (const uint2*)S.d_E.p, (const uint32_t*)S.d_Pk.p,
                            (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)S.d_list_off.p,
                            (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
-                           slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles, pairs, 0u);
+                           slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles, pairs, 0u, short_max, desc);
             }
             const size_t lds = (size_t)e->sx_cap * sizeof(uint32_t), lds_slot = (size_t)e->sx_cap_slot * sizeof(uint32_t);
             FSK_HIP(fsk_hw::allow_dynamic_lds(fsk::k_sx_consume<false>, lds));
@@ -646,7 +656,9 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             // parts of about `target` words: ~1024 workgroups, and never so short that the flush of a
             // part (up to sx_cap cells) outweighs the words it summed
             const uint32_t target = (uint32_t)std::max<u64>((u64)4 * e->sx_cap, (words + 1023) / 1024);
-            const uint32_t max_parts = O + (uint32_t)(((guarded ? guard_cap : words) + target - 1) / target);
+            // (with descriptors k_sx_parts sets the target itself: about SX_DESC_PARTS parts, at most one more a band)
+            const uint32_t max_parts = desc ? O + fsk::SX_DESC_PARTS + 1u : O + (uint32_t)(((guarded ? guard_cap : words) + target - 1) / target);
+            const void* const Ep = (const void*)S.d_E.p;
             if (k_wait) FSK_HIP(hipStreamWaitEvent(stream, k_wait, 0));
             if (slot_stride != 0) {  // one triangle per slot: a slot's words of a stream are one contiguous piece
                 if (slot16) {
@@ -655,19 +667,20 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                     FSK_LAUNCH(k_cs16, dim3(O, e->sx_rounds_slot, nb), dim3(fsk::CS_THREADS), lds_slot, stream, (const uint32_t*)S.d_ulist.p,
                                (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)nullptr, O, target,
                                e->sx_cap_slot, e->sx_pb, K, (const uint32_t*)S.d_ucount.p, tpg, slot_stride, (const u64*)S.d_sxstat.p, cap_words,
-                               e->sx_ovf_now, pairs);
+                               e->sx_ovf_now, pairs, desc, Ep, packed ? 1 : 0);
                 } else {
                     FSK_LAUNCH(fsk::k_sx_consume<true>, dim3(O, e->sx_rounds_slot, nb), dim3(fsk::CS_THREADS), lds_slot, stream, (const uint32_t*)S.d_ulist.p,
                                (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)nullptr, O, target,
                                e->sx_cap_slot, e->sx_pb, K, (const uint32_t*)S.d_ucount.p, tpg, slot_stride, (const u64*)S.d_sxstat.p, cap_words,
-                               (uint32_t*)nullptr, pairs);
+                               (uint32_t*)nullptr, pairs, desc, Ep, packed ? 1 : 0);
                 }
             } else {
                 FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, stream, (const uint32_t*)S.d_list_off.p, O, target, S.d_part_base.p,
-                           (const u64*)S.d_sxstat.p, cap_words);
+                           (const u64*)S.d_sxstat.p, cap_words, desc);
                 FSK_LAUNCH(fsk::k_sx_consume<false>, dim3(max_parts, e->sx_rounds), dim3(fsk::CS_THREADS), lds, stream, (const uint32_t*)S.d_ulist.p,
                            (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)S.d_part_base.p, O, target,
-                           e->sx_cap, e->sx_pb, K, (const uint32_t*)nullptr, tpg, (u64)0, (const u64*)S.d_sxstat.p, cap_words, (uint32_t*)nullptr, pairs);
+                           e->sx_cap, e->sx_pb, K, (const uint32_t*)nullptr, tpg, (u64)0, (const u64*)S.d_sxstat.p, cap_words, (uint32_t*)nullptr, pairs,
+                           desc, Ep, packed ? 1 : 0);
                 e->st.launches += 1;
             }
             e->st.launches += 2;
@@ -680,13 +693,13 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                        reinterpret_cast<const uint16_t*>(S.d_Pk.p), (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift,
                        O, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod,
                        cmax, e->sx_pb, K, tpg, slot_stride, skipping ? reinterpret_cast<const uint16_t*>(S.d_Tk.p) : (const uint16_t*)nullptr,
-                       (const u64*)nullptr, ~(u64)0, ntiles, 0, 0u);
+                       (const u64*)nullptr, ~(u64)0, ntiles, 0, 0u, fsk::SX_SHORT, 0u);
         } else {
             auto k_emit = skipping ? fsk::k_sx_emit<true, true, false> : fsk::k_sx_emit<true, false, false>;
             FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, (const uint2*)S.d_E.p, (const uint32_t*)S.d_Pk.p,
                        (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)nullptr,
                        (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
-                       slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)nullptr, ~(u64)0, ntiles, 0, 0u);
+                       slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)nullptr, ~(u64)0, ntiles, 0, 0u, fsk::SX_SHORT, 0u);
         }
         e->st.launches += 1;
     }
@@ -792,6 +805,7 @@ bool sx_harvest(fsk_engine* e, int slot) {
     e->sx_defer[slot].active = false;
     const u64 pairs = e->h_sx_head_stat[2 * slot], words = e->h_sx_head_stat[2 * slot + 1];
     e->sx_saw(words, e->sx_defer[slot].nrec);
+    e->sx_saw_pairs(pairs, e->sx_defer[slot].nrec);
     if (words > e->sx_defer[slot].cap) { e->sx_redone += 1; return false; }
     e->u_extra += pairs;
     return true;
@@ -923,6 +937,7 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
         if (!b.cap) continue;
         const u64 pairs = e->h_sx_stat[2 * i], words = e->h_sx_stat[2 * i + 1];
         e->sx_saw(words, (u64)b.nb * nfeat);
+        e->sx_saw_pairs(pairs, (u64)b.nb * nfeat);
         if (words <= b.cap) { e->u_extra += pairs; continue; }
         // the batch did not fit and has left K alone: once more, sized exactly
         e->sx_redone += 1;

@@ -141,6 +141,8 @@ typedef struct fsk_stats {
     double sparse_passes;    /* sparse, blocks: passes over disjoint row ranges run since the sequences were loaded */
     double share_positions;  /* sparse: leading kept positions the last batch sorted once per group of slots (0: none) */
     double share_groups;     /* ... and the groups it had                                                          */
+    double sparse_desc;      /* sparse, owner bands: 1 when the last batch sent its long entries as descriptors that
+                                k_sx_consume expands (tuning sparse_desc), else 0                                   */
 } fsk_stats;
 
 /* ---- lifecycle: replaces FastSK::FastSK (fastsk.cpp:19-28) and ~nothing (the reference leaks) */

@@ -1093,3 +1093,62 @@ def test_emu_sparse_two_level_blocks(emu_lib, port, skip):
         assert np.array_equal(e.get_counts()[keep], raw[keep]), (g, m, tun, how)
         assert skip or st["cell_updates"] == U
         e.close()
+
+
+@pytest.mark.parametrize("skip", [False, True])
+@pytest.mark.parametrize("desc_min", [0, 6])
+def test_emu_sparse_descriptors(emu_lib, port, monkeypatch, skip, desc_min):
+    """Descriptors (tuning sparse_desc=1): an entry of more partners than k_sx_emit bins in LDS leaves as ONE descriptor
+    {first partner's entry, partners, row, multiplicity} in its band's descriptor stream and k_sx_consume walks the partners
+    itself. Runs of hundreds of entries (400 sequences over 16 keys), own cells of multiplicities above 1, runs that begin
+    before the tile; every entry above six partners as a descriptor (sparse_desc_min); with the paired unit words on and
+    off; in one call, in three, in row bands; with skip_test_block (partners = the run's train entries)."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(78)
+    N, ntr, g, m = 400, 250, 5, 3
+    X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(14, 30, size=N)]
+    X[11][:] = 2  # a low-complexity sequence: multiplicities above 1
+    tokens, offsets = _native.flatten(X)
+    combos = np.array([0, 4, 9], dtype=np.int32)
+    raw, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=4)
+    a, b = np.tril_indices(N)
+    keep = (b < ntr) | (a == b) if skip else np.ones(len(a), dtype=bool)
+    for pairs in ("1", "0"):
+        set_tuning_env(monkeypatch, sparse_desc=1, sparse_desc_min=desc_min, sparse_pairs=pairs, sparse_form=1)
+        for how in ("whole", "three calls", "row bands"):
+            e = _native.Engine(g, m, path=2, lib=emu_lib, skip_test_block=skip)
+            e.load_sequences(tokens, offsets, ntr if skip else N, N - ntr if skip else 0)
+            if how == "whole":
+                e.accumulate(combos)
+            elif how == "three calls":
+                for part in np.array_split(combos, 3):
+                    e.accumulate(part)
+            else:
+                for lo, hi in ((0, 128), (128, 256), (256, N)):
+                    e.accumulate_rows(combos, lo, hi)
+            e.finalize()
+            got = e.get_counts()
+            st = e.stats()
+            assert st["sparse_desc"] == 1 and st["sparse_form"] == 0
+            assert np.array_equal(got[keep], raw[keep]), (pairs, how)
+            assert skip or st["cell_updates"] == U
+            e.close()
+
+
+@pytest.mark.parametrize("name", ["f6_prot219_skipvar16", "f3_lowcomplexity_g5m2", "f5_prot11_variance_T1_it9", "f4_ep300_variance_T1"])
+@pytest.mark.parametrize("unpacked", ["0", "1"])
+def test_emu_sparse_descriptors_forced_on_the_goldens(emu_lib, monkeypatch, name, unpacked):
+    """tuning sparse_desc=1 with every entry above two partners as a descriptor, on the golden vectors: exact, skip-variance and
+    variance mode (the by-slot form of k_sx_consume: a slot's descriptors are a contiguous piece of every band's descriptor
+    stream), both entry formats."""
+    set_tuning_env(monkeypatch, sparse_desc="1", sparse_desc_min="2", sparse_unpacked=unpacked)
+    d = load_golden(name)
+    e = run_case(emu_lib, d, 2)
+    st = e.stats()
+    assert st["path_used"] == 2 and st["sparse_desc"] == 1
+    assert np.array_equal(e.get_triangle(), d["tri"])
+    if "counts" in d:
+        assert np.array_equal(e.get_counts(), d["counts"])
+    if d["approx"] and not d["skip_variance"]:
+        assert np.array_equal(e.get_stdevs(), d["stdevs"])
+    e.close()

@@ -788,6 +788,73 @@ def test_sparse_paired_unit_words(native, port, monkeypatch, skip):
                 e.close()
 
 
+@pytest.mark.parametrize("skip", [False, True])
+def test_sparse_descriptors(native, port, monkeypatch, skip):
+    """Descriptors (tuning sparse_desc=1): entries of more partners than k_sx_emit bins leave as ONE descriptor each, which
+    k_sx_consume expands in LDS (countAndUpdateTri's += for a whole entry, shared.cpp:316-327). Long runs over 256 keys at
+    N = 4000 (bands of two LDS rounds: every descriptor is walked twice, each round keeping its own cells) and protein-like
+    data at N = 1500, thresholds 48 / 6 partners, a low-complexity sequence (own cells of multiplicities above 1), in one
+    call, in three, in row bands, with skip_test_block: the oracle's counts and U."""
+    for X, g, m, combos, desc_mins in (
+            ([np.random.default_rng(40 + i).integers(1, 5, size=26).astype(np.int32) for i in range(4000)], 6, 2, np.arange(0, 15, 5, dtype=np.int32), ("0", "6")),
+            (protein_like(1500, 40, 160, seed=33), 10, 6, np.arange(0, 210, 9, dtype=np.int32), ("6",))):
+        N, ntr = len(X), (2 * len(X)) // 3
+        X[7][:] = 3
+        tokens, offsets = native.flatten(X)
+        raw, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=min(32, os.cpu_count() or 8))
+        a, b = np.tril_indices(N)
+        keep = (b < ntr) | (a == b) if skip else np.ones(len(a), dtype=bool)
+        for desc_min in desc_mins:
+            set_tuning_env(monkeypatch, sparse_desc="1", sparse_desc_min=desc_min, sparse_form="1")
+            for how in ("whole", "three calls", "row bands"):
+                e = native.Engine(g, m, path=2, skip_test_block=skip)
+                e.load_sequences(tokens, offsets, ntr if skip else N, N - ntr if skip else 0)
+                if how == "whole":
+                    e.accumulate(combos)
+                elif how == "three calls":
+                    for part in np.array_split(combos, 3):
+                        e.accumulate(part)
+                else:
+                    for lo, hi in ((0, N // 4), (N // 4, (2 * N) // 3), ((2 * N) // 3, N)):
+                        e.accumulate_rows(combos, lo, hi)
+                e.finalize()
+                got = e.get_counts()
+                st = e.stats()
+                assert st["sparse_desc"] == 1 and st["sparse_form"] == 0
+                assert np.array_equal(got[keep], raw[keep]), (desc_min, how, g)
+                assert skip or st["cell_updates"] == U
+                e.close()
+
+
+@pytest.mark.parametrize("name", ["f7_cfg4_prot219_exact", "f7_cfg1_prot11_approx_t1", "f5_prot11_variance_T1_it9", "f6_prot219_skipvar16"])
+@pytest.mark.parametrize("tune", [{"sparse_desc": "1"}, {"sparse_desc": "1", "sparse_desc_min": "4", "sparse_unpacked": "1"}])
+def test_sparse_descriptors_on_the_goldens(native, monkeypatch, name, tune):
+    """Descriptors forced on BASELINE configs 4 and 1 at full size (digests of the reference's output) and on the golden
+    slices: exact, skip-variance, variance mode (the by-slot form of k_sx_consume, u16 slot triangles), both entry formats."""
+    if not os.path.exists(os.path.join(GOLD, name + ".npz")):
+        pytest.skip("golden not present")
+    set_tuning_env(monkeypatch, **tune)
+    d = load_golden(name)
+    if "data" in d and "tokens" not in d:
+        tokens, offsets, ntr, nte, _, _ = load_tokens(d["data"])
+    else:
+        tokens, offsets, ntr, nte = d["tokens"], d["offsets"], d["n_train"], d["n_test"]
+    e = engine_for(native, d, path=2)
+    e.compute(tokens, offsets, ntr, nte)
+    assert e.stats()["sparse_desc"] == 1
+    tri = e.get_triangle()
+    if "tri_sha256" in d:
+        assert np.array_equal(tri[d["sample_cells"]], d["sample_tri"]) and sha(tri) == d["tri_sha256"]
+        if "counts_sha256" in d:
+            assert sha(e.get_counts()) == d["counts_sha256"]
+    else:
+        assert np.array_equal(tri, d["tri"])
+        if "counts" in d:
+            assert np.array_equal(e.get_counts(), d["counts"])
+    assert np.array_equal(e.get_stdevs(), d["stdevs"])
+    e.close()
+
+
 @pytest.mark.parametrize("share", ["0", "1", "2", "3", "-1"])
 def test_sparse_shared_leading_positions_config4(native, monkeypatch, share):
     """Shared prefixes: BASELINE config 4 (1001 consecutive combos, k = 4 of 20 symbols — the batches are large enough for the

@@ -19,7 +19,7 @@ for name in sys.argv[1].split(","):
         for _ in range(3):
             t0 = time.perf_counter(); e.compute(tokens, offsets, ntr, nte); best = min(best, time.perf_counter() - t0)
         st = e.stats(); dg = e.counts_digest()
-        out[name] = {"s": round(best, 4), "redone": st["batches_redone"], "digest": format(int(dg[0]), "x") + "." + format(int(dg[1]), "x")}
+        out[name] = {"s": round(best, 4), "redone": st["batches_redone"], "desc": st["sparse_desc"], "digest": format(int(dg[0]), "x") + "." + format(int(dg[1]), "x")}
         e.close()
         continue
     d = load_golden(name)
@@ -33,7 +33,8 @@ for name in sys.argv[1].split(","):
     st = e.stats()
     dg = e.counts_digest() if not d["approx"] else (0, 0)
     out[name] = {"ms": round(best * 1e3, 3), "issued": st["combos_issued"], "done": st["combos_done"], "stdevs": len(e.get_stdevs()),
-                 "launches": st["launches"] // 8, "redone": st["batches_redone"], "digest": format(int(dg[0]), "x") + "." + format(int(dg[1]), "x")}
+                 "launches": st["launches"] // 8, "redone": st["batches_redone"], "desc": st["sparse_desc"],
+                 "stdev0": (float(e.get_stdevs()[-1]) if len(e.get_stdevs()) else 0.0), "digest": format(int(dg[0]), "x") + "." + format(int(dg[1]), "x")}
     e.close()
 print(json.dumps(out))
 ''' % (ROOT, ROOT)
