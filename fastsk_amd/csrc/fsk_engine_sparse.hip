@@ -13,7 +13,7 @@ namespace fsk_detail {
 // sparse dataflow: owner bands of K. The update stream of a band is summed in LDS by one workgroup,
 // so a band is a range of whole rows with 8192 or 16384 cells + up to a row (the LDS budget of k_sx_consume
 // bounds it: SX_CAP cells per round, at most SX_MAX_ROUNDS rounds over the band's stream).
-constexpr uint32_t SX_CAP = 19456;        // u32 cells of K one k_sx_consume workgroup holds in LDS (76 KiB + the parts table: two workgroups per CU)
+constexpr uint32_t SX_CAP = 20480;        // u32 cells of K one k_sx_consume workgroup holds in LDS (80 KiB: two workgroups per CU; its parts table stays in global memory)
 constexpr uint32_t SX_MAX_ROUNDS = 16;
 constexpr uint32_t SX_CAP_SLOT = 20480;   // by-slot form (no parts table in LDS): 80 KiB, two workgroups per CU
 
@@ -549,7 +549,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             const uint32_t n_tiles_max = Op + (uint32_t)((words + fsk::SXB_TILE - 1) / fsk::SXB_TILE);
             const uint32_t n_split = std::min<uint32_t>(n_tiles_max, 2u * (uint32_t)std::max(1, e->n_cu));
             FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, stream, (const uint32_t*)S.d_list_off.p, Op, (uint32_t)fsk::SXB_TILE, S.d_part_base.p,
-                       (const u64*)S.d_sxstat.p, ~(u64)0, 0u);
+                       (const u64*)S.d_sxstat.p, ~(u64)0, 0u, (uint32_t*)nullptr, 0xffffffffu, 1u);
             FSK_LAUNCH(fsk::k_sxb_count, dim3(n_split), dim3(fsk::SXB_THREADS), 0, stream, (const uint32_t*)S.d_ulist.p, (const uint32_t*)S.d_list_off.p,
                        (const uint32_t*)S.d_part_base.p, Op, P.pb, P.sub_shift, P.submax, S.d_subcnt.p);
             FSK_LAUNCH(fsk::k_sxb_scan, dim3(Op), dim3(fsk::SXB_THREADS), 0, stream, (const uint32_t*)S.d_subcnt.p, (const uint32_t*)S.d_list_off.p, P.submax,
@@ -656,9 +656,11 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             // parts of about `target` words: ~1024 workgroups, and never so short that the flush of a
             // part (up to sx_cap cells) outweighs the words it summed
             const uint32_t target = (uint32_t)std::max<u64>((u64)4 * e->sx_cap, (words + 1023) / 1024);
-            // (with descriptors k_sx_parts sets the target itself: about SX_DESC_PARTS parts, at most one more a band)
-            const uint32_t max_parts = desc ? O + fsk::SX_DESC_PARTS + 1u : O + (uint32_t)(((guarded ? guard_cap : words) + target - 1) / target);
+            // (with descriptors k_sx_parts sets the target itself: about sparse_desc_parts parts, at most one more a band)
+            const uint32_t desc_parts = (uint32_t)std::max<int64_t>(1, e->tune.sparse_desc_parts);
+            const uint32_t max_parts = desc ? O + desc_parts + 9u : O + (uint32_t)(((guarded ? guard_cap : words) + target - 1) / target);
             const void* const Ep = (const void*)S.d_E.p;
+            if (slot_stride == 0) FSK_HIP(S.d_part_base.reserve((size_t)O + 2 + max_parts));  // (bases, total, target, then the band of every part)
             if (k_wait) FSK_HIP(hipStreamWaitEvent(stream, k_wait, 0));
             if (slot_stride != 0) {  // one triangle per slot: a slot's words of a stream are one contiguous piece
                 if (slot16) {
@@ -676,7 +678,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                 }
             } else {
                 FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, stream, (const uint32_t*)S.d_list_off.p, O, target, S.d_part_base.p,
-                           (const u64*)S.d_sxstat.p, cap_words, desc);
+                           (const u64*)S.d_sxstat.p, cap_words, desc, S.d_part_base.p + O + 2, max_parts, desc_parts);
                 FSK_LAUNCH(fsk::k_sx_consume<false>, dim3(max_parts, e->sx_rounds), dim3(fsk::CS_THREADS), lds, stream, (const uint32_t*)S.d_ulist.p,
                            (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)S.d_part_base.p, O, target,
                            e->sx_cap, e->sx_pb, K, (const uint32_t*)nullptr, tpg, (u64)0, (const u64*)S.d_sxstat.p, cap_words, (uint32_t*)nullptr, pairs,

@@ -11,6 +11,16 @@ libs = {"base": _native.library()}
 for p in sys.argv[1:]:
     libs[os.path.basename(p)] = _native.Library(p)
 for name in os.environ.get("AB_CASES", "f7_cfg4_prot219_exact,f7_cfg1_prot11_approx_t1").split(","):
+    if name == "large_g":  # EP300, k = 6, g = 20 (one call each; results of measurement builds are not checked)
+        tokens, offsets, ntr, nte, _, _ = load_tokens("EP300")
+        res = {}
+        for k, lib in libs.items():
+            e = _native.Engine(20, 14, lib=lib)
+            e.compute(tokens, offsets, ntr, nte)
+            t0 = time.perf_counter(); e.compute(tokens, offsets, ntr, nte); res[k] = round(time.perf_counter() - t0, 4)
+            e.close()
+        print(json.dumps({"case": name, **res}))
+        continue
     d = load_golden(name)
     tokens, offsets, ntr, nte, _, _ = load_tokens(d["data"])
     eng = {}
