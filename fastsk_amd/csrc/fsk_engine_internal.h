@@ -114,9 +114,10 @@ using fsk_detail::DevBuf;
     X(blocks_scatter_threads, 0, 0, 1024, "sparse, blocks: threads of a k_sxb_scatter workgroup, 256 / 512 / 1024 (0: 256)")          \
     X(blocks_pass_words, 0, 0, (int64_t)1 << 32, "sparse, blocks: update words of one pass at most (0: 2^31)")                       \
     X(sparse_desc, 0, -1, 1, "sparse, owner bands: entries of many partners leave k_sx_emit as ONE descriptor each that k_sx_consume expands in LDS — 1 = always, -1 = never (0: once a batch of these sequences has shown sparse_desc_from pairs per record)") \
-    X(sparse_desc_min, 0, 0, 48, "sparse, descriptors: entries of more partners than this become descriptors (0: 48, what k_sx_emit bins in LDS)") \
+    X(sparse_desc_min, 16, 1, 48, "sparse, descriptors: entries of more partners than this become descriptors (48: everything k_sx_emit does not bin in LDS; measured, large-g regime: 48 0.92 s, 32 0.85, 16 0.83-0.85, 8 0.88, 4 0.90)") \
     X(sparse_desc_from, 8, 1, 1 << 20, "sparse, descriptors: the pairs per sort record of a batch from which on the following batches use them (sparse_desc = 0)") \
-    X(sparse_desc_parts, 1024, 1, 1 << 16, "sparse, descriptors: parts (k_sx_consume workgroups) the bands' streams are cut into, about") \
+    X(sparse_parts_target, 0, 0, 1 << 30, "sparse, owner bands: words of one k_sx_consume part (0: four LDS rounds' worth at least, 1/1024 of the batch's words; tests: several parts a band on small inputs)") \
+    X(sparse_desc_parts, 2048, 1, 1 << 16, "sparse, descriptors: parts (k_sx_consume workgroups) the bands' streams are cut into, about") \
     X(sparse_share, 0, -1, 254, "sparse: leading kept positions sorted once per group of consecutive combos that share them (0: by cost; -1: never); batches of more than 16 slots only (smaller ones read their positions by id), and never when the presort's scratch passes a quarter of the free memory") \
     X(seed_splitmix, 0, 0, 1, "approx modes: 1 = fsk_set_seed draws the engine's older splitmix64 Fisher-Yates order (0: the reference's std::shuffle of minstd_rand0)") \
     X(collective, 0, 0, 2, "fsk_create_multi: FSK_COLL_* when fsk_config.collective is FSK_COLL_AUTO")                                \

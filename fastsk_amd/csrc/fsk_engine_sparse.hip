@@ -655,7 +655,9 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             FSK_HIP(fsk_hw::allow_dynamic_lds(fsk::k_sx_consume<true>, lds_slot));
             // parts of about `target` words: ~1024 workgroups, and never so short that the flush of a
             // part (up to sx_cap cells) outweighs the words it summed
-            const uint32_t target = (uint32_t)std::max<u64>((u64)4 * e->sx_cap, (words + 1023) / 1024);
+            // (tuning sparse_parts_target: tests cut small inputs into several parts a band)
+            const uint32_t target = e->tune.sparse_parts_target > 0 ? (uint32_t)e->tune.sparse_parts_target
+                                                                    : (uint32_t)std::max<u64>((u64)4 * e->sx_cap, (words + 1023) / 1024);
             // (with descriptors k_sx_parts sets the target itself: about sparse_desc_parts parts, at most one more a band)
             const uint32_t desc_parts = (uint32_t)std::max<int64_t>(1, e->tune.sparse_desc_parts);
             const uint32_t max_parts = desc ? O + desc_parts + 9u : O + (uint32_t)(((guarded ? guard_cap : words) + target - 1) / target);

@@ -1095,8 +1095,7 @@ def test_emu_sparse_two_level_blocks(emu_lib, port, skip):
         e.close()
 
 
-@pytest.mark.parametrize("skip", [False, True])
-@pytest.mark.parametrize("desc_min", [0, 6])
+@pytest.mark.parametrize("desc_min,skip", [(48, False), (6, False), (6, True)])
 def test_emu_sparse_descriptors(emu_lib, port, monkeypatch, skip, desc_min):
     """Descriptors (tuning sparse_desc=1): an entry of more partners than k_sx_emit bins in LDS leaves as ONE descriptor
     {first partner's entry, partners, row, multiplicity} in its band's descriptor stream and k_sx_consume walks the partners
@@ -1105,17 +1104,20 @@ def test_emu_sparse_descriptors(emu_lib, port, monkeypatch, skip, desc_min):
     off; in one call, in three, in row bands; with skip_test_block (partners = the run's train entries)."""
     from fastsk_amd import _native
     rng = np.random.default_rng(78)
-    N, ntr, g, m = 400, 250, 5, 3
-    X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(14, 30, size=N)]
+    N, ntr, g, m = 300, 190, 5, 3
+    X = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(14, 26, size=N)]
     X[11][:] = 2  # a low-complexity sequence: multiplicities above 1
     tokens, offsets = _native.flatten(X)
     combos = np.array([0, 4, 9], dtype=np.int32)
     raw, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=4)
     a, b = np.tril_indices(N)
     keep = (b < ntr) | (a == b) if skip else np.ones(len(a), dtype=bool)
-    for pairs in ("1", "0"):
-        set_tuning_env(monkeypatch, sparse_desc=1, sparse_desc_min=desc_min, sparse_pairs=pairs, sparse_form=1)
-        for how in ("whole", "three calls", "row bands"):
+    # (pairs off: also with the bands' streams cut into several parts each — every part takes every nparts-th descriptor of its band
+    # and adds into K with atomics — the stream of a band in pieces of whole 16 bytes)
+    for pairs, parts, hows in (("1", None, ("whole", "row bands")), ("0", 64, ("three calls",))):
+        set_tuning_env(monkeypatch, sparse_desc=1, sparse_desc_min=desc_min, sparse_pairs=pairs, sparse_form=1, sparse_parts_target=parts,
+                       sparse_desc_parts=4096 if parts else None)
+        for how in hows:
             e = _native.Engine(g, m, path=2, lib=emu_lib, skip_test_block=skip)
             e.load_sequences(tokens, offsets, ntr if skip else N, N - ntr if skip else 0)
             if how == "whole":
@@ -1124,7 +1126,7 @@ def test_emu_sparse_descriptors(emu_lib, port, monkeypatch, skip, desc_min):
                 for part in np.array_split(combos, 3):
                     e.accumulate(part)
             else:
-                for lo, hi in ((0, 128), (128, 256), (256, N)):
+                for lo, hi in ((0, 128), (128, N)):
                     e.accumulate_rows(combos, lo, hi)
             e.finalize()
             got = e.get_counts()

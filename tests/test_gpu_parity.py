@@ -796,7 +796,7 @@ def test_sparse_descriptors(native, port, monkeypatch, skip):
     data at N = 1500, thresholds 48 / 6 partners, a low-complexity sequence (own cells of multiplicities above 1), in one
     call, in three, in row bands, with skip_test_block: the oracle's counts and U."""
     for X, g, m, combos, desc_mins in (
-            ([np.random.default_rng(40 + i).integers(1, 5, size=26).astype(np.int32) for i in range(4000)], 6, 2, np.arange(0, 15, 5, dtype=np.int32), ("0", "6")),
+            ([np.random.default_rng(40 + i).integers(1, 5, size=26).astype(np.int32) for i in range(4000)], 6, 2, np.arange(0, 15, 5, dtype=np.int32), ("48", "6")),
             (protein_like(1500, 40, 160, seed=33), 10, 6, np.arange(0, 210, 9, dtype=np.int32), ("6",))):
         N, ntr = len(X), (2 * len(X)) // 3
         X[7][:] = 3
