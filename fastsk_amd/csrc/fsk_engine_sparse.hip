@@ -245,7 +245,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     const uint32_t O = blocks ? (uint32_t)e->tune.blocks_max_bands : e->n_owners;  // (blocks: the most bands a pass can have)
     // descriptors (owner bands only): entries of more than short_max partners leave k_sx_emit as one descriptor each and
     // k_sx_consume walks their partners; the count matrix and the stream offsets then have two columns a band
-    const uint32_t desc = lists && sx_desc_wanted(e) ? 1u : 0u;
+    const uint32_t desc = !sx_desc_wanted(e) ? 0u : lists ? 1u : (blocks && e->tune.sparse_desc_blocks) ? 2u : 0u;  // (1: one descriptor an entry; 2: one per sub-band)
     const uint32_t short_max = desc && e->tune.sparse_desc_min > 0 ? (uint32_t)std::min<int64_t>(e->tune.sparse_desc_min, (int64_t)fsk::SX_SHORT) : fsk::SX_SHORT;
     const uint32_t OC = desc ? 2u * O : O;  // columns
     e->sx_desc_used = desc != 0;
@@ -450,6 +450,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         e->tic(stream);
         std::vector<std::pair<int64_t, int64_t>> todo;
         todo.emplace_back(row0, row1);
+        u64 batch_pairs = 0;  // (the passes' += in all: what decides about descriptors for the batches that follow)
         bool first_pass = true;
         while (!todo.empty()) {
             const int64_t ra = todo.back().first, rb = todo.back().second;
@@ -492,18 +493,19 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                            (const int*)S.d_tile_rs.p, reinterpret_cast<uint32_t*>(S.d_E.p), reinterpret_cast<uint16_t*>(S.d_Pk.p), P.t, Op,
                            S.d_ucount.p, (uint32_t)ra, (uint32_t)rb, e->maxW, maxprod_p, cmax_p, S.d_tile_stat.p, skip_from,
                            skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr,
-                           skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr, P.own_base, fsk::SX_SHORT, 0u);
+                           skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr, P.own_base, short_max, desc, P.sub_shift);
             } else {
                 auto k_seg = skipping ? fsk::k_sx_seg_write<RecT, false, false, true> : fsk::k_sx_seg_write<RecT, false, false, false>;
                 FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)S.d_ebase.p,
                            (const int*)S.d_tile_rs.p, S.d_E.p, S.d_Pk.p, P.t, Op, S.d_ucount.p, (uint32_t)ra, (uint32_t)rb, e->maxW, maxprod_p,
                            cmax_p, S.d_tile_stat.p, skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr,
-                           skipping ? S.d_Tk.p : (uint32_t*)nullptr, P.own_base, fsk::SX_SHORT, 0u);
+                           skipping ? S.d_Tk.p : (uint32_t*)nullptr, P.own_base, short_max, desc, P.sub_shift);
             }
-            FSK_LAUNCH(fsk::k_sx_ucol_sum, dim3(nchunks), dim3(256), 0, stream, (const uint32_t*)S.d_ucount.p, ntiles, Op, S.d_uchunk.p,
+            const uint32_t OCp = desc ? 2u * Op : Op, wcol = desc ? Op : 0u;  // (columns: descriptor streams first, then the words')
+            FSK_LAUNCH(fsk::k_sx_ucol_sum, dim3(nchunks), dim3(256), 0, stream, (const uint32_t*)S.d_ucount.p, ntiles, OCp, S.d_uchunk.p,
                        (const u64*)S.d_tile_stat.p, S.d_sxstat.p, pin, uc);
-            FSK_LAUNCH(fsk::k_sx_ucol_scan, dim3(Op), dim3(256), 0, stream, S.d_uchunk.p, nchunks, Op, S.d_utot.p);
-            FSK_LAUNCH(fsk::k_sx_ucol_apply, dim3(nchunks), dim3(256), 0, stream, S.d_ucount.p, ntiles, Op, (const uint32_t*)S.d_uchunk.p,
+            FSK_LAUNCH(fsk::k_sx_ucol_scan, dim3(OCp), dim3(256), 0, stream, S.d_uchunk.p, nchunks, OCp, S.d_utot.p);
+            FSK_LAUNCH(fsk::k_sx_ucol_apply, dim3(nchunks), dim3(256), 0, stream, S.d_ucount.p, ntiles, OCp, (const uint32_t*)S.d_uchunk.p,
                        (const uint32_t*)S.d_utot.p, S.d_list_off.p, uc);
             e->st.launches += 4;
             FSK_HIP(hipStreamSynchronize(stream));
@@ -517,6 +519,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             if (words >= ((u64)1 << 32))
                 return e->fail(FSK_EUNSUPPORTED, "sparse dataflow: row %lld alone emits %llu update words a batch", (long long)ra, (unsigned long long)words);
             e->u_extra += pass_stat[0];
+            batch_pairs += pass_stat[0];
             e->sx_passes += 1;
             if (e->trace())
                 fprintf(stderr, "[fsk] sparse blocks: pass rows [%lld, %lld), %u bands of 2^%d cells, %u sub-bands a band, %d product bits, %llu words\n",
@@ -537,29 +540,43 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                            (const uint32_t*)S.d_list_off.p, (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)ra, (uint32_t)rb, e->maxW,
                            maxprod_p, cmax_p, P.pb, K, tpg, (u64)0,
                            skipping ? reinterpret_cast<const uint16_t*>(S.d_Tk.p) : (const uint16_t*)nullptr, (const u64*)S.d_sxstat.p, ~(u64)0,
-                           ntiles, 0, P.own_base, fsk::SX_SHORT, 0u);
+                           ntiles, 0, P.own_base, short_max, desc, P.sub_shift);
             } else {
                 auto k_emit = skipping ? fsk::k_sx_emit<false, true, false> : fsk::k_sx_emit<false, false, false>;
                 FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, (const uint2*)S.d_E.p, (const uint32_t*)S.d_Pk.p,
                            (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_blk_r0.p, P.t, Op, (const uint32_t*)S.d_list_off.p,
                            (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)ra, (uint32_t)rb, e->maxW, maxprod_p, cmax_p, P.pb, K, tpg, (u64)0,
-                           skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)S.d_sxstat.p, ~(u64)0, ntiles, 0, P.own_base, fsk::SX_SHORT, 0u);
+                           skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)S.d_sxstat.p, ~(u64)0, ntiles, 0, P.own_base, short_max, desc, P.sub_shift);
             }
             // (persistent launches: two workgroups of 1024 threads a CU walk the tiles of the bands' streams in contiguous chunks)
             const uint32_t n_tiles_max = Op + (uint32_t)((words + fsk::SXB_TILE - 1) / fsk::SXB_TILE);
             const uint32_t n_split = std::min<uint32_t>(n_tiles_max, 2u * (uint32_t)std::max(1, e->n_cu));
-            FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, stream, (const uint32_t*)S.d_list_off.p, Op, (uint32_t)fsk::SXB_TILE, S.d_part_base.p,
+            const uint32_t* const w_off = (const uint32_t*)S.d_list_off.p + wcol;  // where the bands' word streams start
+            FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, stream, w_off, Op, (uint32_t)fsk::SXB_TILE, S.d_part_base.p,
                        (const u64*)S.d_sxstat.p, ~(u64)0, 0u, (uint32_t*)nullptr, 0xffffffffu, 1u);
-            FSK_LAUNCH(fsk::k_sxb_count, dim3(n_split), dim3(fsk::SXB_THREADS), 0, stream, (const uint32_t*)S.d_ulist.p, (const uint32_t*)S.d_list_off.p,
+            FSK_LAUNCH(fsk::k_sxb_count, dim3(n_split), dim3(fsk::SXB_THREADS), 0, stream, (const uint32_t*)S.d_ulist.p, w_off,
                        (const uint32_t*)S.d_part_base.p, Op, P.pb, P.sub_shift, P.submax, S.d_subcnt.p);
-            FSK_LAUNCH(fsk::k_sxb_scan, dim3(Op), dim3(fsk::SXB_THREADS), 0, stream, (const uint32_t*)S.d_subcnt.p, (const uint32_t*)S.d_list_off.p, P.submax,
-                       S.d_suboff.p, S.d_subcur.p);
+            FSK_LAUNCH(fsk::k_sxb_scan, dim3(Op), dim3(fsk::SXB_THREADS), 0, stream, (const uint32_t*)S.d_subcnt.p, w_off, P.submax,
+                       S.d_suboff.p, S.d_subcur.p, 0);
+            if (desc) {  // the descriptor records by (band, sub-band): count, scan, scatter (into the head of the second buffer, as in the first)
+                FSK_HIP(S.d_dsubcnt.reserve(nsub));
+                FSK_HIP(S.d_dsuboff.reserve(nsub));
+                FSK_HIP(S.d_dsubcur.reserve(nsub));
+                FSK_HIP(hipMemsetAsync(S.d_dsubcnt.p, 0, nsub * sizeof(uint32_t), stream));
+                const dim3 dgrid((uint32_t)std::max(1, 16 * e->n_cu / (int)std::max(1u, Op)) + 1u, Op);
+                FSK_LAUNCH(fsk::k_sxb_dcount, dgrid, dim3(256), 0, stream, (const uint32_t*)S.d_ulist.p, (const uint32_t*)S.d_list_off.p, P.submax, S.d_dsubcnt.p);
+                FSK_LAUNCH(fsk::k_sxb_scan, dim3(Op), dim3(fsk::SXB_THREADS), 0, stream, (const uint32_t*)S.d_dsubcnt.p, (const uint32_t*)S.d_list_off.p,
+                           P.submax, S.d_dsuboff.p, S.d_dsubcur.p, 2);
+                FSK_LAUNCH(fsk::k_sxb_dscatter, dgrid, dim3(256), 0, stream, (const uint32_t*)S.d_ulist.p, (const uint32_t*)S.d_list_off.p, P.submax,
+                           S.d_dsubcur.p, reinterpret_cast<uint4*>(S.d_ulist2.p));
+                e->st.launches += 3;
+            }
             {   // (workgroups of 256 threads, three a CU by their LDS; tuning blocks_scatter_threads: 512 / 1024 for the A/B)
                 const int nt = e->tune.blocks_scatter_threads ? (int)e->tune.blocks_scatter_threads : 256;
                 const uint32_t per_cu = nt == 1024 ? 2u : 3u;
                 const uint32_t grid = std::min<uint32_t>(n_tiles_max, per_cu * (uint32_t)std::max(1, e->n_cu));
                 auto k_sc = nt == 1024 ? fsk::k_sxb_scatter<1024> : nt == 512 ? fsk::k_sxb_scatter<512> : fsk::k_sxb_scatter<256>;
-                FSK_LAUNCH(k_sc, dim3(grid), dim3((uint32_t)nt), 0, stream, (const uint32_t*)S.d_ulist.p, (const uint32_t*)S.d_list_off.p,
+                FSK_LAUNCH(k_sc, dim3(grid), dim3((uint32_t)nt), 0, stream, (const uint32_t*)S.d_ulist.p, w_off,
                            (const uint32_t*)S.d_part_base.p, Op, P.pb, P.sub_shift, P.submax, S.d_subcur.p, S.d_ulist2.p);
             }
             const size_t lds_sub = sizeof(uint32_t) << P.sub_shift;
@@ -567,7 +584,9 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                 auto k_cs = P.sub_shift <= 13 ? fsk::k_sxb_consume<512> : fsk::k_sxb_consume<1024>;
                 FSK_HIP(fsk_hw::allow_dynamic_lds(k_cs, lds_sub));
                 FSK_LAUNCH(k_cs, dim3(P.submax, Op), dim3(P.sub_shift <= 13 ? 512u : 1024u), lds_sub, stream, (const uint32_t*)S.d_ulist2.p,
-                           (const uint32_t*)S.d_suboff.p, (const uint32_t*)S.d_subcnt.p, (const uint32_t*)e->d_blk_r0.p, P.pb, P.sub_shift, P.submax, K);
+                           (const uint32_t*)S.d_suboff.p, (const uint32_t*)S.d_subcnt.p, (const uint32_t*)e->d_blk_r0.p, P.pb, P.sub_shift, P.submax, K,
+                           desc ? reinterpret_cast<const uint4*>(S.d_ulist2.p) : (const uint4*)nullptr, (const uint32_t*)S.d_dsuboff.p,
+                           (const uint32_t*)S.d_dsubcnt.p, (const void*)S.d_E.p, packed ? 1 : 0);
             }
             e->st.launches += 6;
             FSK_HIP(hipStreamSynchronize(stream));  // (the next pass overwrites the band table, the entries' unit marks and the streams)
@@ -582,6 +601,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         e->toc(&e->st.ms_pairs, stream);
         FSK_HIP(hipGetLastError());
         stat_pin[0] = stat_pin[1] = 0;  // (every pass has been added to u_extra already)
+        e->sx_saw_pairs(batch_pairs, nrec);
         return FSK_OK;
     }
     if (packed) {
@@ -591,14 +611,14 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                    (const int*)S.d_tile_rs.p, reinterpret_cast<uint32_t*>(S.d_E.p), reinterpret_cast<uint16_t*>(S.d_Pk.p), e->sx_own_shift, O,
                    lists ? S.d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, S.d_tile_stat.p,
                    skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr,
-                   skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr, 0u, short_max, desc);
+                   skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr, 0u, short_max, desc, 0);
     } else {
         auto k_seg = skipping ? (pairs ? fsk::k_sx_seg_write<RecT, false, true, true> : fsk::k_sx_seg_write<RecT, false, false, true>)
                               : (pairs ? fsk::k_sx_seg_write<RecT, false, true, false> : fsk::k_sx_seg_write<RecT, false, false, false>);
         FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)S.d_ebase.p,
                    (const int*)S.d_tile_rs.p, S.d_E.p, S.d_Pk.p, e->sx_own_shift, O,
                    lists ? S.d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, S.d_tile_stat.p,
-                   skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr, skipping ? S.d_Tk.p : (uint32_t*)nullptr, 0u, short_max, desc);
+                   skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr, skipping ? S.d_Tk.p : (uint32_t*)nullptr, 0u, short_max, desc, 0);
     }
     stat_pin[0] = stat_pin[1] = 0;
     e->st.launches += 3;
@@ -642,13 +662,13 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                            reinterpret_cast<const uint16_t*>(S.d_Pk.p), (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p,
                            e->sx_own_shift, O, (const uint32_t*)S.d_list_off.p, (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)row0,
                            (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg, slot_stride,
-                           skipping ? reinterpret_cast<const uint16_t*>(S.d_Tk.p) : (const uint16_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles, pairs, 0u, short_max, desc);
+                           skipping ? reinterpret_cast<const uint16_t*>(S.d_Tk.p) : (const uint16_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles, pairs, 0u, short_max, desc, 0);
             } else {
                 auto k_emit = skipping ? fsk::k_sx_emit<false, true, false> : fsk::k_sx_emit<false, false, false>;
                 FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, (const uint2*)S.d_E.p, (const uint32_t*)S.d_Pk.p,
                            (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)S.d_list_off.p,
                            (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
-                           slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles, pairs, 0u, short_max, desc);
+                           slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles, pairs, 0u, short_max, desc, 0);
             }
             const size_t lds = (size_t)e->sx_cap * sizeof(uint32_t), lds_slot = (size_t)e->sx_cap_slot * sizeof(uint32_t);
             FSK_HIP(fsk_hw::allow_dynamic_lds(fsk::k_sx_consume<false>, lds));
@@ -697,13 +717,13 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                        reinterpret_cast<const uint16_t*>(S.d_Pk.p), (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift,
                        O, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod,
                        cmax, e->sx_pb, K, tpg, slot_stride, skipping ? reinterpret_cast<const uint16_t*>(S.d_Tk.p) : (const uint16_t*)nullptr,
-                       (const u64*)nullptr, ~(u64)0, ntiles, 0, 0u, fsk::SX_SHORT, 0u);
+                       (const u64*)nullptr, ~(u64)0, ntiles, 0, 0u, fsk::SX_SHORT, 0u, 0);
         } else {
             auto k_emit = skipping ? fsk::k_sx_emit<true, true, false> : fsk::k_sx_emit<true, false, false>;
             FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, (const uint2*)S.d_E.p, (const uint32_t*)S.d_Pk.p,
                        (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)nullptr,
                        (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
-                       slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)nullptr, ~(u64)0, ntiles, 0, 0u, fsk::SX_SHORT, 0u);
+                       slot_stride, skipping ? (const uint32_t*)S.d_Tk.p : (const uint32_t*)nullptr, (const u64*)nullptr, ~(u64)0, ntiles, 0, 0u, fsk::SX_SHORT, 0u, 0);
         }
         e->st.launches += 1;
     }

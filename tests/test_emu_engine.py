@@ -1054,13 +1054,15 @@ def test_emu_sparse_shared_leading_positions(emu_lib, port, monkeypatch, case):
             e.close()
 
 
-@pytest.mark.parametrize("skip", [False, True])
-def test_emu_sparse_two_level_blocks(emu_lib, port, skip):
+@pytest.mark.parametrize("skip,desc", [(False, 0), (True, 0), (False, 1), (True, 1)])
+def test_emu_sparse_two_level_blocks(emu_lib, port, skip, desc):
     """The two-level form of the update stage (fsk_sparse_blocks.inc: bands binned by k_sx_emit, every band's stream split by
     sub-band, one workgroup a sub-band) — what N beyond the owner bands takes instead of one atomic per += — forced on a small
     input with small blocks: several passes over row ranges (few bands a pass, a word budget that halves ranges), several bands a
     pass, several sub-bands a band; packed and general entries; protein-like runs with a low-complexity sequence and long DNA
-    runs; whole, in two calls and in row bands; skip_test_block. Against the oracle's counts and its exact U."""
+    runs; whole, in two calls and in row bands; skip_test_block. desc: every entry above three partners as descriptor records, one
+    per sub-band its partners fall into (k_sx_emit's bisection, k_sxb_dcount / k_sxb_dscatter, sx_expand_descriptors in
+    k_sxb_consume), its own cell as a word. Against the oracle's counts and its exact U."""
     from fastsk_amd import _native
     rng = np.random.default_rng(21)
     N, ntr = 140, 90
@@ -1076,6 +1078,7 @@ def test_emu_sparse_two_level_blocks(emu_lib, port, skip):
     for X, g, m, combos, tun, how in plans:
         tokens, offsets = _native.flatten(X)
         raw, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=4)
+        tun = dict(tun, sparse_desc=1, sparse_desc_min=3) if desc else dict(tun, sparse_desc=-1)
         e = _native.Engine(g, m, path=2, lib=emu_lib, skip_test_block=skip, tuning=tun)
         e.load_sequences(tokens, offsets, ntr if skip else N, N - ntr if skip else 0)
         if how == "whole":
@@ -1088,8 +1091,8 @@ def test_emu_sparse_two_level_blocks(emu_lib, port, skip):
                 e.accumulate_rows(combos, lo, hi)
         e.finalize()
         st = e.stats()
-        assert st["sparse_form"] == 2
-        assert len(tun) == 1 or st["sparse_passes"] > 2
+        assert st["sparse_form"] == 2 and st["sparse_desc"] == desc
+        assert "blocks_sub_shift" not in tun or st["sparse_passes"] > 2
         assert np.array_equal(e.get_counts()[keep], raw[keep]), (g, m, tun, how)
         assert skip or st["cell_updates"] == U
         e.close()
