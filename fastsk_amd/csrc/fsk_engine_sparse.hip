@@ -563,11 +563,12 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                 FSK_HIP(S.d_dsuboff.reserve(nsub));
                 FSK_HIP(S.d_dsubcur.reserve(nsub));
                 FSK_HIP(hipMemsetAsync(S.d_dsubcnt.p, 0, nsub * sizeof(uint32_t), stream));
-                const dim3 dgrid((uint32_t)std::max(1, 16 * e->n_cu / (int)std::max(1u, Op)) + 1u, Op);
-                FSK_LAUNCH(fsk::k_sxb_dcount, dgrid, dim3(256), 0, stream, (const uint32_t*)S.d_ulist.p, (const uint32_t*)S.d_list_off.p, P.submax, S.d_dsubcnt.p);
+                const dim3 dgrid((uint32_t)std::max(1, 4 * e->n_cu / (int)std::max(1u, Op)) + 1u, Op);
+                FSK_LAUNCH(fsk::k_sxb_drecords<false>, dgrid, dim3(1024), 0, stream, (const uint32_t*)S.d_ulist.p, (const uint32_t*)S.d_list_off.p, P.submax,
+                           S.d_dsubcnt.p, (uint4*)nullptr);
                 FSK_LAUNCH(fsk::k_sxb_scan, dim3(Op), dim3(fsk::SXB_THREADS), 0, stream, (const uint32_t*)S.d_dsubcnt.p, (const uint32_t*)S.d_list_off.p,
                            P.submax, S.d_dsuboff.p, S.d_dsubcur.p, 2);
-                FSK_LAUNCH(fsk::k_sxb_dscatter, dgrid, dim3(256), 0, stream, (const uint32_t*)S.d_ulist.p, (const uint32_t*)S.d_list_off.p, P.submax,
+                FSK_LAUNCH(fsk::k_sxb_drecords<true>, dgrid, dim3(1024), 0, stream, (const uint32_t*)S.d_ulist.p, (const uint32_t*)S.d_list_off.p, P.submax,
                            S.d_dsubcur.p, reinterpret_cast<uint4*>(S.d_ulist2.p));
                 e->st.launches += 3;
             }

@@ -584,23 +584,24 @@ def test_wave_primitives(native):
 
 # ---- the two-level form of the update stage (fsk_sparse_blocks.inc): what countAndUpdateTri (shared.cpp:268-333) takes where the
 # owner bands end — bands binned by k_sx_emit, every band's stream split by sub-band, one workgroup a sub-band
-@pytest.mark.parametrize("skip", [False, True])
-def test_sparse_two_level_blocks_100k_protein_like(native, port, skip):
+@pytest.mark.parametrize("skip,desc", [(False, -1), (False, 1), (True, 1)])
+def test_sparse_two_level_blocks_100k_protein_like(native, port, skip, desc):
     """N = 100,000 protein-like ragged sequences (20 letters, 60-220 long), g=10 m=6, four combos: 5 * 10^9 cells — more than
     one pass's 32-bit cell offsets cover, several passes by word count too — through the blocks form. Random 1400-sequence subset
     (rows on both sides of 65,535) against the oracle, U on that subset, the digest of the whole triangle against the same combos
-    added with one 64-bit atomic per += (tuning sparse_form=3); with skip_test_block."""
+    added with one 64-bit atomic per += (tuning sparse_form=3); with skip_test_block. desc = 1: the entries of more than 16
+    partners as descriptor records, one per sub-band their partners fall into (8-byte entries: rows beyond 65,535)."""
     N, g, m = 100000, 10, 6
     X = protein_like(N, 60, 221, seed=100)
     tokens, offsets = native.flatten(X)
     combos = np.array([0, 71, 140, 209], dtype=np.int32)
     n_train = 60000
-    e = native.Engine(g, m, path=2, skip_test_block=skip)
+    e = native.Engine(g, m, path=2, skip_test_block=skip, tuning={"sparse_desc": desc})
     e.load_sequences(tokens, offsets, n_train if skip else N, N - n_train if skip else 0)
     e.accumulate(combos)
     e.finalize()
     st = e.stats()
-    assert st["path_used"] == 2 and st["sparse_form"] == 2 and st["sparse_passes"] >= 2 and st["n_seq"] == N
+    assert st["path_used"] == 2 and st["sparse_form"] == 2 and st["sparse_passes"] >= 2 and st["n_seq"] == N and st["sparse_desc"] == (desc > 0)
     rng = np.random.Generator(np.random.PCG64(9))
     idx = np.sort(np.concatenate([rng.choice(65535, size=800, replace=False), 65535 + rng.choice(N - 65535, size=600, replace=False)]))
     stoks, soff, U = _subset_against_oracle(native, port, e, X, idx, g, m, combos, n_train if skip else None)
@@ -634,7 +635,11 @@ def test_sparse_two_level_blocks_forced_small(native, port):
         for tun in ({"sparse_form": 1}, {"sparse_form": 3}, {"sparse_form": 2},
                     {"sparse_form": 2, "blocks_sub_shift": 8, "blocks_max_bands": 7, "blocks_band_shift_max": 12},
                     {"sparse_form": 2, "blocks_sub_shift": 10, "blocks_max_bands": 64, "blocks_band_shift_max": 13, "blocks_pass_words": 400000,
-                     "sparse_unpacked": 1}):
+                     "sparse_unpacked": 1},
+                    {"sparse_form": 2, "sparse_desc": 1, "sparse_desc_min": 3},
+                    {"sparse_form": 2, "blocks_sub_shift": 8, "blocks_max_bands": 7, "blocks_band_shift_max": 12, "sparse_desc": 1},
+                    {"sparse_form": 2, "blocks_sub_shift": 10, "blocks_max_bands": 64, "blocks_band_shift_max": 13, "blocks_pass_words": 400000,
+                     "sparse_unpacked": 1, "sparse_desc": 1, "sparse_desc_min": 5}):
             for how in ("whole", "three calls", "row bands"):
                 e = native.Engine(g, m, path=2, tuning=tun)
                 e.load_sequences(tokens, offsets, N, 0)
@@ -649,7 +654,8 @@ def test_sparse_two_level_blocks_forced_small(native, port):
                 e.finalize()
                 st = e.stats()
                 assert st["sparse_form"] == {1: 0, 2: 2, 3: 1}[tun["sparse_form"]]
-                assert len(tun) == 1 or st["sparse_passes"] >= 4
+                assert "blocks_sub_shift" not in tun or st["sparse_passes"] >= 4
+                assert st["sparse_desc"] == (1 if tun.get("sparse_desc") == 1 else st["sparse_desc"])
                 assert np.array_equal(e.get_counts(), want), (g, m, tun, how)
                 assert st["cell_updates"] == U
                 e.close()
@@ -815,7 +821,7 @@ def test_sparse_descriptors(native, port, monkeypatch, skip):
                     for part in np.array_split(combos, 3):
                         e.accumulate(part)
                 else:
-                    for lo, hi in ((0, N // 4), (N // 4, (2 * N) // 3), ((2 * N) // 3, N)):
+                    for lo, hi in ((0, 128 * (N // 512)), (128 * (N // 512), 128 * (N // 192)), (128 * (N // 192), N)):  # (multiples of 128)
                         e.accumulate_rows(combos, lo, hi)
                 e.finalize()
                 got = e.get_counts()
@@ -843,7 +849,7 @@ def test_sparse_descriptors_on_the_goldens(native, monkeypatch, name, tune):
     e.compute(tokens, offsets, ntr, nte)
     assert e.stats()["sparse_desc"] == 1
     tri = e.get_triangle()
-    if "tri_sha256" in d:
+    if "sample_cells" in d:
         assert np.array_equal(tri[d["sample_cells"]], d["sample_tri"]) and sha(tri) == d["tri_sha256"]
         if "counts_sha256" in d:
             assert sha(e.get_counts()) == d["counts_sha256"]
