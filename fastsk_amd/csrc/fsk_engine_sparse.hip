@@ -110,10 +110,14 @@ void plan_owner_bands(fsk_engine* e) {
 void sx_choose_form(fsk_engine* e) {
     const int64_t want = e->tune.sparse_form;
     const bool blocks_ok = blocks_plan_pass(e, 0, e->N, nullptr);
+    // (with descriptors a round of the bands walks every descriptor's partners again: the blocks from two rounds a band on —
+    // measured, DNA k = 8, N = 6,000 / 8,000 / 12,000 / 16,000, 495 combos: bands 0.09 / 0.14 / 0.86 / 1.3 s, blocks 0.07 / 0.10 / 0.16 / 0.22;
+    // one round, N = 4,000, the large-g regime: bands 0.83 s, blocks 1.38)
+    const uint32_t max_rounds = e->sx_desc_now() && e->tune.sparse_desc_blocks ? 1u : SX_BLOCKS_FROM_ROUNDS;
     e->sx_form = (want == 3 || e->tune.sparse_global) ? 1
                  : (want == 2 && blocks_ok)          ? 2
                  : (want == 1 && e->sx_lists)        ? 0
-                 : e->sx_lists && e->sx_rounds <= SX_BLOCKS_FROM_ROUNDS ? 0
+                 : e->sx_lists && e->sx_rounds <= max_rounds ? 0
                  : blocks_ok                                            ? 2
                  : e->sx_lists                                          ? 0
                                                                         : 1;

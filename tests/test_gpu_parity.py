@@ -1340,8 +1340,9 @@ def test_sequential_sum_on_the_device(native):
 def test_sparse_batches_enqueued_ahead_of_their_size(native, port, monkeypatch, env):
     """Sparse dataflow, several accumulate calls: batches after the first are enqueued before their
     update-word count is known; the same counts and U as batches sized one by one, also when every
-    such batch overflows the (shrunk) guard and is redone."""
-    set_tuning_env(monkeypatch, **env)
+    such batch overflows the (shrunk) guard and is redone. (Without descriptors: the batch that switches them on forgets the
+    words per record seen so far, and the next one is sized exactly instead of under a guard.)"""
+    set_tuning_env(monkeypatch, sparse_desc="-1", **env)
     tokens, offsets = synthetic_dna(900, 120, seed=21)
     g, m = 12, 6
     combos = np.arange(0, port.num_combos(g, m), 5, dtype=np.int32)
@@ -1509,15 +1510,16 @@ def test_sparse_guarded_batch_beyond_32_bit_word_total(native):
     d.finalize()
     want = d.get_counts()
     d.close()
-    e = native.Engine(g, m, path=2)
-    e.load_sequences(tokens, offsets, N, 0)
-    e.accumulate_rows(combos, 0, 768)     # sized exactly: ~0.3 G words, the guard of the next batch is 1.5x that
-    e.accumulate_rows(combos, 768, N)     # ~4.3 G words
-    e.finalize()
-    st = e.stats()
-    assert st["cell_updates"] > 2 ** 32 + 2 ** 28 and st["batches_redone"] == 1
-    assert np.array_equal(e.get_counts(), want)
-    e.close()
+    for desc in (-1, 1):  # (with descriptors the same pairs are a fraction of the words: nothing overflows, the same counts)
+        e = native.Engine(g, m, path=2, tuning={"sparse_desc": desc})
+        e.load_sequences(tokens, offsets, N, 0)
+        e.accumulate_rows(combos, 0, 768)     # sized exactly: ~0.3 G words, the guard of the next batch is 1.5x that
+        e.accumulate_rows(combos, 768, N)     # ~4.3 G words
+        e.finalize()
+        st = e.stats()
+        assert st["cell_updates"] > 2 ** 32 + 2 ** 28 and (desc > 0 or st["batches_redone"] == 1)
+        assert np.array_equal(e.get_counts(), want), desc
+        e.close()
 
 
 @pytest.mark.parametrize("forced", ["0", "1"])
@@ -1743,6 +1745,7 @@ def test_sparse_pair_accumulation_variants(native, port, monkeypatch, global_pai
 def test_sparse_words_per_record_hint_across_loads(native, port, monkeypatch, hint):
     """Sparse dataflow: a second set of sequences of the same shape starts from the first set's words per record as a hint
     (its first batch goes out under a guard, at full size); a hint that is far too low costs a redone batch, never a count."""
+    set_tuning_env(monkeypatch, sparse_desc="-1")  # (the batch that switches descriptors on forgets the words per record seen so far)
     if hint is not None:
         set_tuning_env(monkeypatch, sparse_hint=hint)
     rng = np.random.default_rng(5)

@@ -34,6 +34,11 @@ WORKLOADS = {
     "protein_like_12k": (12000, 20, 60, 220, 10, 6),
     "protein_like_16k": (16000, 20, 60, 220, 10, 6),
     "protein_like_20k": (20000, 20, 60, 220, 10, 6),
+    # long runs (descriptors) around the crossover
+    "dna_k8_6k": (6000, 4, 300, 300, 12, 4),
+    "dna_k8_8k": (8000, 4, 300, 300, 12, 4),
+    "dna_k8_12k": (12000, 4, 300, 300, 12, 4),
+    "dna_k8_16k": (16000, 4, 300, 300, 12, 4),
 }
 DEFAULT = ["protein_like_32k", "protein_like_64k", "protein_like_100k", "dna_k8_32k"]
 FORMS = {0: "bands", 1: "direct", 2: "blocks"}
