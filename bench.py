@@ -316,6 +316,13 @@ def other_configs(_native):
         out["sparse_large_n"] = {name: large_n.run(name, 20) for name in large_n.DEFAULT}
     except Exception as exc:
         out["sparse_large_n_error"] = repr(exc)
+    # the reference paper's large-g regime (EP300, k = 6, g = 16 and 20: 8,008 and 38,760 combos; tools/bench_large_g.py):
+    # seconds a whole kernel, U, algorithmic bytes and the fraction of the HBM roofline (the tool run by itself also checks a 12-combo subset against the oracle)
+    try:
+        import bench_large_g as large_g
+        out["large_g"] = {"g%d_m%d" % gm: large_g.run(*gm, check=False) for gm in ((16, 10), (20, 14))}
+    except Exception as exc:
+        out["large_g_error"] = repr(exc)
     return out or None
 
 

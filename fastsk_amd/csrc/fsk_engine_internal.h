@@ -115,6 +115,7 @@ using fsk_detail::DevBuf;
     X(blocks_pass_words, 0, 0, (int64_t)1 << 32, "sparse, blocks: update words of one pass at most (0: 2^31)")                       \
     X(sparse_desc, 0, -1, 1, "sparse, owner bands: entries of many partners leave k_sx_emit as ONE descriptor each that k_sx_consume expands in LDS — 1 = always, -1 = never (0: once a batch of these sequences has shown sparse_desc_from pairs per record)") \
     X(sparse_desc_blocks, 1, 0, 1, "sparse, two-level blocks: 0 = never descriptors there (1: as sparse_desc says — one record per sub-band an entry's partners fall into)") \
+    X(sparse_desc_cols, 1, 0, 3, "sparse, descriptors: where the partners are read from — 0 = the entries themselves; 1 = a column array (sequence id | multiplicity, 4 bytes) beside 8-byte entries, the entries themselves when they are packed (measured: 2-byte columns beside packed entries are no faster, 0.88 against 0.84 s in the large-g regime; 4-byte columns beside 8-byte entries 4.69 -> 4.44 ms a combo at N = 100k); tests: 2 = 4-byte columns always, 3 = 2-byte columns when N < 32768") \
     X(sparse_desc_min, 16, 1, 48, "sparse, descriptors: entries of more partners than this become descriptors (48: everything k_sx_emit does not bin in LDS; measured, large-g regime: 48 0.92 s, 32 0.85, 16 0.83-0.85, 8 0.88, 4 0.90)") \
     X(sparse_desc_from, 8, 1, 1 << 20, "sparse, descriptors: the pairs per sort record of a batch from which on the following batches use them (sparse_desc = 0)") \
     X(sparse_parts_target, 0, 0, 1 << 30, "sparse, owner bands: words of one k_sx_consume part (0: four LDS rounds' worth at least, 1/1024 of the batch's words; tests: several parts a band on small inputs)") \
@@ -157,9 +158,10 @@ struct SxScratch {
     DevBuf<unsigned char> d_part;                        // the windows and part records of every group in presorted order
     DevBuf<uint32_t> d_ulist2, d_subcnt, d_suboff, d_subcur;  // blocks form: the stream split by sub-band, words / start / cursor per (band, sub-band)
     DevBuf<uint32_t> d_dsubcnt, d_dsuboff, d_dsubcur;         //              the same for the descriptor records
+    DevBuf<uint32_t> d_cols;                                  // descriptors: the entries' column array (2 or 4 bytes an entry)
     void release() {
         d_ulist2.release(); d_subcnt.release(); d_suboff.release(); d_subcur.release();
-        d_dsubcnt.release(); d_dsuboff.release(); d_dsubcur.release();
+        d_dsubcnt.release(); d_dsuboff.release(); d_dsubcur.release(); d_cols.release();
         d_group_of.release(); d_group_head.release(); d_winp.release(); d_part.release();
         for (auto& k : d_keys) k.release();
         d_blockhist.release(); d_totals.release(); d_tile_ent.release(); d_ebase.release(); d_Pk.release(); d_Tk.release();

@@ -443,6 +443,15 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     }
     // entries in the packed format (4 + 2 + 2 bytes) when sequence ids, multiplicities and ranks fit 16 bits
     const bool packed = e->N < 65535 && e->maxW < 65536u && !e->tune.sparse_unpacked;
+    // descriptors: the entries' column array (what the partners are read from: 2 bytes when N < 32768, else 4)
+    // (col16 = bits of a sequence id << 1 | two-byte columns: what is left of the 16 or 32 bits holds the multiplicity)
+    const int colbits = std::max(1, sx_bits_below((u64)e->N));
+    const int col16 = (colbits << 1) | (e->N < 32768 && e->tune.sparse_desc_cols == 3 ? 1 : 0);
+    void* colp = nullptr;
+    if (desc && (e->tune.sparse_desc_cols >= 2 || (e->tune.sparse_desc_cols == 1 && !packed))) {
+        FSK_HIP(S.d_cols.reserve((col16 & 1) ? (nrec + 1) / 2 : nrec));
+        colp = (void*)S.d_cols.p;
+    }
     if (blocks) {
         // ---- the two-level form (fsk_sparse_blocks.inc): passes over disjoint row ranges, each sized exactly (a pass is
         // milliseconds of work: the wait for its word count does not show). A range that does not fit one pass — more cells
@@ -497,13 +506,13 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                            (const int*)S.d_tile_rs.p, reinterpret_cast<uint32_t*>(S.d_E.p), reinterpret_cast<uint16_t*>(S.d_Pk.p), P.t, Op,
                            S.d_ucount.p, (uint32_t)ra, (uint32_t)rb, e->maxW, maxprod_p, cmax_p, S.d_tile_stat.p, skip_from,
                            skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr,
-                           skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr, P.own_base, short_max, desc, P.sub_shift);
+                           skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr, P.own_base, short_max, desc, P.sub_shift, colp, col16);
             } else {
                 auto k_seg = skipping ? fsk::k_sx_seg_write<RecT, false, false, true> : fsk::k_sx_seg_write<RecT, false, false, false>;
                 FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)S.d_ebase.p,
                            (const int*)S.d_tile_rs.p, S.d_E.p, S.d_Pk.p, P.t, Op, S.d_ucount.p, (uint32_t)ra, (uint32_t)rb, e->maxW, maxprod_p,
                            cmax_p, S.d_tile_stat.p, skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr,
-                           skipping ? S.d_Tk.p : (uint32_t*)nullptr, P.own_base, short_max, desc, P.sub_shift);
+                           skipping ? S.d_Tk.p : (uint32_t*)nullptr, P.own_base, short_max, desc, P.sub_shift, colp, col16);
             }
             const uint32_t OCp = desc ? 2u * Op : Op, wcol = desc ? Op : 0u;  // (columns: descriptor streams first, then the words')
             FSK_LAUNCH(fsk::k_sx_ucol_sum, dim3(nchunks), dim3(256), 0, stream, (const uint32_t*)S.d_ucount.p, ntiles, OCp, S.d_uchunk.p,
@@ -591,7 +600,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                 FSK_LAUNCH(k_cs, dim3(P.submax, Op), dim3(P.sub_shift <= 13 ? 512u : 1024u), lds_sub, stream, (const uint32_t*)S.d_ulist2.p,
                            (const uint32_t*)S.d_suboff.p, (const uint32_t*)S.d_subcnt.p, (const uint32_t*)e->d_blk_r0.p, P.pb, P.sub_shift, P.submax, K,
                            desc ? reinterpret_cast<const uint4*>(S.d_ulist2.p) : (const uint4*)nullptr, (const uint32_t*)S.d_dsuboff.p,
-                           (const uint32_t*)S.d_dsubcnt.p, (const void*)S.d_E.p, packed ? 1 : 0);
+                           (const uint32_t*)S.d_dsubcnt.p, (const void*)S.d_E.p, packed ? 1 : 0, (const void*)colp, col16);
             }
             e->st.launches += 6;
             FSK_HIP(hipStreamSynchronize(stream));  // (the next pass overwrites the band table, the entries' unit marks and the streams)
@@ -616,14 +625,14 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                    (const int*)S.d_tile_rs.p, reinterpret_cast<uint32_t*>(S.d_E.p), reinterpret_cast<uint16_t*>(S.d_Pk.p), e->sx_own_shift, O,
                    lists ? S.d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, S.d_tile_stat.p,
                    skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr,
-                   skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr, 0u, short_max, desc, 0);
+                   skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr, 0u, short_max, desc, 0, colp, col16);
     } else {
         auto k_seg = skipping ? (pairs ? fsk::k_sx_seg_write<RecT, false, true, true> : fsk::k_sx_seg_write<RecT, false, false, true>)
                               : (pairs ? fsk::k_sx_seg_write<RecT, false, true, false> : fsk::k_sx_seg_write<RecT, false, false, false>);
         FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)S.d_ebase.p,
                    (const int*)S.d_tile_rs.p, S.d_E.p, S.d_Pk.p, e->sx_own_shift, O,
                    lists ? S.d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, S.d_tile_stat.p,
-                   skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr, skipping ? S.d_Tk.p : (uint32_t*)nullptr, 0u, short_max, desc, 0);
+                   skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr, skipping ? S.d_Tk.p : (uint32_t*)nullptr, 0u, short_max, desc, 0, colp, col16);
     }
     stat_pin[0] = stat_pin[1] = 0;
     e->st.launches += 3;
@@ -696,12 +705,12 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                     FSK_LAUNCH(k_cs16, dim3(O, e->sx_rounds_slot, nb), dim3(fsk::CS_THREADS), lds_slot, stream, (const uint32_t*)S.d_ulist.p,
                                (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)nullptr, O, target,
                                e->sx_cap_slot, e->sx_pb, K, (const uint32_t*)S.d_ucount.p, tpg, slot_stride, (const u64*)S.d_sxstat.p, cap_words,
-                               e->sx_ovf_now, pairs, desc, Ep, packed ? 1 : 0);
+                               e->sx_ovf_now, pairs, desc, Ep, packed ? 1 : 0, (const void*)colp, col16);
                 } else {
                     FSK_LAUNCH(fsk::k_sx_consume<true>, dim3(O, e->sx_rounds_slot, nb), dim3(fsk::CS_THREADS), lds_slot, stream, (const uint32_t*)S.d_ulist.p,
                                (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)nullptr, O, target,
                                e->sx_cap_slot, e->sx_pb, K, (const uint32_t*)S.d_ucount.p, tpg, slot_stride, (const u64*)S.d_sxstat.p, cap_words,
-                               (uint32_t*)nullptr, pairs, desc, Ep, packed ? 1 : 0);
+                               (uint32_t*)nullptr, pairs, desc, Ep, packed ? 1 : 0, (const void*)colp, col16);
                 }
             } else {
                 FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, stream, (const uint32_t*)S.d_list_off.p, O, target, S.d_part_base.p,
@@ -709,7 +718,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                 FSK_LAUNCH(fsk::k_sx_consume<false>, dim3(max_parts, e->sx_rounds), dim3(fsk::CS_THREADS), lds, stream, (const uint32_t*)S.d_ulist.p,
                            (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)S.d_part_base.p, O, target,
                            e->sx_cap, e->sx_pb, K, (const uint32_t*)nullptr, tpg, (u64)0, (const u64*)S.d_sxstat.p, cap_words, (uint32_t*)nullptr, pairs,
-                           desc, Ep, packed ? 1 : 0);
+                           desc, Ep, packed ? 1 : 0, (const void*)colp, col16);
                 e->st.launches += 1;
             }
             e->st.launches += 2;

@@ -1141,12 +1141,13 @@ def test_emu_sparse_descriptors(emu_lib, port, monkeypatch, skip, desc_min):
 
 
 @pytest.mark.parametrize("name", ["f6_prot219_skipvar16", "f3_lowcomplexity_g5m2", "f5_prot11_variance_T1_it9", "f4_ep300_variance_T1"])
-@pytest.mark.parametrize("unpacked", ["0", "1"])
-def test_emu_sparse_descriptors_forced_on_the_goldens(emu_lib, monkeypatch, name, unpacked):
+@pytest.mark.parametrize("unpacked,cols", [("0", "3"), ("1", "1"), ("0", "2"), ("0", "1"), ("1", "0")])
+def test_emu_sparse_descriptors_forced_on_the_goldens(emu_lib, monkeypatch, name, unpacked, cols):
     """tuning sparse_desc=1 with every entry above two partners as a descriptor, on the golden vectors: exact, skip-variance and
     variance mode (the by-slot form of k_sx_consume: a slot's descriptors are a contiguous piece of every band's descriptor
-    stream), both entry formats."""
-    set_tuning_env(monkeypatch, sparse_desc="1", sparse_desc_min="2", sparse_unpacked=unpacked)
+    stream), both entry formats; the partners read from the 2-byte and the 4-byte column array (an entry of multiplicity above 1:
+    from the entries themselves) and from the entries alone (tuning sparse_desc_cols)."""
+    set_tuning_env(monkeypatch, sparse_desc="1", sparse_desc_min="2", sparse_unpacked=unpacked, sparse_desc_cols=cols)
     d = load_golden(name)
     e = run_case(emu_lib, d, 2)
     st = e.stats()

@@ -88,7 +88,7 @@ def run(name, n_combos=0, tuning=None, reps=2, lib=None):
                 U_per_combo=int(U), algorithmic_GB_per_combo=round(alg / 1e9, 3),
                 algorithmic_GBs=round(alg / 1e9 / per, 1), frac_of_hbm_peak=round(alg / 1e9 / per / HBM_PEAK_GBS, 4),
                 atomic_added_GBs=round(8.0 * U / 1e9 / per, 1), frac_of_atomic_ceiling=round(8.0 * U / 1e9 / per / ATOMIC_CEILING_GBS, 3),
-                path_used="dense" if st["path_used"] == 1 else "sparse", sparse_form=form,
+                path_used="dense" if st["path_used"] == 1 else "sparse", sparse_form=form, descriptors=bool(st["sparse_desc"]),
                 batches_redone=st["batches_redone"], passes=int(st["sparse_passes"]), full_kernel_seconds_estimate=round(per * nc, 2),
                 ms={k: round(st[k] / reps_total, 2) for k in ("ms_extract", "ms_sort", "ms_segment", "ms_pairs", "ms_total")},
                 digest=format(dg[0], "x") + "." + format(dg[1], "x"))
