@@ -117,7 +117,7 @@ using fsk_detail::DevBuf;
     X(sparse_desc_blocks, 1, 0, 1, "sparse, two-level blocks: 0 = never descriptors there (1: as sparse_desc says — one record per sub-band an entry's partners fall into)") \
     X(sparse_desc_cols, 1, 0, 3, "sparse, descriptors: where the partners are read from — 0 = the entries themselves; 1 = a column array (sequence id | multiplicity, 4 bytes) beside 8-byte entries, the entries themselves when they are packed (measured: 2-byte columns beside packed entries are no faster, 0.88 against 0.84 s in the large-g regime; 4-byte columns beside 8-byte entries 4.69 -> 4.44 ms a combo at N = 100k); tests: 2 = 4-byte columns always, 3 = 2-byte columns when N < 32768") \
     X(sparse_desc_min, 16, 1, 48, "sparse, descriptors: entries of more partners than this become descriptors (48: everything k_sx_emit does not bin in LDS; measured, large-g regime: 48 0.92 s, 32 0.85, 16 0.83-0.85, 8 0.88, 4 0.90)") \
-    X(sparse_desc_from, 8, 1, 1 << 20, "sparse, descriptors: the pairs per sort record of a batch from which on the following batches use them (sparse_desc = 0)") \
+    X(sparse_desc_from, 12, 1, 1 << 20, "sparse, descriptors: the pairs per sort record of a batch from which on the following batches use them (sparse_desc = 0)") \
     X(sparse_parts_target, 0, 0, 1 << 30, "sparse, owner bands: words of one k_sx_consume part (0: four LDS rounds' worth at least, 1/1024 of the batch's words; tests: several parts a band on small inputs)") \
     X(sparse_desc_parts, 2048, 1, 1 << 16, "sparse, descriptors: parts (k_sx_consume workgroups) the bands' streams are cut into, about") \
     X(sparse_share, 0, -1, 254, "sparse: leading kept positions sorted once per group of consecutive combos that share them (0: by cost; -1: never); batches of more than 16 slots only (smaller ones read their positions by id), and never when the presort's scratch passes a quarter of the free memory") \

@@ -501,14 +501,16 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             u64* const pin = stat_pin;
             pin[0] = pin[1] = 0;
             if (packed) {
-                auto k_seg = skipping ? fsk::k_sx_seg_write<RecT, true, false, true> : fsk::k_sx_seg_write<RecT, true, false, false>;
+                auto k_seg = desc ? (skipping ? fsk::k_sx_seg_write<RecT, true, false, true, true> : fsk::k_sx_seg_write<RecT, true, false, false, true>)
+                                  : (skipping ? fsk::k_sx_seg_write<RecT, true, false, true> : fsk::k_sx_seg_write<RecT, true, false, false>);
                 FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)S.d_ebase.p,
                            (const int*)S.d_tile_rs.p, reinterpret_cast<uint32_t*>(S.d_E.p), reinterpret_cast<uint16_t*>(S.d_Pk.p), P.t, Op,
                            S.d_ucount.p, (uint32_t)ra, (uint32_t)rb, e->maxW, maxprod_p, cmax_p, S.d_tile_stat.p, skip_from,
                            skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr,
                            skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr, P.own_base, short_max, desc, P.sub_shift, colp, col16);
             } else {
-                auto k_seg = skipping ? fsk::k_sx_seg_write<RecT, false, false, true> : fsk::k_sx_seg_write<RecT, false, false, false>;
+                auto k_seg = desc ? (skipping ? fsk::k_sx_seg_write<RecT, false, false, true, true> : fsk::k_sx_seg_write<RecT, false, false, false, true>)
+                                  : (skipping ? fsk::k_sx_seg_write<RecT, false, false, true> : fsk::k_sx_seg_write<RecT, false, false, false>);
                 FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)S.d_ebase.p,
                            (const int*)S.d_tile_rs.p, S.d_E.p, S.d_Pk.p, P.t, Op, S.d_ucount.p, (uint32_t)ra, (uint32_t)rb, e->maxW, maxprod_p,
                            cmax_p, S.d_tile_stat.p, skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr,
@@ -547,7 +549,8 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             FSK_HIP(hipMemsetAsync(S.d_subcnt.p, 0, nsub * sizeof(uint32_t), stream));
             if (k_wait) { FSK_HIP(hipStreamWaitEvent(stream, k_wait, 0)); k_wait = nullptr; }
             if (packed) {
-                auto k_emit = skipping ? fsk::k_sx_emit<false, true, true> : fsk::k_sx_emit<false, false, true>;
+                auto k_emit = desc ? (skipping ? fsk::k_sx_emit<false, true, true, true> : fsk::k_sx_emit<false, false, true, true>)
+                                   : (skipping ? fsk::k_sx_emit<false, true, true> : fsk::k_sx_emit<false, false, true>);
                 FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, reinterpret_cast<const uint32_t*>(S.d_E.p),
                            reinterpret_cast<const uint16_t*>(S.d_Pk.p), (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_blk_r0.p, P.t, Op,
                            (const uint32_t*)S.d_list_off.p, (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)ra, (uint32_t)rb, e->maxW,
@@ -555,7 +558,8 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                            skipping ? reinterpret_cast<const uint16_t*>(S.d_Tk.p) : (const uint16_t*)nullptr, (const u64*)S.d_sxstat.p, ~(u64)0,
                            ntiles, 0, P.own_base, short_max, desc, P.sub_shift);
             } else {
-                auto k_emit = skipping ? fsk::k_sx_emit<false, true, false> : fsk::k_sx_emit<false, false, false>;
+                auto k_emit = desc ? (skipping ? fsk::k_sx_emit<false, true, false, true> : fsk::k_sx_emit<false, false, false, true>)
+                                   : (skipping ? fsk::k_sx_emit<false, true, false> : fsk::k_sx_emit<false, false, false>);
                 FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, (const uint2*)S.d_E.p, (const uint32_t*)S.d_Pk.p,
                            (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_blk_r0.p, P.t, Op, (const uint32_t*)S.d_list_off.p,
                            (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)ra, (uint32_t)rb, e->maxW, maxprod_p, cmax_p, P.pb, K, tpg, (u64)0,
@@ -619,16 +623,20 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
         return FSK_OK;
     }
     if (packed) {
-        auto k_seg = skipping ? (pairs ? fsk::k_sx_seg_write<RecT, true, true, true> : fsk::k_sx_seg_write<RecT, true, false, true>)
-                              : (pairs ? fsk::k_sx_seg_write<RecT, true, true, false> : fsk::k_sx_seg_write<RecT, true, false, false>);
+        auto k_seg = desc ? (skipping ? (pairs ? fsk::k_sx_seg_write<RecT, true, true, true, true> : fsk::k_sx_seg_write<RecT, true, false, true, true>)
+                                      : (pairs ? fsk::k_sx_seg_write<RecT, true, true, false, true> : fsk::k_sx_seg_write<RecT, true, false, false, true>))
+                          : (skipping ? (pairs ? fsk::k_sx_seg_write<RecT, true, true, true> : fsk::k_sx_seg_write<RecT, true, false, true>)
+                                      : (pairs ? fsk::k_sx_seg_write<RecT, true, true, false> : fsk::k_sx_seg_write<RecT, true, false, false>));
         FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)S.d_ebase.p,
                    (const int*)S.d_tile_rs.p, reinterpret_cast<uint32_t*>(S.d_E.p), reinterpret_cast<uint16_t*>(S.d_Pk.p), e->sx_own_shift, O,
                    lists ? S.d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, S.d_tile_stat.p,
                    skip_from, skipping ? (const int*)S.d_tile_ts.p : (const int*)nullptr,
                    skipping ? reinterpret_cast<uint16_t*>(S.d_Tk.p) : (uint16_t*)nullptr, 0u, short_max, desc, 0, colp, col16);
     } else {
-        auto k_seg = skipping ? (pairs ? fsk::k_sx_seg_write<RecT, false, true, true> : fsk::k_sx_seg_write<RecT, false, false, true>)
-                              : (pairs ? fsk::k_sx_seg_write<RecT, false, true, false> : fsk::k_sx_seg_write<RecT, false, false, false>);
+        auto k_seg = desc ? (skipping ? (pairs ? fsk::k_sx_seg_write<RecT, false, true, true, true> : fsk::k_sx_seg_write<RecT, false, false, true, true>)
+                                      : (pairs ? fsk::k_sx_seg_write<RecT, false, true, false, true> : fsk::k_sx_seg_write<RecT, false, false, false, true>))
+                          : (skipping ? (pairs ? fsk::k_sx_seg_write<RecT, false, true, true> : fsk::k_sx_seg_write<RecT, false, false, true>)
+                                      : (pairs ? fsk::k_sx_seg_write<RecT, false, true, false> : fsk::k_sx_seg_write<RecT, false, false, false>));
         FSK_LAUNCH(k_seg, dim3(tpg, nb), dim3(256), 0, stream, (const RecT*)rec[cur], nfeat, tpg, sb, (const uint32_t*)S.d_ebase.p,
                    (const int*)S.d_tile_rs.p, S.d_E.p, S.d_Pk.p, e->sx_own_shift, O,
                    lists ? S.d_ucount.p : (uint32_t*)nullptr, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, S.d_tile_stat.p,
@@ -671,14 +679,16 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                 FSK_HIP(S.d_ulist.reserve((size_t)std::max<u64>(1, words + words / 4)));
             // (function pointers: a template-id with a comma cannot pass through the launch macro)
             if (packed) {
-                auto k_emit = skipping ? fsk::k_sx_emit<false, true, true> : fsk::k_sx_emit<false, false, true>;
+                auto k_emit = desc ? (skipping ? fsk::k_sx_emit<false, true, true, true> : fsk::k_sx_emit<false, false, true, true>)
+                                   : (skipping ? fsk::k_sx_emit<false, true, true> : fsk::k_sx_emit<false, false, true>);
                 FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, reinterpret_cast<const uint32_t*>(S.d_E.p),
                            reinterpret_cast<const uint16_t*>(S.d_Pk.p), (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p,
                            e->sx_own_shift, O, (const uint32_t*)S.d_list_off.p, (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)row0,
                            (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg, slot_stride,
                            skipping ? reinterpret_cast<const uint16_t*>(S.d_Tk.p) : (const uint16_t*)nullptr, (const u64*)S.d_sxstat.p, cap_words, ntiles, pairs, 0u, short_max, desc, 0);
             } else {
-                auto k_emit = skipping ? fsk::k_sx_emit<false, true, false> : fsk::k_sx_emit<false, false, false>;
+                auto k_emit = desc ? (skipping ? fsk::k_sx_emit<false, true, false, true> : fsk::k_sx_emit<false, false, false, true>)
+                                   : (skipping ? fsk::k_sx_emit<false, true, false> : fsk::k_sx_emit<false, false, false>);
                 FSK_LAUNCH(k_emit, dim3(fsk::xcd_grid(ntiles)), dim3(fsk::EM_THREADS), 0, stream, (const uint2*)S.d_E.p, (const uint32_t*)S.d_Pk.p,
                            (const uint32_t*)S.d_ebase.p, (const uint32_t*)e->d_owner_r0.p, e->sx_own_shift, O, (const uint32_t*)S.d_list_off.p,
                            (const uint32_t*)S.d_ucount.p, S.d_ulist.p, (uint32_t)row0, (uint32_t)row1, e->maxW, maxprod, cmax, e->sx_pb, K, tpg,
@@ -696,7 +706,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
             const uint32_t desc_parts = (uint32_t)std::max<int64_t>(1, e->tune.sparse_desc_parts);
             const uint32_t max_parts = desc ? O + desc_parts + 9u : O + (uint32_t)(((guarded ? guard_cap : words) + target - 1) / target);
             const void* const Ep = (const void*)S.d_E.p;
-            if (slot_stride == 0) FSK_HIP(S.d_part_base.reserve((size_t)O + 2 + max_parts));  // (bases, total, target, then the band of every part)
+            if (slot_stride == 0) FSK_HIP(S.d_part_base.reserve((size_t)O + 8 + (size_t)4 * max_parts));  // (bases, total, target, then 16 bytes a part)
             if (k_wait) FSK_HIP(hipStreamWaitEvent(stream, k_wait, 0));
             if (slot_stride != 0) {  // one triangle per slot: a slot's words of a stream are one contiguous piece
                 if (slot16) {
@@ -714,7 +724,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                 }
             } else {
                 FSK_LAUNCH(fsk::k_sx_parts, dim3(1), dim3(512), 0, stream, (const uint32_t*)S.d_list_off.p, O, target, S.d_part_base.p,
-                           (const u64*)S.d_sxstat.p, cap_words, desc, S.d_part_base.p + O + 2, max_parts, desc_parts);
+                           (const u64*)S.d_sxstat.p, cap_words, desc, S.d_part_base.p + ((O + 2 + 3) & ~3u), max_parts, desc_parts);
                 FSK_LAUNCH(fsk::k_sx_consume<false>, dim3(max_parts, e->sx_rounds), dim3(fsk::CS_THREADS), lds, stream, (const uint32_t*)S.d_ulist.p,
                            (const uint32_t*)S.d_list_off.p, (const uint32_t*)e->d_owner_r0.p, (const uint32_t*)S.d_part_base.p, O, target,
                            e->sx_cap, e->sx_pb, K, (const uint32_t*)nullptr, tpg, (u64)0, (const u64*)S.d_sxstat.p, cap_words, (uint32_t*)nullptr, pairs,
