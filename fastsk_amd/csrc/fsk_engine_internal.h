@@ -113,7 +113,7 @@ using fsk_detail::DevBuf;
     X(blocks_band_shift_max, 23, 4, 23, "sparse, blocks: log2 of a band's cells at most (tests)")                                    \
     X(blocks_scatter_threads, 0, 0, 1024, "sparse, blocks: threads of a k_sxb_scatter workgroup, 256 / 512 / 1024 (0: 256)")          \
     X(blocks_pass_words, 0, 0, (int64_t)1 << 32, "sparse, blocks: update words of one pass at most (0: 2^31)")                       \
-    X(sparse_desc, 0, -1, 1, "sparse, owner bands: entries of many partners leave k_sx_emit as ONE descriptor each that k_sx_consume expands in LDS — 1 = always, -1 = never (0: once a batch of these sequences has shown sparse_desc_from pairs per record)") \
+    X(sparse_desc, 0, -1, 1, "sparse, owner bands and two-level blocks: entries of many partners leave k_sx_emit as descriptors (one an entry; blocks: one per sub-band its partners fall into) that k_sx_consume / k_sxb_consume expand in LDS — 1 = always, -1 = never (0: once a batch of these sequences has shown sparse_desc_from pairs per record)") \
     X(sparse_desc_blocks, 1, 0, 1, "sparse, two-level blocks: 0 = never descriptors there (1: as sparse_desc says — one record per sub-band an entry's partners fall into)") \
     X(sparse_desc_cols, 1, 0, 3, "sparse, descriptors: where the partners are read from — 0 = the entries themselves; 1 = a column array (sequence id | multiplicity, 4 bytes) beside 8-byte entries, the entries themselves when they are packed (measured: 2-byte columns beside packed entries are no faster, 0.88 against 0.84 s in the large-g regime; 4-byte columns beside 8-byte entries 4.69 -> 4.44 ms a combo at N = 100k); tests: 2 = 4-byte columns always, 3 = 2-byte columns when N < 32768") \
     X(sparse_desc_min, 16, 1, 48, "sparse, descriptors: entries of more partners than this become descriptors (48: everything k_sx_emit does not bin in LDS; measured, large-g regime: 48 0.92 s, 32 0.85, 16 0.83-0.85, 8 0.88, 4 0.90)") \

@@ -98,10 +98,15 @@ def main():
                              "correction) + WRITE_SIZE KiB x1024, one fsk_compute of all 1001 combos" % TAG},
                   open(os.path.join(DST, "traffic_config4.json"), "w"), indent=1)
     for src, dst in (("sparse_large_n.jsonl", TAG + "_sparse_large_n.jsonl"), ("sparse_mid_n.jsonl", TAG + "_sparse_mid_n_bands_vs_blocks.jsonl"),
+                     ("sparse_large_n_no_desc.jsonl", TAG + "_sparse_large_n_word_streams_only.jsonl"), ("sparse_mid_n_dna_k8.jsonl", TAG + "_sparse_mid_n_dna_k8_bands_vs_blocks.jsonl"),
+                     ("desc_ab.txt", TAG + "_descriptors_ab.txt"), ("kernel_times_large_g.txt", TAG + "_kernel_times_large_g.txt"),
                      ("dropin_wall.json", TAG + "_dropin_wall.json"), ("ubench_sparse_ops.txt", TAG + "_ubench_sparse_ops.txt"),
                      ("ubench_rmw.txt", TAG + "_ubench_rmw_shapes.txt")):
         if os.path.exists(os.path.join(SRC, src)) and os.path.getsize(os.path.join(SRC, src)) > 0:
             shutil.copy(os.path.join(SRC, src), os.path.join(DST, dst))
+    lg = os.path.join(ROOT, "gpurun_out", "pmc", TAG + "_large_g16", "summary.json")
+    if os.path.exists(lg):
+        shutil.copy(lg, os.path.join(DST, TAG + "_pmc_sparse_large_g16.json"))
     b64 = os.path.join(ROOT, "gpurun_out", "pmc", TAG + "_blocks64k", "summary.json")
     if os.path.exists(b64):
         shutil.copy(b64, os.path.join(DST, TAG + "_pmc_sparse_blocks_64k.json"))

@@ -25,6 +25,13 @@ done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_configs" -- python3 "$R/tools/bench_configs.py" > /dev/null 2> "$O/stats_configs.err"
 cd "$R" && python3 tools/bench_configs.py > "$O/configs.jsonl" 2> "$O/configs.err"
 python3 tools/bench_large_g.py > "$O/large_g.jsonl" 2> "$O/large_g.err"
+# round 6: the descriptors — large-g kernel times and counters, the A/B against the word streams (large-g, configs 1 and 4), large N without them
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_large_g" -- python3 "$R/tools/bench_large_g.py" 20,14 > "$O/stats_large_g.out" 2>&1)
+python3 tools/kstats.py "$O/stats_large_g" > "$O/kernel_times_large_g.txt" 2>&1
+tools/pmc_passes.sh ${TAG}_large_g16 "$R/tools/bench_large_g.py" 16,10 > "$O/pmc_large_g16.log" 2>&1
+python3 tools/ab_env.py large_g,f7_cfg1_prot11_approx_t1,f7_cfg4_prot219_exact "sparse_desc=-1" "sparse_desc=1" "sparse_desc_min=48" "sparse_desc_cols=3" > "$O/desc_ab.txt" 2>&1
+python3 tools/bench_sparse_large_n.py --combos 20 --tuning sparse_desc=-1 > "$O/sparse_large_n_no_desc.jsonl" 2>> "$O/sparse_large_n.err"
+for f in 1 2; do python3 tools/bench_sparse_large_n.py --only dna_k8_6k,dna_k8_8k,dna_k8_12k,dna_k8_16k --combos 20 --tuning sparse_form=$f,sparse_desc=1; done > "$O/sparse_mid_n_dna_k8.jsonl" 2>> "$O/sparse_large_n.err"
 tools/pmc_passes.sh ${TAG}_cfg1 "$R/tools/profile_one.py" f7_cfg1_prot11_approx_t1 > "$O/pmc_cfg1.log" 2>&1
 tools/bench_n_series.sh > /dev/null 2>&1; cp "$R/gpurun_out/n_series.jsonl" "$O/n_series.jsonl"
 [ -x tools/ubench_mfma_i8 ] && tools/ubench_mfma_i8 > "$O/ubench_mfma_i8.txt" 2>&1
