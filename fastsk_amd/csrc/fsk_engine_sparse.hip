@@ -262,7 +262,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     FSK_HIP(S.d_tile_lrh.reserve(ntiles));
     FSK_HIP(S.d_tile_rs.reserve(ntiles));
     FSK_HIP(S.d_ebase.reserve((size_t)ntiles + 1));
-    FSK_HIP(S.d_E.reserve(nrec));
+    FSK_HIP(S.d_E.reserve(nrec + 2));  // (+ 16 bytes: the descriptors' partners are read in whole 16-byte pieces)
     FSK_HIP(S.d_Pk.reserve(nrec));
     // skip_test_block: test rows pair only with the train entries of their runs (and themselves)
     const uint32_t skip_from = e->cfg.skip_test_block && e->n_test > 0 ? (uint32_t)e->n_train : 0xffffffffu;
@@ -449,7 +449,7 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
     const int col16 = (colbits << 1) | (e->N < 32768 && e->tune.sparse_desc_cols == 3 ? 1 : 0);
     void* colp = nullptr;
     if (desc && (e->tune.sparse_desc_cols >= 2 || (e->tune.sparse_desc_cols == 1 && !packed))) {
-        FSK_HIP(S.d_cols.reserve((col16 & 1) ? (nrec + 1) / 2 : nrec));
+        FSK_HIP(S.d_cols.reserve(((col16 & 1) ? (nrec + 1) / 2 : nrec) + 4));  // (+ 16 bytes: a lane's last load reads whole 16-byte pieces)
         colp = (void*)S.d_cols.p;
     }
     if (blocks) {
@@ -490,6 +490,16 @@ int sparse_batch(fsk_engine* e, const int32_t* combos, int nb, u64* K, int64_t r
                 continue;
             }
             const uint32_t Op = P.n_owners;
+            {   // (a pass of ONE row longer than blocks_max_bands bands cover has more bands than that — up to SX_MAX_OWNERS —: the
+                // count matrix and the offsets by this pass's own bands; found by tools/stress_parity.py's blocks cases as a
+                // memory fault at N = 6500 with seven bands of 2^9 cells a pass. The previous pass has been waited for.)
+                const size_t cols = (size_t)(desc ? 2u : 1u) * std::max(Op, O);
+                FSK_HIP(S.d_ucount.reserve(cols * ntiles));
+                FSK_HIP(S.d_uchunk.reserve(cols * nchunks));
+                FSK_HIP(S.d_utot.reserve(cols));
+                FSK_HIP(S.d_list_off.reserve(cols + 1));
+                FSK_HIP(S.d_part_base.reserve((size_t)std::max(Op, O) + 2));
+            }
             FSK_HIP(e->d_blk_r0.reserve((size_t)fsk::SX_MAX_OWNERS + 1));
             // (the previous pass has been waited for: nothing reads the table any more)
             FSK_HIP(hipMemcpy(e->d_blk_r0.p, P.r0.data(), P.r0.size() * sizeof(uint32_t), hipMemcpyHostToDevice));

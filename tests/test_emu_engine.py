@@ -1074,13 +1074,20 @@ def test_emu_sparse_two_level_blocks(emu_lib, port, skip, desc):
     plans = [(X1, 4, 2, np.arange(4, dtype=np.int32), {"sparse_form": 2}, "whole"),
              (X1, 4, 2, np.arange(4, dtype=np.int32), {"sparse_form": 2, "blocks_sub_shift": 6, "blocks_max_bands": 5, "blocks_band_shift_max": 9}, "row bands"),
              (X2, 5, 2, np.array([0, 9], dtype=np.int32), {"sparse_form": 2, "blocks_sub_shift": 5, "blocks_max_bands": 12, "blocks_band_shift_max": 8,
-                                                           "blocks_pass_words": 30000, "sparse_unpacked": 1}, "two calls")]
+                                                           "blocks_pass_words": 30000, "sparse_unpacked": 1}, "two calls"),
+             # (two bands of 2^5 cells a pass: the rows beyond 64 sequences are passes of ONE row with more bands than blocks_max_bands)
+             (X1[:100], 4, 2, np.arange(1, dtype=np.int32), {"sparse_form": 2, "blocks_sub_shift": 4, "blocks_max_bands": 2, "blocks_band_shift_max": 5}, "whole")]
+    if skip:
+        plans.pop()
     for X, g, m, combos, tun, how in plans:
         tokens, offsets = _native.flatten(X)
         raw, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=4)
+        if len(X) != N:  # (the plan on the first hundred sequences)
+            a, b = np.tril_indices(len(X))
+            keep = np.ones(len(a), dtype=bool)
         tun = dict(tun, sparse_desc=1, sparse_desc_min=3) if desc else dict(tun, sparse_desc=-1)
         e = _native.Engine(g, m, path=2, lib=emu_lib, skip_test_block=skip, tuning=tun)
-        e.load_sequences(tokens, offsets, ntr if skip else N, N - ntr if skip else 0)
+        e.load_sequences(tokens, offsets, ntr if skip else len(X), N - ntr if skip else 0)
         if how == "whole":
             e.accumulate(combos)
         elif how == "two calls":

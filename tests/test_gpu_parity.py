@@ -636,6 +636,8 @@ def test_sparse_two_level_blocks_forced_small(native, port):
                     {"sparse_form": 2, "blocks_sub_shift": 8, "blocks_max_bands": 7, "blocks_band_shift_max": 12},
                     {"sparse_form": 2, "blocks_sub_shift": 10, "blocks_max_bands": 64, "blocks_band_shift_max": 13, "blocks_pass_words": 400000,
                      "sparse_unpacked": 1},
+                    # (passes of ONE row with more bands than blocks_max_bands: rows beyond 256 sequences at two bands of 2^7 cells a pass)
+                    {"sparse_form": 2, "blocks_sub_shift": 6, "blocks_max_bands": 2, "blocks_band_shift_max": 7, "sparse_desc": 1, "sparse_desc_min": 7},
                     {"sparse_form": 2, "sparse_desc": 1, "sparse_desc_min": 3},
                     {"sparse_form": 2, "blocks_sub_shift": 8, "blocks_max_bands": 7, "blocks_band_shift_max": 12, "sparse_desc": 1},
                     {"sparse_form": 2, "blocks_sub_shift": 10, "blocks_max_bands": 64, "blocks_band_shift_max": 13, "blocks_pass_words": 400000,

@@ -42,7 +42,8 @@ def main(iters=150, seed=0):
         if os.environ.get("FSK_STRESS_VERBOSE"):  # (a crash loses the buffered line: say what is about to run)
             print("iter %d: sigma=%d g=%d m=%d N=%d Lmax=%d ntr=%d combos=%s" % (it, sigma, g, m, N, hi, ntr, combos.tolist()), flush=True)
         res = {}
-        for name, path, env in (("dense", 1, "0"), ("dense_compact", 1, "1"), ("sparse", 2, "0"), ("sparse_global", 2, "1")):
+        for name, path, env in (("dense", 1, "0"), ("dense_compact", 1, "1"), ("sparse", 2, "0"), ("sparse_global", 2, "1"), ("sparse_desc", 2, "0"),
+                                ("sparse_blocks", 2, "0")):
             if path == 1 and (sigma ** k > 16384 or k > 16):
                 continue
             if name == "dense_compact" and sigma ** k > 4096:
@@ -54,6 +55,29 @@ def main(iters=150, seed=0):
             # the batches of an exact accumulate in two lanes, with batches of a few combos; the unpacked entry format
             if name == "dense_compact":
                 tuning["compact_rare"] = int(rng.integers(0, 2))
+            # descriptors (an entry of more than desc_min partners as one descriptor), forced or never: the owner bands with
+            # several parts a band, the two-level blocks with small blocks (several passes, bands, sub-bands), every partner source
+            if name in ("sparse", "sparse_global"):
+                tuning["sparse_desc"] = -1
+            if name in ("sparse_desc", "sparse_blocks"):
+                tuning["sparse_desc"] = 1 if name == "sparse_desc" else int(rng.choice([-1, 1]))
+                tuning["sparse_desc_min"] = int(rng.choice([1, 2, 5, 16, 48]))
+                tuning["sparse_desc_cols"] = int(rng.integers(0, 4))
+                if rng.random() < 0.5:
+                    tuning["sparse_pairs"] = 0
+                if name == "sparse_desc":
+                    tuning["sparse_form"] = 1
+                    if rng.random() < 0.5:
+                        tuning["sparse_parts_target"] = int(rng.choice([16, 64, 1000]))
+                        tuning["sparse_desc_parts"] = int(rng.choice([1, 64, 4096]))
+                else:
+                    tuning["sparse_form"] = 2
+                    if rng.random() < 0.7:
+                        tuning["blocks_sub_shift"] = int(rng.integers(5, 13))
+                        tuning["blocks_max_bands"] = int(rng.choice([2, 7, 64, 512]))
+                        tuning["blocks_band_shift_max"] = int(rng.integers(max(6, tuning["blocks_sub_shift"]), 16))
+                        if rng.random() < 0.4:
+                            tuning["blocks_pass_words"] = int(rng.choice([5000, 100000]))
             if path == 2 and rng.random() < 0.5:
                 tuning["sparse_exact_lanes"] = 2
                 tuning["sparse_batch_records"] = max(1, int(rng.integers(1, 5)) * int(sum(max(0, int(L) - g + 1) for L in lens)))
@@ -79,7 +103,9 @@ def main(iters=150, seed=0):
             res[name] = (e.get_counts(), e.get_triangle())
             e.close()
         if N - ntr > 0:  # skip_test_block on the sparse dataflow: exactly the test x test cells off the diagonal stay zero
-            e = _native.Engine(g, m, path=2, skip_test_block=True, tuning={"sparse_global": it % 2, "sparse_unpacked": (it // 2) % 2})
+            e = _native.Engine(g, m, path=2, skip_test_block=True, tuning={"sparse_global": it % 2, "sparse_unpacked": (it // 2) % 2,
+                                                                            "sparse_desc": 1 if (it // 4) % 2 else -1, "sparse_desc_min": 1 + it % 7,
+                                                                            "sparse_form": (0, 2)[(it // 8) % 2]})
             e.load_sequences(tokens, offsets, ntr, N - ntr)
             e.accumulate(combos)
             e.finalize()

@@ -44,6 +44,12 @@ def main(iters=200, seed=0):
                 if mode == "sync": tuning["sparse_sync"] = 1
                 if mode == "overflow": tuning["guard_cap"] = int(rng.choice([1, 50, 2000]))
                 if mode == "ungrouped": tuning["list_max_words"] = int(rng.choice([10, 1000]))
+                # descriptors in the by-slot form of k_sx_consume (a slot's descriptors: a contiguous piece of every band's stream)
+                tuning["sparse_desc"] = int(rng.choice([-1, 1, 1]))
+                if tuning["sparse_desc"] == 1:
+                    tuning["sparse_desc_min"] = int(rng.choice([1, 3, 16, 48]))
+                    tuning["sparse_desc_cols"] = int(rng.integers(0, 4))
+                    tuning["sparse_unpacked"] = int(rng.integers(0, 2))
             e = _native.Engine(g, m, t=T, approx=True, delta=delta, max_iters=max_iters, path=path, tuning=tuning)
             e.set_combo_order(order)
             e.compute(tokens, offsets, ntr, N - ntr)
