@@ -1166,3 +1166,37 @@ def test_emu_sparse_descriptors_forced_on_the_goldens(emu_lib, monkeypatch, name
     if d["approx"] and not d["skip_variance"]:
         assert np.array_equal(e.get_stdevs(), d["stdevs"])
     e.close()
+
+
+def test_emu_sparse_descriptors_switch_on_by_the_data(emu_lib, port):
+    """tuning sparse_desc=0 (the default): the first batch of a set of sequences goes out as update words; once it has shown
+    sparse_desc_from pairs a sort record (here: runs of ~60 entries over 16 keys) the batches that follow send descriptors — and
+    forget the words per record seen so far, so the next one is sized exactly, not under the old guard; short runs never switch.
+    A reload of sequences of the same shape keeps the decision (sparse_hint), another shape starts over."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(9)
+    N, g, m = 150, 5, 3
+    long_runs = [rng.integers(1, 5, size=int(L)).astype(np.int32) for L in rng.integers(12, 20, size=N)]
+    short_runs = [rng.integers(1, 21, size=int(L)).astype(np.int32) for L in rng.integers(12, 20, size=N)]
+    combos = np.arange(6, dtype=np.int32)
+    e = _native.Engine(g, m, path=2, lib=emu_lib)
+    for X, want_desc in ((long_runs, [0, 1, 1]), (short_runs, [0, 0, 0])):
+        tokens, offsets = _native.flatten(X)
+        raw, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=4)
+        e.load_sequences(tokens, offsets, N, 0)
+        seen = []
+        for part in np.array_split(combos, 3):
+            e.accumulate(part)
+            e.synchronize()
+            seen.append(int(e.stats()["sparse_desc"]))
+        e.finalize()
+        assert seen == want_desc, seen
+        assert np.array_equal(e.get_counts(), raw)
+    tokens, offsets = _native.flatten(long_runs)
+    e.load_sequences(tokens, offsets, N, 0)   # (another shape than the last one loaded: the decision starts over)
+    e.accumulate(combos[:2])
+    assert int(e.stats()["sparse_desc"]) == 0
+    e.load_sequences(tokens, offsets, N, 0)   # (the same shape again: kept)
+    e.accumulate(combos[:2])
+    assert int(e.stats()["sparse_desc"]) == 1
+    e.close()
