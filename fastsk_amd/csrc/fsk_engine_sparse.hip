@@ -886,8 +886,12 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     // record seen so far on these sequences; while none has been seen, a first batch of at most 2^25 records.
     const size_t nfeat = (size_t)std::max<int64_t>(1, e->nfeat);
     const u64 by_cells = std::max<u64>(1, 0xffffffffull / std::max<u64>(1, (u64)e->maxW * e->maxW));
+    // (owner bands with descriptors: batches of 2^25 records — the entries of a batch, which every descriptor's partners are read
+    // from again and again, then stay in the 256 MB Infinity Cache: large-g regime 0.82 -> 0.795 s; 2^26: 0.805; 2^24: 0.826)
+    // (a call of at least sixteen such batches: g = 12, 924 combos, three batches of 2^27: 0.025 s, nine of 2^25: 0.031)
+    const size_t max_records = e->sx_desc_now() && !blocks_form && slot_stride == 0 && (u64)n * nfeat >= ((u64)1 << 29) ? (size_t)1 << 25 : SPARSE_MAX_RECORDS;
     auto batch_combos = [&](int left) {
-        size_t recs = e->tune.sparse_batch_records ? (size_t)e->tune.sparse_batch_records : SPARSE_MAX_RECORDS;
+        size_t recs = e->tune.sparse_batch_records ? (size_t)e->tune.sparse_batch_records : max_records;
         // (the two-level form takes a batch of any word count in passes, and sweeps K once a batch: as many records as the cap allows)
         if (e->sx_wpr == 0) recs = std::min<size_t>(recs, (size_t)1 << 25);
         else if (!blocks_form) recs = std::min<size_t>(recs, (size_t)std::max(1.0, (double)(e->sx_max_words() / 2) / e->sx_wpr));
@@ -935,7 +939,7 @@ int accumulate_sparse(fsk_engine* e, const int32_t* combos, int n, u64* K, int64
     // fsk_compute starts with one — says nothing about the batches that follow)
     int nb_steady = nb0;
     if (e->sx_wpr == 0) {
-        const size_t recs = e->tune.sparse_batch_records ? (size_t)e->tune.sparse_batch_records : SPARSE_MAX_RECORDS;
+        const size_t recs = e->tune.sparse_batch_records ? (size_t)e->tune.sparse_batch_records : max_records;
         nb_steady = (int)std::max<u64>(1, std::min<u64>({(u64)(recs / nfeat), (u64)n, by_cells, (u64)65535}));
     }
     const bool many = (n + nb_steady - 1) / nb_steady >= 6;
