@@ -1200,3 +1200,25 @@ def test_emu_sparse_descriptors_switch_on_by_the_data(emu_lib, port):
     e.accumulate(combos[:2])
     assert int(e.stats()["sparse_desc"]) == 1
     e.close()
+
+
+def test_emu_sparse_descriptors_two_lds_rounds(emu_lib, port):
+    """Owner bands of TWO LDS rounds (N = 4200: 270 bands of 2^15 cells + a row, 20480 cells a round) with descriptors: every round
+    of k_sx_consume walks the band's descriptors again and keeps the cells of its own range (the round's first cell in
+    sx_expand_descriptors' base); runs of ~100 entries over 400 keys, a low-complexity sequence."""
+    from fastsk_amd import _native
+    rng = np.random.default_rng(3)
+    N, g, m = 4200, 4, 2
+    X = [rng.integers(1, 21, size=int(L)).astype(np.int32) for L in rng.integers(8, 12, size=N)]
+    X[9][:] = 4
+    tokens, offsets = _native.flatten(X)
+    combos = np.array([0, 3], dtype=np.int32)
+    raw, _, U = port.raw_counts(tokens, offsets, g, m, combos, threads=4)
+    e = _native.Engine(g, m, path=2, lib=emu_lib, tuning={"sparse_desc": 1, "sparse_desc_min": 6, "sparse_form": 1})
+    e.load_sequences(tokens, offsets, N, 0)
+    e.accumulate(combos)
+    e.finalize()
+    st = e.stats()
+    assert st["sparse_desc"] == 1 and st["sparse_form"] == 0 and st["cell_updates"] == U
+    assert np.array_equal(e.get_counts(), raw)
+    e.close()

@@ -800,11 +800,11 @@ def test_sparse_paired_unit_words(native, port, monkeypatch, skip):
 def test_sparse_descriptors(native, port, monkeypatch, skip):
     """Descriptors (tuning sparse_desc=1): entries of more partners than k_sx_emit bins leave as ONE descriptor each, which
     k_sx_consume expands in LDS (countAndUpdateTri's += for a whole entry, shared.cpp:316-327). Long runs over 256 keys at
-    N = 4000 (bands of two LDS rounds: every descriptor is walked twice, each round keeping its own cells) and protein-like
+    N = 5000 (bands of two LDS rounds: every descriptor is walked twice, each round keeping its own cells) and protein-like
     data at N = 1500, thresholds 48 / 6 partners, a low-complexity sequence (own cells of multiplicities above 1), in one
     call, in three, in row bands, with skip_test_block: the oracle's counts and U."""
     for X, g, m, combos, desc_mins in (
-            ([np.random.default_rng(40 + i).integers(1, 5, size=26).astype(np.int32) for i in range(4000)], 6, 2, np.arange(0, 15, 5, dtype=np.int32), ("48", "6")),
+            ([np.random.default_rng(40 + i).integers(1, 5, size=26).astype(np.int32) for i in range(5000)], 6, 2, np.arange(0, 15, 5, dtype=np.int32), ("48", "6")),
             (protein_like(1500, 40, 160, seed=33), 10, 6, np.arange(0, 210, 9, dtype=np.int32), ("6",))):
         N, ntr = len(X), (2 * len(X)) // 3
         X[7][:] = 3
