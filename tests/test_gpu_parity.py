@@ -2065,3 +2065,24 @@ def test_tokeniser_to_kernel_on_the_gpu_box(native, port):
     f.compute_kernel_flat(toks, offs, 1)
     assert np.array_equal(f.get_train_kernel_np(), tri_to_square(tri, 2)[:1, :1])
     assert np.array_equal(f.get_test_kernel_np(), tri_to_square(tri, 2)[1:, :1])
+
+
+def test_variance_mode_descriptors_two_lds_rounds(native, port, monkeypatch):
+    """Variance mode (the by-slot form of k_sx_consume: one u16 / u32 triangle a slot) on owner bands of TWO LDS rounds with
+    descriptors forced: N = 4500 sequences over 400 keys (runs of ~100 entries), six iterations — kernel and stdevs against the
+    oracle, with and without descriptors."""
+    rng = np.random.default_rng(8)
+    N, g, m = 4500, 4, 2
+    X = [rng.integers(1, 21, size=int(L)).astype(np.int32) for L in rng.integers(8, 12, size=N)]
+    X[3][:] = 2
+    tokens, offsets = native.flatten(X)
+    order = rng.permutation(port.num_combos(g, m)).astype(np.int32)
+    want, sd, _ = port.compute(tokens, offsets, 3000, 1500, g, m, t=1, approx=True, delta=1e-9, max_iters=6, order=order)
+    for desc in (1, -1):
+        set_tuning_env(monkeypatch, sparse_desc=desc, sparse_desc_min=5, sparse_form=1)
+        e = native.Engine(g, m, t=1, approx=True, delta=1e-9, max_iters=6, path=2)
+        e.set_combo_order(order)
+        e.compute(tokens, offsets, 3000, 1500)
+        assert e.stats()["sparse_desc"] == (desc > 0)
+        assert np.array_equal(e.get_stdevs(), sd) and np.array_equal(e.get_triangle(), want), desc
+        e.close()
