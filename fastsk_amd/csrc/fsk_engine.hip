@@ -191,14 +191,31 @@ bool dense_is_cheaper(const fsk_engine* e) {
     // (tile kernel: 3.0e14 count-MAC/s with thousands of tiles, ~2.4e14 with few)
     const double dense = 0.5 * N * N * (double)(((e->Vq + 1) / 2) * 8) / (N < 8192.0 ? 2.4e14 : 3.0e14) +
                          (double)e->nfeat * (1e-12 + (sweeps - 1.0) * sweep_cost) + N * V * 7e-13;
-    // sparse: sort + segments per g-mer, then one update per (run, pair). d = sequences holding a
-    // given key. Update streams summed in LDS by the owner bands (N up to ~23,000): 1.7e11 updates/s
-    // through emit + consume, a band with several LDS rounds re-reads its stream once per round;
-    // per-pair global atomics beyond that: 1.6e10/s. Extraction + sort + segments: 3.1e-11 s per g-mer.
+    // sparse: sort + segments per g-mer (3.1e-11 s each), then one update per (run, pair). d = sequences holding a given key.
+    // SHORT runs — update words through emit + consume: 1.7e11 updates/s on owner bands of one LDS round, a band of several
+    // rounds re-reads its stream once per round; beyond four rounds the two-level blocks, ~1.0e11/s (N = 100k: 9.3e10); where
+    // neither exists per-pair global atomics, 1.6e10/s. LONG runs (12 += a sort record and more, i.e. d >= ~24) — DESCRIPTORS,
+    // bands of one round or blocks: the longer the run the cheaper a pair (a descriptor's fixed cost, then four partners a
+    // 16-byte load): 2.2e12 d / (d + 300) updates/s fits profiles/dense_vs_sparse_regimes.jsonl (DNA k = 4 .. 7, N = 4000 and
+    // 16000: 0.2e12 at d = 22, 0.5 at 88, 1.2 at 300, 1.6 at 1000, 2.0 at 2700) within a fifth. The blocks sweep K once a batch
+    // (16 B a cell at ~5 TB/s, a batch = 2^27 records). The approx modes' variance form (slot triangles, owner bands only)
+    // does not have the blocks and expands a slot's few descriptors in workgroups of their own: priced as the word streams.
     const double d = N * (1.0 - std::exp(-W / V));
     const double U = V * d * (d + 1.0) / 2.0;
-    const double rate = e->sx_lists ? 1.7e11 / (1.0 + 0.3 * ((double)e->sx_rounds - 1.0)) : 1.6e10;
-    const double sparse = U / rate + (double)e->nfeat * 3.1e-11;
+    const bool variance_form = e->cfg.approx && !e->cfg.skip_variance;
+    const bool blocks_ok = !variance_form && blocks_plan_pass(const_cast<fsk_engine*>(e), 0, e->N, nullptr);
+    const bool bands_few_rounds = e->sx_lists && e->sx_rounds <= 4;
+    double rate = bands_few_rounds ? 1.7e11 / (1.0 + 0.3 * ((double)e->sx_rounds - 1.0))
+                  : blocks_ok      ? 1.0e11
+                  : e->sx_lists    ? 1.7e11 / (1.0 + 0.3 * ((double)e->sx_rounds - 1.0))
+                                   : 1.6e10;
+    const bool descriptors = !variance_form && e->tune.sparse_desc >= 0 && d >= 24.0 && ((e->sx_lists && e->sx_rounds <= 1) || blocks_ok);
+    if (descriptors) rate = std::max(rate, 2.2e12 * d / (d + 300.0));
+    double sparse = U / rate + (double)e->nfeat * 3.1e-11;
+    if (!bands_few_rounds && blocks_ok) {
+        const double per_batch = std::max(1.0, std::floor((double)SPARSE_MAX_RECORDS / std::max(1.0, (double)e->nfeat)));
+        sparse += 0.5 * N * N * 16.0 / 5e12 / per_batch;
+    }
     return dense <= sparse;
 }
 
