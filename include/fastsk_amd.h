@@ -54,8 +54,11 @@ enum {
     FSK_PATH_SPARSE = 2  /* the reference's dataflow (cntsrtna + countAndUpdateTri) as streams: packed
                             (k-mer, seq) records -> LSD radix sort in LDS-staged passes -> run-length
                             entries -> one 32-bit update word per += binned by owner band of K -> the
-                            band's words summed in LDS, one 64-bit add per touched cell; 64-bit
-                            atomicAdd per (run, pair) only when no band of K fits LDS (N > ~23,000)   */
+                            band's words summed in LDS, one 64-bit add per touched cell; beyond a few
+                            LDS rounds a band (N > ~9,000) K is owned in two levels (bands, then blocks of
+                            2^14 cells); where runs are long an entry of many partners travels as one
+                            16-byte descriptor that the owning workgroup expands itself; a 64-bit
+                            atomicAdd per (run, pair) only on request or for sequences in the millions   */
 };
 
 /* how the engines of fsk_create_multi sum their partial triangles (fastsk_kernel.cpp:286-315) */
